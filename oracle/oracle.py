@@ -1,0 +1,308 @@
+"""ctypes front-end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It wraps
+
+  * oracle/liboracle.so      -- plain-C restatement of the hot path (cup2d_oracle.c)
+  * oracle/_ref/ref_harness  -- the reference's own main.cpp, compiled where it lies
+                                under /root/reference (ref_harness.cpp), run as a subprocess
+
+Arrays are global row-major float64: scalar (ny, nx), vector (ny, nx, 2).
+"""
+import ctypes
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    """(Re)build liboracle.so and, when /root/reference exists, oracle/_ref/ref_harness."""
+    if force or not os.path.exists(LIB_PATH) or (
+        os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "cup2d_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.oracle_compute_dt.restype = ctypes.c_double
+        _lib.oracle_max_abs.restype = ctypes.c_double
+        _lib.oracle_step.restype = ctypes.c_double
+        _lib.oracle_weno5_plus.restype = ctypes.c_double
+        _lib.oracle_weno5_minus.restype = ctypes.c_double
+        _lib.oracle_derivative.restype = ctypes.c_double
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def P_inv():
+    P = np.empty((64, 64))
+    lib().oracle_P_inv(_p(P))
+    return P
+
+
+def advect_diffuse_rhs(vel, h, nu, dt):
+    vel = _c(vel)
+    ny, nx, _ = vel.shape
+    out = np.empty_like(vel)
+    lib().oracle_advect_diffuse_rhs(nx, ny, ctypes.c_double(h), ctypes.c_double(nu), ctypes.c_double(dt), _p(vel), _p(out))
+    return out
+
+
+def rk2_advect_diffuse(vel, h, nu, dt):
+    """returns (vel_new, stage1)"""
+    v = _c(vel).copy()
+    ny, nx, _ = v.shape
+    s1 = np.empty_like(v)
+    lib().oracle_rk2_advect_diffuse(nx, ny, ctypes.c_double(h), ctypes.c_double(nu), ctypes.c_double(dt), _p(v), _p(s1))
+    return v, s1
+
+
+def vorticity(vel, h):
+    vel = _c(vel)
+    ny, nx, _ = vel.shape
+    out = np.empty((ny, nx))
+    lib().oracle_vorticity(nx, ny, ctypes.c_double(h), _p(vel), _p(out))
+    return out
+
+
+def pressure_rhs(vel, h, dt, udef=None, chi=None):
+    vel = _c(vel)
+    ny, nx, _ = vel.shape
+    out = np.empty((ny, nx))
+    ud = _c(udef) if udef is not None else None
+    ch = _c(chi) if chi is not None else None
+    lib().oracle_pressure_rhs(nx, ny, ctypes.c_double(h), ctypes.c_double(dt), _p(vel),
+                              _p(ud) if ud is not None else None, _p(ch) if ch is not None else None, _p(out))
+    return out
+
+
+def laplacian_sub(p, tmp):
+    """returns tmp - Lap5(p) (Neumann ghosts)"""
+    p = _c(p)
+    t = _c(tmp).copy()
+    ny, nx = p.shape
+    lib().oracle_laplacian_sub(nx, ny, _p(p), _p(t))
+    return t
+
+
+def apply_A(x):
+    x = _c(x)
+    ny, nx = x.shape
+    y = np.empty_like(x)
+    lib().oracle_apply_A(nx, ny, _p(x), _p(y))
+    return y
+
+
+def precond(x, P=None):
+    x = _c(x)
+    ny, nx = x.shape
+    P = P_inv() if P is None else _c(P)
+    y = np.empty_like(x)
+    lib().oracle_precond(nx, ny, _p(P), _p(x), _p(y))
+    return y
+
+
+def pressure_correction(pres, h, dt):
+    pres = _c(pres)
+    ny, nx = pres.shape
+    out = np.empty((ny, nx, 2))
+    lib().oracle_pressure_correction(nx, ny, ctypes.c_double(h), ctypes.c_double(dt), _p(pres), _p(out))
+    return out
+
+
+def add_scaled(vel, tmpV, h):
+    v = _c(vel).copy()
+    ny, nx, _ = v.shape
+    lib().oracle_add_scaled(nx, ny, ctypes.c_double(h), _p(_c(tmpV)), _p(v))
+    return v
+
+
+def compute_dt(h, nu, cfl, umax):
+    return lib().oracle_compute_dt(ctypes.c_double(h), ctypes.c_double(nu), ctypes.c_double(cfl), ctypes.c_double(umax))
+
+
+def bicgstab(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000, P=None):
+    """returns (x_opt, dict(iters, restarts, err, err_init))"""
+    b = _c(b)
+    ny, nx = b.shape
+    x = np.zeros_like(b) if x0 is None else _c(x0).copy()
+    P = P_inv() if P is None else _c(P)
+    info = np.zeros(4)
+    lib().oracle_bicgstab(nx, ny, _p(P), _p(b), _p(x), ctypes.c_double(tol), ctypes.c_double(rel_tol),
+                          int(max_restarts), int(max_iter), _p(info))
+    return x, dict(iters=int(info[0]), restarts=int(info[1]), err=info[2], err_init=info[3])
+
+
+def pressure_update(x, pold, h):
+    x = _c(x)
+    ny, nx = x.shape
+    out = np.empty_like(x)
+    lib().oracle_pressure_update(nx, ny, ctypes.c_double(h), _p(x), _p(_c(pold)), _p(out))
+    return out
+
+
+def step(vel, pres, h, nu, cfl, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000, P=None):
+    """one body-free time step (main.cpp:6576-7187). returns (vel, pres, dt, info)"""
+    v = _c(vel).copy()
+    p = _c(pres).copy()
+    ny, nx = p.shape
+    P = P_inv() if P is None else _c(P)
+    info = np.zeros(4)
+    dt = lib().oracle_step(nx, ny, ctypes.c_double(h), ctypes.c_double(nu), ctypes.c_double(cfl), _p(P), _p(v), _p(p),
+                           ctypes.c_double(tol), ctypes.c_double(rel_tol), int(max_restarts), int(max_iter), _p(info))
+    return v, p, dt, dict(iters=int(info[0]), restarts=int(info[1]), err=info[2], err_init=info[3])
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic inputs shared by oracle, tests and bench
+# ----------------------------------------------------------------------------------------------
+def taylor_green(n, noise=1e-3, seed=20250117, ny=None):
+    """u = sin(2 pi x) cos(2 pi y), v = -cos(2 pi x) sin(2 pi y) at cell centres of the unit
+    square (h = 1/n) plus uniform noise; returns (ny, nx, 2) float64."""
+    nx = n
+    ny = n if ny is None else ny
+    h = 1.0 / max(nx, ny)
+    x = (np.arange(nx) + 0.5) * h
+    y = (np.arange(ny) + 0.5) * h
+    X, Y = np.meshgrid(x, y, indexing="xy")
+    rng = np.random.default_rng(seed)
+    u = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+    v = -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+    vel = np.stack([u, v], axis=-1)
+    if noise:
+        vel = vel + noise * rng.uniform(-1.0, 1.0, vel.shape)
+    return np.ascontiguousarray(vel)
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference itself (oracle/_ref/ref_harness)
+# ----------------------------------------------------------------------------------------------
+def have_reference():
+    return os.path.exists(REF_HARNESS) and os.access(REF_HARNESS, os.X_OK)
+
+
+def _level(n):
+    lv = int(round(np.log2(n // 8)))
+    assert 8 << lv == n, "reference harness grids are 8*2^k square"
+    return lv
+
+
+def _run_ref(mode, n, d, **kw):
+    cmd = [REF_HARNESS, mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
+    env = dict(os.environ)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("ref_harness failed (%d): %s" % (r.returncode, r.stderr.decode()[-2000:]))
+    return r.stdout.decode()
+
+
+def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
+    """Run every hot-path block functor of the reference on the given fields.
+    Returns dict of arrays (see ref_harness.cpp 'functors')."""
+    vel = _c(vel)
+    n = vel.shape[0]
+    assert vel.shape == (n, n, 2)
+    with tempfile.TemporaryDirectory() as d:
+        vel.tofile(os.path.join(d, "vel.in"))
+        if pres is not None:
+            _c(pres).tofile(os.path.join(d, "pres.in"))
+        if chi is not None:
+            _c(chi).tofile(os.path.join(d, "chi.in"))
+        if udef is not None:
+            _c(udef).tofile(os.path.join(d, "udef.in"))
+        kw = dict(nu=float(nu))
+        if dt is not None:
+            kw["dt"] = float(dt)
+        _run_ref("functors", n, d, **kw)
+        out = {}
+        for name, dim in [("advdiff_rhs", 2), ("rk2_stage1", 2), ("rk2_vel", 2), ("vorticity", 1), ("pressure_rhs", 1),
+                          ("poisson_b", 1), ("pgrad_tmpV", 2), ("projected_vel", 2)]:
+            a = np.fromfile(os.path.join(d, name + ".out"))
+            out[name] = a.reshape(n, n, 2) if dim == 2 else a.reshape(n, n)
+        s = np.fromfile(os.path.join(d, "scalars.out"))
+        out["dt_ref"], out["umax"], out["h"], out["dt"] = s
+        out["block_order"] = np.fromfile(os.path.join(d, "block_order.out")).reshape(-1, 2).astype(np.int64)
+    return out
+
+
+def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None):
+    """BiCGSTAB (CPU port of cuda.cu) on the matrix the reference assembles; also returns A*x0."""
+    b = _c(b)
+    n = b.shape[0]
+    with tempfile.TemporaryDirectory() as d:
+        b.tofile(os.path.join(d, "b.in"))
+        if x0 is not None:
+            _c(x0).tofile(os.path.join(d, "x0.in"))
+        kw = dict(tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
+        if max_iter is not None:
+            kw["maxiter"] = int(max_iter)
+        _run_ref("solve", n, d, **kw)
+        x = np.fromfile(os.path.join(d, "x.out")).reshape(n, n)
+        ax0 = np.fromfile(os.path.join(d, "Ax0.out")).reshape(n, n)
+        s = np.fromfile(os.path.join(d, "solve_scalars.out"))
+    return x, ax0, dict(iters=int(s[0]), err=s[1], err_init=s[2], restarts=int(s[3]), seconds=s[4])
+
+
+def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None):
+    """The reference's own time loop (main.cpp:6576-7290) from the IC vel0 for `steps` steps."""
+    vel0 = _c(vel0)
+    n = vel0.shape[0]
+    d = keep or tempfile.mkdtemp()
+    vel0.tofile(os.path.join(d, "vel.in"))
+    kw = dict(nu=float(nu), cfl=float(cfl), steps=int(steps), tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
+    if max_iter is not None:
+        kw["maxiter"] = int(max_iter)
+    _run_ref("run", n, d, **kw)
+    out = dict(vel=np.fromfile(os.path.join(d, "vel.final")).reshape(n, n, 2),
+               pres=np.fromfile(os.path.join(d, "pres.final")).reshape(n, n), steps=[])
+    meta = open(os.path.join(d, "meta.txt")).read().strip().split("\n")
+    for line in meta:
+        t = line.split()
+        if t[0] == "step":
+            k = int(t[1])
+            out["steps"].append(dict(step=k, dt=float(t[3]), time=float(t[5]),
+                                     vel_adv=np.fromfile(os.path.join(d, "vel_adv.%d" % k)).reshape(n, n, 2),
+                                     b=np.fromfile(os.path.join(d, "b.%d" % k)).reshape(n, n),
+                                     pold=np.fromfile(os.path.join(d, "pold.%d" % k)).reshape(n, n)))
+        else:
+            out["final"] = dict(iters=int(t[2]), err=float(t[4]), time=float(t[10]), nsteps=int(t[12]))
+    if keep is None:
+        import shutil
+        shutil.rmtree(d)
+    return out
+
+
+def ref_bench(n, reps=10, vel=None, dt=1e-4, threads=None):
+    """Time the reference functors (OpenMP) -- CPU baseline, kind='reference'."""
+    import json
+    if vel is None:
+        vel = taylor_green(n)
+    with tempfile.TemporaryDirectory() as d:
+        _c(vel).tofile(os.path.join(d, "vel.in"))
+        if threads:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        txt = _run_ref("bench", n, d, reps=int(reps), dt=float(dt))
+    return json.loads(txt.strip().split("\n")[-1])

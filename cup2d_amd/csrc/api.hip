@@ -1,0 +1,491 @@
+// api.hip -- the extern "C" surface declared in include/cup2d_hip.h
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "ctx.h"
+
+namespace cup2d {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+// Block-Jacobi preconditioner P_inv = -(A_loc)^-1, A_loc = 64x64 in-block Dirichlet 5-point
+// Laplacian (4 on the diagonal, -1 towards in-block neighbours): what main.cpp:46-57 + 6451-6488
+// build with a Cholesky factorisation.  Here: A = L L^T, then columns of A^-1 by two triangular
+// solves.
+static void build_P_inv(std::vector<double> &P) {
+  const int N = BC;
+  std::vector<double> A(N * N, 0.0), L(N * N, 0.0);
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < N; j++) {
+      const int dx = abs(i % BS - j % BS), dy = abs(i / BS - j / BS);
+      A[i * N + j] = (dx + dy == 0) ? 4.0 : (dx + dy == 1 ? -1.0 : 0.0);
+    }
+  for (int j = 0; j < N; j++) {
+    double d = A[j * N + j];
+    for (int k = 0; k < j; k++) d -= L[j * N + k] * L[j * N + k];
+    L[j * N + j] = sqrt(d);
+    for (int i = j + 1; i < N; i++) {
+      double s = A[i * N + j];
+      for (int k = 0; k < j; k++) s -= L[i * N + k] * L[j * N + k];
+      L[i * N + j] = s / L[j * N + j];
+    }
+  }
+  P.assign(N * N, 0.0);
+  std::vector<double> y(N), x(N);
+  for (int col = 0; col < N; col++) {
+    for (int i = 0; i < N; i++) {  // L y = e_col
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = 0; k < i; k++) s -= L[i * N + k] * y[k];
+      y[i] = s / L[i * N + i];
+    }
+    for (int i = N - 1; i >= 0; i--) {  // L^T x = y
+      double s = y[i];
+      for (int k = i + 1; k < N; k++) s -= L[k * N + i] * x[k];
+      x[i] = s / L[i * N + i];
+    }
+    for (int i = 0; i < N; i++) P[i * N + col] = -x[i];
+  }
+  // symmetrise exactly: kernels read P[j][i] for row i
+  for (int i = 0; i < N; i++)
+    for (int j = i + 1; j < N; j++) {
+      const double m = 0.5 * (P[i * N + j] + P[j * N + i]);
+      P[i * N + j] = P[j * N + i] = m;
+    }
+}
+
+static size_t slab_doubles(const cup2d_ctx *c, int dim) { return (size_t)c->ntotal * BC * dim; }
+
+int prof_resolve(cup2d_ctx *c) {
+  if (c->prof_used == 0) return CUP2D_OK;
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->prof_used; k++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]) == hipSuccess) {
+      c->t_ms[c->prof_id[k]] += ms;
+      c->t_calls[c->prof_id[k]]++;
+    }
+  }
+  c->prof_used = 0;
+  return CUP2D_OK;
+}
+
+}  // namespace cup2d
+
+using namespace cup2d;
+
+extern "C" {
+
+const char *cup2d_last_error(void) { return g_err; }
+const char *cup2d_version(void) { return "cup2d_hip 0.1 (gfx950)"; }
+
+int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const int32_t *nbr, double h, int device) {
+  if (!out || nblocks <= 0 || nghost < 0 || !nbr || !(h > 0) || n_inner < 0 || n_inner > nblocks) {
+    set_error("cup2d_create: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  for (int i = 0; i < 4 * nblocks; i++)
+    if (nbr[i] < CUP2D_WALL || nbr[i] >= nblocks + nghost) {
+      set_error("cup2d_create: nbr[%d] = %d out of range", i, nbr[i]);
+      return CUP2D_ERR_ARG;
+    }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("cup2d_create: no HIP device visible");
+    return CUP2D_ERR_NODEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("cup2d_create: device %d of %d", device, ndev);
+    return CUP2D_ERR_ARG;
+  }
+  CUP2D_HIP_CHECK(hipSetDevice(device));
+  cup2d_ctx *c = new cup2d_ctx;
+  c->device = device;
+  c->nblocks = nblocks;
+  c->nghost = nghost;
+  c->ntotal = nblocks + nghost;
+  c->n_inner = n_inner;
+  c->h = h;
+  c->grid = MAX_GRID;
+  CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
+  CUP2D_HIP_CHECK(hipMemcpy(c->d_nbr, nbr, sizeof(int32_t) * 4 * nblocks, hipMemcpyHostToDevice));
+  for (int f = 0; f < CUP2D_NFIELDS; f++) {
+    const size_t bytes = slab_doubles(c, dim_of(f)) * sizeof(double);
+    CUP2D_HIP_CHECK(hipMalloc(&c->d_field[f], bytes));
+    CUP2D_HIP_CHECK(hipMemset(c->d_field[f], 0, bytes));  // calloc, main.cpp:6517
+  }
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_vscratch, slab_doubles(c, 2) * sizeof(double)));
+  CUP2D_HIP_CHECK(hipMemset(c->d_vscratch, 0, slab_doubles(c, 2) * sizeof(double)));
+  double **kv[] = {&c->d_r, &c->d_rhat, &c->d_p, &c->d_nu, &c->d_t, &c->d_z, &c->d_z2, &c->d_xopt};
+  for (double **p : kv) {
+    CUP2D_HIP_CHECK(hipMalloc(p, slab_doubles(c, 1) * sizeof(double)));
+    CUP2D_HIP_CHECK(hipMemset(*p, 0, slab_doubles(c, 1) * sizeof(double)));
+  }
+  build_P_inv(c->h_Pinv);
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_Pinv, BC * BC * sizeof(double)));
+  CUP2D_HIP_CHECK(hipMemcpy(c->d_Pinv, c->h_Pinv.data(), BC * BC * sizeof(double), hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * MAX_GRID));
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_red, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_sc, sizeof(KrylovScalars)));
+  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
+  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
+  *out = c;
+  return CUP2D_OK;
+}
+
+void cup2d_destroy(cup2d_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->d_nbr);
+  for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
+  (void)hipFree(c->d_vscratch);
+  double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_partials, c->d_red};
+  for (double *p : kv) (void)hipFree(p);
+  (void)hipFree(c->d_sc);
+  (void)hipHostFree(c->h_sc);
+  (void)hipHostFree(c->h_red);
+  (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
+  (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
+  for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int cup2d_set_stream(cup2d_ctx *c, void *s) {
+  CUP2D_CHECK_CTX(c);
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return CUP2D_OK;
+}
+int cup2d_get_stream(cup2d_ctx *c, void **s) {
+  CUP2D_CHECK_CTX(c);
+  if (!s) return CUP2D_ERR_ARG;
+  *s = (void *)c->stream;
+  return CUP2D_OK;
+}
+int cup2d_synchronize(cup2d_ctx *c) {
+  CUP2D_CHECK_CTX(c);
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
+int cup2d_set_math(cup2d_ctx *c, int math) {
+  CUP2D_CHECK_CTX(c);
+  if (math != CUP2D_MATH_FAST && math != CUP2D_MATH_STRICT) { set_error("bad math mode %d", math); return CUP2D_ERR_ARG; }
+  c->math = math;
+  return CUP2D_OK;
+}
+
+#define CHECK_FIELD(f)                                                   \
+  if (!field_ok(f)) { set_error("%s: bad field %d", __func__, f); return CUP2D_ERR_ARG; }
+
+int cup2d_upload(cup2d_ctx *c, int field, const double *const *blocks) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!blocks) return CUP2D_ERR_ARG;
+  const size_t per = (size_t)BC * dim_of(field);
+  std::vector<double> stage((size_t)c->nblocks * per);
+  for (int b = 0; b < c->nblocks; b++) memcpy(&stage[b * per], blocks[b], per * sizeof(double));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[field], stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
+int cup2d_download(cup2d_ctx *c, int field, double *const *blocks) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!blocks) return CUP2D_ERR_ARG;
+  const size_t per = (size_t)BC * dim_of(field);
+  std::vector<double> stage((size_t)c->nblocks * per);
+  CUP2D_HIP_CHECK(hipMemcpyAsync(stage.data(), c->d_field[field], stage.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int b = 0; b < c->nblocks; b++) memcpy(blocks[b], &stage[b * per], per * sizeof(double));
+  return CUP2D_OK;
+}
+int cup2d_upload_slab(cup2d_ctx *c, int field, const double *slab) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!slab) return CUP2D_ERR_ARG;
+  const size_t bytes = (size_t)c->nblocks * BC * dim_of(field) * sizeof(double);
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[field], slab, bytes, hipMemcpyHostToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
+int cup2d_download_slab(cup2d_ctx *c, int field, double *slab) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!slab) return CUP2D_ERR_ARG;
+  const size_t bytes = (size_t)c->nblocks * BC * dim_of(field) * sizeof(double);
+  CUP2D_HIP_CHECK(hipMemcpyAsync(slab, c->d_field[field], bytes, hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
+int cup2d_field_ptr(cup2d_ctx *c, int field, void **p) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!p) return CUP2D_ERR_ARG;
+  *p = c->d_field[field];
+  return CUP2D_OK;
+}
+__global__ void k_fill(double *p, double v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int cup2d_fill(cup2d_ctx *c, int field, double value) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  const size_t n = slab_doubles(c, dim_of(field));
+  if (value == 0.0) {
+    CUP2D_HIP_CHECK(hipMemsetAsync(c->d_field[field], 0, n * sizeof(double), c->stream));
+  } else {
+    hipLaunchKernelGGL(k_fill, dim3(c->grid), dim3(WG), 0, c->stream, c->d_field[field], value, n);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  return CUP2D_OK;
+}
+int cup2d_copy_field(cup2d_ctx *c, int dst, int src) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(dst);
+  CHECK_FIELD(src);
+  if (dim_of(dst) != dim_of(src)) { set_error("copy_field: dim mismatch"); return CUP2D_ERR_ARG; }
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[dst], c->d_field[src], slab_doubles(c, dim_of(src)) * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c->stream));
+  return CUP2D_OK;
+}
+
+// ---- block operators --------------------------------------------------------------------------
+int cup2d_advect_diffuse_rhs(cup2d_ctx *c, double nu, double dt, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  return launch_advect(c, c->d_field[CUP2D_VEL], nullptr, c->d_field[CUP2D_TMPV], 0, nu, dt, 0.0, first, count);
+}
+int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  const double ih2 = 1.0 / (c->h * c->h);
+  if (stage == 1)  // main.cpp:6616-6626: mid = vel + (0.5/h^2) rhs(vel)
+    return launch_advect(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_VEL], c->d_vscratch, 1, nu, dt, 0.5 / (c->h * c->h),
+                         first, count);
+  if (stage == 2)  // main.cpp:6632-6642: vel = vold + (1/h^2) rhs(mid); vold is the unmodified vel
+    return launch_advect(c, c->d_vscratch, c->d_field[CUP2D_VEL], c->d_field[CUP2D_VEL], 1, nu, dt, ih2, first, count);
+  set_error("advect_diffuse_stage: stage %d", stage);
+  return CUP2D_ERR_ARG;
+}
+int cup2d_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
+  CUP2D_CHECK_CTX(c);
+  CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 3));
+  CUP2D_TRY(cup2d_advect_diffuse_stage(c, nu, dt, 1, CUP2D_BLOCKS_ALL));
+  CUP2D_TRY(exchange_halo(c, c->d_vscratch, 2, 3));
+  return cup2d_advect_diffuse_stage(c, nu, dt, 2, CUP2D_BLOCKS_ALL);
+}
+int cup2d_vorticity(cup2d_ctx *c, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  return launch_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP], first, count);
+}
+int cup2d_pressure_rhs(cup2d_ctx *c, double dt, int use_bodies, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  if (!(dt > 0)) { set_error("pressure_rhs: dt"); return CUP2D_ERR_ARG; }
+  return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
+                             use_bodies ? c->d_field[CUP2D_CHI] : nullptr, nullptr, c->d_field[CUP2D_TMP], dt, first, count);
+}
+int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  return launch_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1, first, count);
+}
+int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
+  CUP2D_CHECK_CTX(c);
+  if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
+  // pold = pres; pres = 0 (main.cpp:7016-7021) as a pointer swap + memset
+  double *tmp = c->d_field[CUP2D_POLD];
+  c->d_field[CUP2D_POLD] = c->d_field[CUP2D_PRES];
+  c->d_field[CUP2D_PRES] = tmp;
+  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_field[CUP2D_PRES], 0, slab_doubles(c, 1) * sizeof(double), c->stream));
+  CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
+  CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_POLD], 1, 1));
+  if (use_bodies) CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_TMPV], 2, 1));
+  return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
+                             use_bodies ? c->d_field[CUP2D_CHI] : nullptr, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], dt,
+                             0, c->nblocks);
+}
+int cup2d_pressure_correction(cup2d_ctx *c, double dt, int phase) {
+  CUP2D_CHECK_CTX(c);
+  int first, count;
+  CUP2D_TRY(phase_range(c, phase, &first, &count));
+  return launch_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], nullptr, dt, 0, first, count);
+}
+int cup2d_add_correction(cup2d_ctx *c) {
+  CUP2D_CHECK_CTX(c);
+  return launch_axpy_field(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], 1.0 / c->h / c->h,
+                           (size_t)c->nblocks * BC * 2);
+}
+int cup2d_project(cup2d_ctx *c, double dt) {
+  CUP2D_CHECK_CTX(c);
+  ProfScope t(c, CUP2D_T_PROJECT);
+  return project_impl(c, dt);
+}
+
+// ---- scalars ----------------------------------------------------------------------------------
+int cup2d_max_abs_vel(cup2d_ctx *c, double *umax) {
+  CUP2D_CHECK_CTX(c);
+  if (!umax) return CUP2D_ERR_ARG;
+  CUP2D_TRY(launch_max_abs(c, c->d_field[CUP2D_VEL], (size_t)c->nblocks * BC * 2, c->d_red));
+  if (c->allreduce && c->allreduce(c->comm_user, c->d_red, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_red, c->d_red, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  *umax = c->h_red[0];
+  return CUP2D_OK;
+}
+int cup2d_compute_dt(cup2d_ctx *c, double nu, double cfl, double *dt) {
+  CUP2D_CHECK_CTX(c);
+  if (!dt) return CUP2D_ERR_ARG;
+  double umax = 0;
+  CUP2D_TRY(cup2d_max_abs_vel(c, &umax));
+  const double h = c->h;  // uniform level: min h == h (main.cpp:6580-6583)
+  const double dtDiffusion = 0.25 * h * h / (nu + 0.25 * h * umax);
+  const double dtAdvection = h / (umax + 1e-8);
+  *dt = fmin(dtDiffusion, cfl * dtAdvection);
+  return CUP2D_OK;
+}
+
+// ---- Poisson ----------------------------------------------------------------------------------
+int cup2d_poisson_solve(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
+                        int *restarts, double *linf, double *linf_init) {
+  CUP2D_CHECK_CTX(c);
+  if (max_iter < 0) { set_error("poisson_solve: max_iter"); return CUP2D_ERR_ARG; }
+  return solve_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
+}
+static bool scalar_field(int f) { return field_ok(f) && dim_of(f) == 1; }
+int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {
+  CUP2D_CHECK_CTX(c);
+  if (!scalar_field(dst) || !scalar_field(src) || dst == src) { set_error("apply_A: fields"); return CUP2D_ERR_ARG; }
+  CUP2D_TRY(exchange_halo(c, c->d_field[src], 1, 1));
+  return launch_laplacian(c, c->d_field[src], c->d_field[dst], 0, 0, c->nblocks);
+}
+int cup2d_precond(cup2d_ctx *c, int dst, int src) {
+  CUP2D_CHECK_CTX(c);
+  if (!scalar_field(dst) || !scalar_field(src)) { set_error("precond: fields"); return CUP2D_ERR_ARG; }
+  return launch_precond(c, c->d_field[src], c->d_field[dst], 0, c->nblocks);
+}
+int cup2d_get_P_inv(cup2d_ctx *c, double *P) {
+  CUP2D_CHECK_CTX(c);
+  if (!P) return CUP2D_ERR_ARG;
+  memcpy(P, c->h_Pinv.data(), BC * BC * sizeof(double));
+  return CUP2D_OK;
+}
+
+// ---- whole step (main.cpp:6576-7187, body-free) -------------------------------------------------
+int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
+               int max_iter, double *dt_out, int *iters, double *linf) {
+  CUP2D_CHECK_CTX(c);
+  double dt = 0;
+  CUP2D_TRY(cup2d_compute_dt(c, nu, cfl, &dt));
+  if (!(dt > 2e-16)) {  // main.cpp:6596
+    if (dt_out) *dt_out = dt;
+    return CUP2D_OK;
+  }
+  CUP2D_TRY(cup2d_advect_diffuse_rk2(c, nu, dt));
+  CUP2D_TRY(cup2d_poisson_rhs(c, dt, 0));
+  CUP2D_TRY(cup2d_poisson_solve(c, max_error, max_rel_error, max_restarts, max_iter, iters, nullptr, linf, nullptr));
+  CUP2D_TRY(cup2d_project(c, dt));
+  if (dt_out) *dt_out = dt;
+  return CUP2D_OK;
+}
+
+// ---- halos -------------------------------------------------------------------------------------
+int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *sf, int nrecv, const int32_t *rb,
+                    const int32_t *rf) {
+  CUP2D_CHECK_CTX(c);
+  if (nsend < 0 || nrecv < 0 || (nsend && (!sb || !sf)) || (nrecv && (!rb || !rf))) return CUP2D_ERR_ARG;
+  for (int i = 0; i < nsend; i++)
+    if (sb[i] < 0 || sb[i] >= c->nblocks || sf[i] < 0 || sf[i] > 3) { set_error("halo_plan: send entry %d", i); return CUP2D_ERR_ARG; }
+  for (int i = 0; i < nrecv; i++)
+    if (rb[i] < c->nblocks || rb[i] >= c->ntotal || rf[i] < 0 || rf[i] > 3) { set_error("halo_plan: recv entry %d", i); return CUP2D_ERR_ARG; }
+  HaloPlan &p = c->plan;
+  (void)hipFree(p.d_send_block); (void)hipFree(p.d_send_face); (void)hipFree(p.d_recv_block); (void)hipFree(p.d_recv_face);
+  p = HaloPlan();
+  p.nsend = nsend; p.nrecv = nrecv;
+  if (nsend) {
+    CUP2D_HIP_CHECK(hipMalloc(&p.d_send_block, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMalloc(&p.d_send_face, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(p.d_send_block, sb, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMemcpy(p.d_send_face, sf, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (nrecv) {
+    CUP2D_HIP_CHECK(hipMalloc(&p.d_recv_block, nrecv * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMalloc(&p.d_recv_face, nrecv * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_block, rb, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_face, rf, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return CUP2D_OK;
+}
+static bool width_ok(int w) { return w >= 1 && w <= 4; }
+int cup2d_halo_pack(cup2d_ctx *c, int field, int width, double *buf) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!width_ok(width) || (!buf && c->plan.nsend)) return CUP2D_ERR_ARG;
+  return halo_pack_impl(c, c->d_field[field], dim_of(field), width, buf);
+}
+int cup2d_halo_unpack(cup2d_ctx *c, int field, int width, const double *buf) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!width_ok(width) || (!buf && c->plan.nrecv)) return CUP2D_ERR_ARG;
+  return halo_unpack_impl(c, c->d_field[field], dim_of(field), width, buf);
+}
+int cup2d_halo_pack_vec(cup2d_ctx *c, const double *vec, int dim, int width, double *buf) {
+  CUP2D_CHECK_CTX(c);
+  if (!vec || (dim != 1 && dim != 2) || !width_ok(width)) return CUP2D_ERR_ARG;
+  return halo_pack_impl(c, vec, dim, width, buf);
+}
+int cup2d_halo_unpack_vec(cup2d_ctx *c, double *vec, int dim, int width, const double *buf) {
+  CUP2D_CHECK_CTX(c);
+  if (!vec || (dim != 1 && dim != 2) || !width_ok(width)) return CUP2D_ERR_ARG;
+  return halo_unpack_impl(c, vec, dim, width, buf);
+}
+int cup2d_set_comm(cup2d_ctx *c, cup2d_exchange_fn ex, cup2d_allreduce_fn ar, void *user, double *send, double *recv) {
+  CUP2D_CHECK_CTX(c);
+  c->exchange = ex;
+  c->allreduce = ar;
+  c->comm_user = user;
+  c->d_send = send;
+  c->d_recv = recv;
+  return CUP2D_OK;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------------
+int cup2d_set_timing(cup2d_ctx *c, int enabled) {
+  CUP2D_CHECK_CTX(c);
+  if (enabled && c->prof_ev.empty()) {
+    const int pairs = 4096;
+    c->prof_ev.resize(2 * pairs);
+    c->prof_id.resize(pairs);
+    for (auto &e : c->prof_ev) CUP2D_HIP_CHECK(hipEventCreate(&e));
+  }
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->prof_used = 0;
+  c->timing = enabled ? 1 : 0;
+  for (int i = 0; i < CUP2D_T_NTIMERS; i++) { c->t_ms[i] = 0; c->t_calls[i] = 0; }
+  return CUP2D_OK;
+}
+int cup2d_get_timing(cup2d_ctx *c, int timer, double *ms, int *calls) {
+  CUP2D_CHECK_CTX(c);
+  if (timer < 0 || timer >= CUP2D_T_NTIMERS) return CUP2D_ERR_ARG;
+  CUP2D_TRY(prof_resolve(c));
+  if (ms) *ms = c->t_ms[timer];
+  if (calls) *calls = c->t_calls[timer];
+  return CUP2D_OK;
+}
+
+}  // extern "C"

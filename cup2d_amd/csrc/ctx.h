@@ -1,0 +1,166 @@
+// ctx.h -- context object and launch helpers shared by the translation units of libcup2d_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cup2d_hip.h"
+
+namespace cup2d {
+
+constexpr int BS = CUP2D_BS;
+constexpr int BC = BS * BS;        // cells per block = one wavefront
+constexpr int WG = 256;            // threads per workgroup = 4 waves = 4 blocks in flight
+constexpr int WPG = WG / 64;       // waves (= blocks) per workgroup pass
+constexpr int MAX_GRID = 2048;     // persistent grid: 256 CUs x 8 workgroups, multiple of the 8 XCDs
+constexpr int NSLOT = 4;           // reduction slots per launch
+
+void set_error(const char *fmt, ...);
+#define CUP2D_HIP_CHECK(expr)                                                                   \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      cup2d::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));     \
+      return CUP2D_ERR_HIP;                                                                     \
+    }                                                                                           \
+  } while (0)
+#define CUP2D_CHECK_CTX(c)                                   \
+  do {                                                       \
+    if (!(c)) {                                              \
+      cup2d::set_error("%s: null context", __func__);        \
+      return CUP2D_ERR_ARG;                                  \
+    }                                                        \
+    CUP2D_HIP_CHECK(hipSetDevice((c)->device));              \
+  } while (0)
+#define CUP2D_TRY(expr)        \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != CUP2D_OK)        \
+      return _s;               \
+  } while (0)
+
+// device-resident BiCGSTAB state: the reference's BiCGSTABScalars (cuda.cu:24-34) plus the
+// control flow its host loop keeps in local variables (cuda.cu:404-545)
+struct KrylovScalars {
+  double alpha, beta, omega, eps, rho_prev, rho_curr;
+  double rr;         // ||r||^2
+  double rhat2;      // ||rhat||^2 (changes only at a restart)
+  double err, err_init, err_opt;
+  double max_error, max_rel_error;
+  int max_restarts, max_iter;
+  int iter, restarts;
+  int status;        // 0 running, 1 converged, 2 restart limit, 3 iteration cap
+  int restart_flag;  // next p-update must do rhat = r, p = r (cuda.cu:461-476)
+  int x_is_best;     // the iterate held in x is the best so far (cuda.cu:535-538)
+  int pad;
+};
+
+struct HaloPlan {
+  int nsend = 0, nrecv = 0;
+  int32_t *d_send_block = nullptr, *d_send_face = nullptr;
+  int32_t *d_recv_block = nullptr, *d_recv_face = nullptr;
+};
+
+}  // namespace cup2d
+
+struct cup2d_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  int nblocks = 0, nghost = 0, ntotal = 0, n_inner = 0;
+  double h = 0;
+  int math = CUP2D_MATH_FAST;
+  int grid = 0;  // persistent grid size
+  int32_t *d_nbr = nullptr;
+  double *d_field[CUP2D_NFIELDS] = {nullptr};
+  double *d_vscratch = nullptr;  // RK2 mid-point velocity (vector slab)
+  // Krylov vectors (scalar slabs; z/z2 carry ghost blocks)
+  double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_nu = nullptr, *d_t = nullptr;
+  double *d_z = nullptr, *d_z2 = nullptr, *d_xopt = nullptr;
+  double *d_Pinv = nullptr;
+  std::vector<double> h_Pinv;
+  double *d_partials = nullptr;  // [NSLOT][grid]
+  double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
+  cup2d::KrylovScalars *d_sc = nullptr;
+  cup2d::KrylovScalars *h_sc = nullptr;  // pinned
+  double *h_red = nullptr;               // pinned [8]
+  cup2d::HaloPlan plan;
+  // communication callbacks
+  cup2d_exchange_fn exchange = nullptr;
+  cup2d_allreduce_fn allreduce = nullptr;
+  void *comm_user = nullptr;
+  double *d_send = nullptr, *d_recv = nullptr;
+  // timing: pool of event pairs, resolved lazily
+  int timing = 0;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_id;
+  int prof_used = 0;
+  double t_ms[CUP2D_T_NTIMERS] = {0};
+  int t_calls[CUP2D_T_NTIMERS] = {0};
+};
+
+namespace cup2d {
+
+static inline int dim_of(int field) {
+  return (field == CUP2D_VEL || field == CUP2D_VOLD || field == CUP2D_TMPV) ? 2 : 1;
+}
+static inline bool field_ok(int f) { return f >= 0 && f < CUP2D_NFIELDS; }
+
+// block range of a phase (computeA's inner/halo split, main.cpp:3035-3057)
+static inline int phase_range(const cup2d_ctx *c, int phase, int *first, int *count) {
+  switch (phase) {
+  case CUP2D_BLOCKS_ALL: *first = 0; *count = c->nblocks; return CUP2D_OK;
+  case CUP2D_BLOCKS_INNER: *first = 0; *count = c->n_inner; return CUP2D_OK;
+  case CUP2D_BLOCKS_HALO: *first = c->n_inner; *count = c->nblocks - c->n_inner; return CUP2D_OK;
+  }
+  set_error("bad phase %d", phase);
+  return CUP2D_ERR_ARG;
+}
+// persistent grid for `count` blocks: every workgroup loops over groups of WPG blocks
+static inline int grid_for(const cup2d_ctx *c, int count) {
+  int groups = (count + WPG - 1) / WPG;
+  int g = groups < c->grid ? groups : c->grid;
+  if (g >= 8) g -= g % 8;  // equal share per XCD
+  return g < 1 ? 1 : g;
+}
+
+int prof_resolve(cup2d_ctx *c);
+// records an event pair around the launches issued during its lifetime
+struct ProfScope {
+  cup2d_ctx *c;
+  int slot;
+  ProfScope(cup2d_ctx *c_, int id) : c(c_), slot(-1) {
+    if (!c->timing) return;
+    if ((size_t)(2 * c->prof_used + 2) > c->prof_ev.size()) (void)prof_resolve(c);
+    slot = c->prof_used++;
+    c->prof_id[slot] = id;
+    (void)hipEventRecord(c->prof_ev[2 * slot], c->stream);
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], c->stream);
+  }
+};
+
+// implemented in the kernel translation units
+int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *out, int mode, double nu,
+                  double dt, double coef, int first, int count);
+int launch_vorticity(cup2d_ctx *c, const double *vel, double *out, int first, int count);
+int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi,
+                        const double *pold, double *out, double dt, int first, int count);
+int launch_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int first, int count);
+int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double *vel, double dt,
+                               int fused_update, int first, int count);
+int launch_axpy_field(cup2d_ctx *c, double *y, const double *x, double a, size_t n);
+int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out);
+int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
+int project_impl(cup2d_ctx *c, double dt);
+int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,
+               int *iters, int *restarts, double *linf, double *linf_init);
+int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
+int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);
+// exchange ghost strips of a device vector through the comm callback (no-op without ghosts)
+int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
+
+}  // namespace cup2d

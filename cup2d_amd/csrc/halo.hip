@@ -1,0 +1,74 @@
+// halo.hip -- face-halo pack / unpack kernels for a domain-decomposed block grid
+// (sync1 / pack / unpack_subregion, main.cpp:1971-2142, 58-110, same-level faces).
+//
+// A strip is the `width` cell layers of one 8x8 block nearest one of its faces:
+//   face 0 (W): ix in [0,width)      face 1 (E): ix in [8-width,8)
+//   face 2 (S): iy in [0,width)      face 3 (N): iy in [8-width,8)
+// stored as [8 positions along the face][width layers][dim] for W/E and [width][8][dim] for S/N, i.e.
+// in the source block's own (iy, ix) order.  The sender packs strips of owned blocks; the receiver
+// unpacks the same cells into its ghost copy of that block, so every stencil kernel reads owned
+// and ghost neighbours through the one neighbour table.  One thread per double.
+#include "block.h"
+
+namespace cup2d {
+
+static __device__ __forceinline__ int strip_cell(int face, int width, int e) {
+  // e in [0, 8*width): cell index (iy*8+ix) of the e-th strip cell in source-block order
+  if (face < 2) {
+    const int iy = e / width, k = e - iy * width;
+    return iy * BS + (face == 0 ? k : BS - width + k);
+  }
+  const int j = e >> 3, ix = e & 7;
+  return (face == 2 ? j : BS - width + j) * BS + ix;
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(WG) void k_halo(double *__restrict__ field, double *__restrict__ buf,
+                                             const int32_t *__restrict__ blocks, const int32_t *__restrict__ faces,
+                                             int nstrips, int dim, int width) {
+  const int per = BS * width * dim;
+  const size_t total = (size_t)nstrips * per;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const int s = (int)(i / per), q = (int)(i - (size_t)s * per);
+    const int e = q / dim, comp = q - e * dim;
+    const size_t cell = (size_t)blocks[s] * BC + strip_cell(faces[s], width, e);
+    if (PACK) buf[i] = field[cell * dim + comp];
+    else field[cell * dim + comp] = buf[i];
+  }
+}
+
+int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf) {
+  if (c->plan.nsend == 0) return CUP2D_OK;
+  const size_t total = (size_t)c->plan.nsend * BS * width * dim;
+  int grid = (int)((total + WG - 1) / WG);
+  if (grid > c->grid) grid = c->grid;
+  ProfScope prof(c, CUP2D_T_HALO);
+  hipLaunchKernelGGL(k_halo<true>, dim3(grid), dim3(WG), 0, c->stream, const_cast<double *>(src), buf,
+                     c->plan.d_send_block, c->plan.d_send_face, c->plan.nsend, dim, width);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf) {
+  if (c->plan.nrecv == 0) return CUP2D_OK;
+  const size_t total = (size_t)c->plan.nrecv * BS * width * dim;
+  int grid = (int)((total + WG - 1) / WG);
+  if (grid > c->grid) grid = c->grid;
+  ProfScope prof(c, CUP2D_T_HALO);
+  hipLaunchKernelGGL(k_halo<false>, dim3(grid), dim3(WG), 0, c->stream, dst, const_cast<double *>(buf),
+                     c->plan.d_recv_block, c->plan.d_recv_face, c->plan.nrecv, dim, width);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
+// pack -> exchange callback -> unpack, all ordered on the context stream
+int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  CUP2D_TRY(halo_pack_impl(c, vec, dim, width, c->d_send));
+  if (c->exchange(c->comm_user, c->d_send, c->d_recv, BS * width * dim, c->stream) != 0) {
+    set_error("exchange callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  return halo_unpack_impl(c, vec, dim, width, c->d_recv);
+}
+
+}  // namespace cup2d

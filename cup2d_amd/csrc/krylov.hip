@@ -1,0 +1,374 @@
+// krylov.hip -- block-Jacobi preconditioned BiCGSTAB for the pressure Poisson equation, matrix-free
+// on the block grid (SURVEY.md rows a16, a17 and the scalar kernels cuda.cu:303-330).
+//
+// Reference: BiCGSTABSolver::main cuda.cu:403-548.  The reference spends, per iteration, two COO
+// cuSPARSE SpMVs (96 B/row), two cuBLAS DGEMMs, ~17 cuBLAS level-1 passes, four host
+// synchronisations and four MPI_Allreduce.  Here the same recurrences run as FIVE fused sweeps:
+//   A  p = beta*(p - omega*nu) + r ; z = P_inv p                      (cuda.cu:478-486)
+//   B  nu = A z ; partial(rhat.nu)                                     (cuda.cu:487-488)
+//   C  r -= alpha*nu ; z2 = P_inv r                                    (cuda.cu:498-505, x update deferred)
+//   D  t = A z2 ; partial(t.r, t.t)                                    (cuda.cu:506-509)
+//   E  x += alpha*z + omega*z2 ; r -= omega*t ; partial(rhat.r, r.r, max|r|)   (cuda.cu:498, 520-525, 440-442)
+// separated by single-workgroup scalar kernels that finish the reductions and keep alpha, beta,
+// omega, the breakdown/restart logic and the best-iterate bookkeeping ON THE DEVICE; the host
+// reads one small struct per iteration to learn whether to stop.
+#include <string.h>
+
+#include "block.h"
+
+namespace cup2d {
+
+// ---- preconditioner: z_b = P_inv p_b, 64x64 symmetric (cuda.cu:484-486 Dgemm(T,N)) ----------
+// LDS-resident P_inv (32 KiB per workgroup, loaded once per persistent workgroup); lane i
+// accumulates row i: P_inv[j][i] is read with lane-consecutive addresses (conflict-free
+// ds_read_b64), p[j] is a wave-uniform broadcast read.
+static __device__ __forceinline__ void load_Pinv(const double *__restrict__ Pinv, double *sP) {
+  for (int i = threadIdx.x; i < BC * BC; i += WG) sP[i] = Pinv[i];
+  __syncthreads();
+}
+static __device__ __forceinline__ double precond_row(const double *sP, const double *sv, int lane) {
+  double acc = 0.0;
+#pragma unroll 16
+  for (int j = 0; j < BC; j++) acc = __builtin_fma(sP[j * BC + lane], sv[j], acc);
+  return acc;
+}
+
+__global__ __launch_bounds__(WG) void k_precond(const double *__restrict__ in, double *__restrict__ out,
+                                                const double *__restrict__ Pinv, int first, int count) {
+  __shared__ double sP[BC * BC];
+  __shared__ double sv[WPG][BC];
+  load_Pinv(Pinv, sP);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      const size_t o = (size_t)(first + rel) * BC + lane;
+      sv[wave][lane] = in[o];
+      wave_lds_sync();
+      out[o] = precond_row(sP, sv[wave], lane);
+      wave_lds_sync();
+    }
+  }
+}
+int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count) {
+  if (count <= 0) return CUP2D_OK;
+  hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
+// ---- sweep A --------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_sweepA(double *__restrict__ p, const double *__restrict__ nu,
+                                               const double *__restrict__ r, double *__restrict__ rhat,
+                                               double *__restrict__ z, const double *__restrict__ Pinv,
+                                               const KrylovScalars *__restrict__ sc, int count) {
+  __shared__ double sP[BC * BC];
+  __shared__ double sv[WPG][BC];
+  if (sc->status != 0) return;
+  load_Pinv(Pinv, sP);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double beta = sc->beta, momega = -sc->omega;
+  const int restart = sc->restart_flag;
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      const size_t o = (size_t)rel * BC + lane;
+      const double rv = r[o];
+      double pv;
+      if (restart) {  // cuda.cu:461-476: rhat = r, nu = p = 0  =>  p = r
+        rhat[o] = rv;
+        pv = rv;
+      } else {        // cuda.cu:478-483: p += (-omega) nu ; p *= beta ; p += r
+        pv = p[o] + momega * nu[o];
+        pv = pv * beta;
+        pv = pv + rv;
+      }
+      p[o] = pv;
+      sv[wave][lane] = pv;
+      wave_lds_sync();
+      z[o] = precond_row(sP, sv[wave], lane);
+      wave_lds_sync();
+    }
+  }
+}
+
+// ---- sweeps B and D: y = A x with fused dot products -----------------------------------------
+// NDOT = 1: partial(w.y)            (B: w = rhat)
+// NDOT = 2: partial(y.w, y.y)       (D: w = r)
+template <int NDOT>
+__global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, double *__restrict__ y,
+                                                const double *__restrict__ w, const int *__restrict__ nbr,
+                                                const KrylovScalars *__restrict__ sc, double *__restrict__ partials,
+                                                int count) {
+  __shared__ double slabs[WPG][LAB1 * LAB1];
+  if (sc->status != 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *slab = slabs[wave];
+  const int ix = lane & 7, iy = lane >> 3;
+  const int c0 = (iy + 1) * LAB1 + ix + 1;
+  double acc[NDOT];
+#pragma unroll
+  for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      load_scalar_lab1(x, nbr, rel, lane, slab);
+      wave_lds_sync();
+      const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
+      const double yv = l1 + l2 + l3 + l4 - 4 * l0;
+      const size_t o = (size_t)rel * BC + lane;
+      y[o] = yv;
+      const double wv = w[o];
+      acc[0] = __builtin_fma(yv, wv, acc[0]);
+      if constexpr (NDOT == 2) acc[NDOT - 1] = __builtin_fma(yv, yv, acc[NDOT - 1]);
+      wave_lds_sync();
+    }
+  }
+  workgroup_reduce_store<NDOT, false>(acc, partials, 0);
+}
+
+// ---- sweep C ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_sweepC(double *__restrict__ r, const double *__restrict__ nu,
+                                               double *__restrict__ z2, const double *__restrict__ Pinv,
+                                               const KrylovScalars *__restrict__ sc, int count) {
+  __shared__ double sP[BC * BC];
+  __shared__ double sv[WPG][BC];
+  if (sc->status != 0) return;
+  load_Pinv(Pinv, sP);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double malpha = -sc->alpha;
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      const size_t o = (size_t)rel * BC + lane;
+      const double rv = r[o] + malpha * nu[o];  // cuda.cu:499-502
+      r[o] = rv;
+      sv[wave][lane] = rv;
+      wave_lds_sync();
+      z2[o] = precond_row(sP, sv[wave], lane);
+      wave_lds_sync();
+    }
+  }
+}
+
+// ---- sweep E ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_sweepE(double *__restrict__ x, double *__restrict__ xopt,
+                                               const double *__restrict__ z, const double *__restrict__ z2,
+                                               double *__restrict__ r, const double *__restrict__ t,
+                                               const double *__restrict__ rhat, const KrylovScalars *__restrict__ sc,
+                                               double *__restrict__ partials, size_t n) {
+  if (sc->status != 0) return;
+  const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega;
+  const int save = sc->x_is_best;
+  double s[2] = {0.0, 0.0}, m[1] = {0.0};
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    double xv = x[i];
+    if (save) xopt[i] = xv;  // cuda.cu:535-538, deferred: the iterate about to be overwritten was the best
+    xv = xv + alpha * z[i];  // cuda.cu:498
+    xv = xv + omega * z2[i]; // cuda.cu:520
+    x[i] = xv;
+    const double rv = r[i] + momega * t[i];  // cuda.cu:521-524
+    r[i] = rv;
+    s[0] = __builtin_fma(rhat[i], rv, s[0]);
+    s[1] = __builtin_fma(rv, rv, s[1]);
+    m[0] = fmax(m[0], fabs(rv));
+  }
+  workgroup_reduce_store<2, false>(s, partials, 0);
+  workgroup_reduce_store<1, true>(m, partials, 2);
+}
+
+// ---- initial residual: r = b - A x0, rhat = r, partial(r.r, max|r|) (cuda.cu:412-436) ---------
+__global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__ x, const double *__restrict__ b,
+                                                      double *__restrict__ r, double *__restrict__ rhat,
+                                                      const int *__restrict__ nbr, double *__restrict__ partials,
+                                                      int count) {
+  __shared__ double slabs[WPG][LAB1 * LAB1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *slab = slabs[wave];
+  const int ix = lane & 7, iy = lane >> 3;
+  const int c0 = (iy + 1) * LAB1 + ix + 1;
+  double s[1] = {0.0}, m[1] = {0.0};
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      load_scalar_lab1(x, nbr, rel, lane, slab);
+      wave_lds_sync();
+      const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
+      const size_t o = (size_t)rel * BC + lane;
+      const double rv = b[o] - (l1 + l2 + l3 + l4 - 4 * l0);
+      r[o] = rv;
+      rhat[o] = rv;
+      s[0] = __builtin_fma(rv, rv, s[0]);
+      m[0] = fmax(m[0], fabs(rv));
+      wave_lds_sync();
+    }
+  }
+  workgroup_reduce_store<1, false>(s, partials, 0);
+  workgroup_reduce_store<1, true>(m, partials, 2);
+}
+
+// ---- scalar kernels ---------------------------------------------------------------------------
+// finish the per-workgroup partials of slots [0,nsum) (sums) and slot 2 (max) into red[0..2]
+__global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict__ partials, int G, int nsum,
+                                                        int with_max, double *__restrict__ red,
+                                                        const KrylovScalars *__restrict__ sc) {
+  __shared__ double sm[3][WG];
+  if (sc && sc->status != 0) return;
+  double a0 = 0, a1 = 0, mx = 0;
+  for (int i = threadIdx.x; i < G; i += WG) {
+    a0 += partials[i];
+    if (nsum > 1) a1 += partials[G + i];
+    if (with_max) mx = fmax(mx, partials[2 * (size_t)G + i]);
+  }
+  sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = WG / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+      sm[2][threadIdx.x] = fmax(sm[2][threadIdx.x], sm[2][threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { red[0] = sm[0][0]; red[1] = sm[1][0]; red[2] = sm[2][0]; }
+}
+
+// beginning of an iteration (cuda.cu:440-477): consumes rho = rhat.r and ||r||^2
+static __device__ void begin_iteration(KrylovScalars *sc) {
+  if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
+  const bool serious_breakdown = sc->rho_curr * sc->rho_curr < 1e-16 * sc->rr * sc->rhat2;
+  sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta
+  sc->restart_flag = 0;
+  if (serious_breakdown && sc->max_restarts > 0) {
+    sc->restarts++;
+    if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
+    sc->restart_flag = 1;
+    sc->rhat2 = sc->rr;     // rhat = r
+    sc->rho_curr = sc->rr;  // Dnrm2(rhat)^2
+    sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;  // breakdown_update
+    sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
+  }
+}
+// STAGE 0: after k_init_residual  red = {r.r, -, max|r|}
+// STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
+// STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
+// STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
+__global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (stage != 0 && sc->status != 0) return;
+  switch (stage) {
+  case 0:
+    sc->err = sc->err_init = sc->err_opt = red[2];
+    sc->x_is_best = 1;
+    sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
+    begin_iteration(sc);
+    break;
+  case 1:
+    sc->alpha = sc->rho_curr / (red[0] + sc->eps);
+    break;
+  case 2:
+    sc->omega = red[0] / (red[1] + sc->eps);
+    break;
+  case 3:
+    sc->iter++;
+    sc->err = red[2];
+    if (sc->err < sc->err_opt) {
+      sc->err_opt = sc->err;
+      sc->x_is_best = 1;
+      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
+    } else {
+      sc->x_is_best = 0;
+    }
+    sc->rho_prev = sc->rho_curr;  // set_rho
+    sc->rho_curr = red[0];
+    sc->rr = red[1];
+    begin_iteration(sc);
+    break;
+  }
+}
+
+static int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded) {
+  ProfScope prof(c, CUP2D_T_SCALARS);
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(WG), 0, c->stream, c->d_partials, G, nsum, with_max, c->d_red,
+                     guarded ? c->d_sc : nullptr);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  if (c->allreduce) {
+    if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
+    if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+  }
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
+// b = TMP, x0 = PRES, result -> PRES
+int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
+               int *restarts, double *linf, double *linf_init) {
+  const int nb = c->nblocks;
+  const size_t n = (size_t)nb * BC;
+  double *x = c->d_field[CUP2D_PRES];
+  const double *b = c->d_field[CUP2D_TMP];
+  KrylovScalars init;
+  ::memset(&init, 0, sizeof init);
+  init.alpha = init.beta = init.omega = init.rho_prev = init.rho_curr = 1.0;
+  init.eps = 1e-21;  // cuda.cu:409
+  init.err = init.err_init = init.err_opt = 1e50;
+  init.max_error = max_error; init.max_rel_error = max_rel_error;
+  init.max_restarts = max_restarts; init.max_iter = max_iter;
+  *c->h_sc = init;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->h_sc, sizeof init, hipMemcpyHostToDevice, c->stream));
+  const int G = grid_for(c, nb);
+  int gridE = (int)((n + WG - 1) / WG);
+  if (gridE > c->grid) gridE = c->grid;
+
+  CUP2D_TRY(exchange_halo(c, x, 1, 1));
+  hipLaunchKernelGGL(k_init_residual, dim3(G), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                     c->d_partials, nb);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  CUP2D_TRY(finish(c, G, 1, 1, 0, false));
+  // p, nu start at zero (cuda.cu:436-437); status gate: a zero right-hand side converges at once
+  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
+  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
+
+  for (int k = 0; k <= max_iter; k++) {
+    CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
+    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->h_sc->status != 0) break;
+    { ProfScope prof(c, CUP2D_T_SWEEP_A);
+    hipLaunchKernelGGL(k_sweepA, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
+                       c->d_Pinv, c->d_sc, nb); }
+    CUP2D_TRY(exchange_halo(c, c->d_z, 1, 1));
+    { ProfScope prof(c, CUP2D_T_SWEEP_B);
+    hipLaunchKernelGGL(k_sweepBD<1>, dim3(G), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
+                       c->d_partials, nb); }
+    CUP2D_TRY(finish(c, G, 1, 0, 1, true));
+    { ProfScope prof(c, CUP2D_T_SWEEP_C);
+    hipLaunchKernelGGL(k_sweepC, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_Pinv, c->d_sc, nb); }
+    CUP2D_TRY(exchange_halo(c, c->d_z2, 1, 1));
+    { ProfScope prof(c, CUP2D_T_SWEEP_D);
+    hipLaunchKernelGGL(k_sweepBD<2>, dim3(G), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
+                       c->d_partials, nb); }
+    CUP2D_TRY(finish(c, G, 2, 0, 2, true));
+    { ProfScope prof(c, CUP2D_T_SWEEP_E);
+    hipLaunchKernelGGL(k_sweepE, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r, c->d_t,
+                       c->d_rhat, c->d_sc, c->d_partials, n); }
+    CUP2D_HIP_CHECK(hipGetLastError());
+    CUP2D_TRY(finish(c, gridE, 2, 1, 3, true));
+  }
+  // cuda.cu:546-547: return x_opt (with the synchronisation the reference omits)
+  if (!c->h_sc->x_is_best)
+    CUP2D_HIP_CHECK(hipMemcpyAsync(x, c->d_xopt, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (iters) *iters = c->h_sc->iter;
+  if (restarts) *restarts = c->h_sc->restarts;
+  if (linf) *linf = c->h_sc->err_opt;
+  if (linf_init) *linf_init = c->h_sc->err_init;
+  return CUP2D_OK;
+}
+
+}  // namespace cup2d

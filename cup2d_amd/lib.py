@@ -1,0 +1,104 @@
+"""ctypes binding of libcup2d_hip.so (include/cup2d_hip.h).  No compute happens in Python."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# enum mirrors (include/cup2d_hip.h)
+TMP, CHI, VEL, VOLD, PRES, POLD, TMPV = range(7)
+FIELD_DIM = {TMP: 1, CHI: 1, VEL: 2, VOLD: 2, PRES: 1, POLD: 1, TMPV: 2}
+MATH_FAST, MATH_STRICT = 0, 1
+BLOCKS_ALL, BLOCKS_INNER, BLOCKS_HALO = 0, 1, 2
+WALL = -1
+(T_ADVECT_STAGE, T_POISSON_RHS, T_SWEEP_A, T_SWEEP_B, T_SWEEP_C, T_SWEEP_D, T_SWEEP_E, T_SCALARS, T_PROJECT,
+ T_REDUCE, T_HALO) = range(11)
+TIMER_NAMES = ['advect_stage', 'poisson_rhs', 'sweep_A', 'sweep_B', 'sweep_C', 'sweep_D', 'sweep_E', 'scalars', 'project',
+               'reduce', 'halo']
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+# every symbol include/cup2d_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "cup2d_create", "cup2d_destroy", "cup2d_last_error", "cup2d_version", "cup2d_set_stream", "cup2d_get_stream",
+    "cup2d_synchronize", "cup2d_set_math", "cup2d_upload", "cup2d_download", "cup2d_upload_slab",
+    "cup2d_download_slab", "cup2d_field_ptr", "cup2d_fill", "cup2d_copy_field", "cup2d_advect_diffuse_rhs",
+    "cup2d_advect_diffuse_rk2", "cup2d_advect_diffuse_stage", "cup2d_vorticity", "cup2d_pressure_rhs",
+    "cup2d_laplacian_sub", "cup2d_poisson_rhs", "cup2d_pressure_correction", "cup2d_add_correction", "cup2d_project",
+    "cup2d_max_abs_vel", "cup2d_compute_dt", "cup2d_poisson_solve", "cup2d_apply_A", "cup2d_precond",
+    "cup2d_get_P_inv", "cup2d_step", "cup2d_halo_plan", "cup2d_halo_pack", "cup2d_halo_unpack",
+    "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_timing", "cup2d_get_timing",
+]
+
+
+class Cup2dError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libcup2d_hip.so")
+
+
+def load_library():
+    """Load libcup2d_hip.so; raises Cup2dError if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise Cup2dError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(make -C cup2d_amd/csrc). There is no CPU fallback." % path)
+    L = ctypes.CDLL(path)
+    L.cup2d_last_error.restype = ctypes.c_char_p
+    L.cup2d_version.restype = ctypes.c_char_p
+    L.cup2d_destroy.restype = None
+    d = ctypes.c_double
+    vp = ctypes.c_void_p
+    i = ctypes.c_int
+    L.cup2d_create.argtypes = [ctypes.POINTER(vp), i, i, i, vp, d, i]
+    L.cup2d_destroy.argtypes = [vp]
+    L.cup2d_set_stream.argtypes = [vp, vp]
+    L.cup2d_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    L.cup2d_synchronize.argtypes = [vp]
+    L.cup2d_set_math.argtypes = [vp, i]
+    L.cup2d_upload.argtypes = [vp, i, vp]
+    L.cup2d_download.argtypes = [vp, i, vp]
+    L.cup2d_upload_slab.argtypes = [vp, i, vp]
+    L.cup2d_download_slab.argtypes = [vp, i, vp]
+    L.cup2d_field_ptr.argtypes = [vp, i, ctypes.POINTER(vp)]
+    L.cup2d_fill.argtypes = [vp, i, d]
+    L.cup2d_copy_field.argtypes = [vp, i, i]
+    L.cup2d_advect_diffuse_rhs.argtypes = [vp, d, d, i]
+    L.cup2d_advect_diffuse_rk2.argtypes = [vp, d, d]
+    L.cup2d_advect_diffuse_stage.argtypes = [vp, d, d, i, i]
+    L.cup2d_vorticity.argtypes = [vp, i]
+    L.cup2d_pressure_rhs.argtypes = [vp, d, i, i]
+    L.cup2d_laplacian_sub.argtypes = [vp, i]
+    L.cup2d_poisson_rhs.argtypes = [vp, d, i]
+    L.cup2d_pressure_correction.argtypes = [vp, d, i]
+    L.cup2d_add_correction.argtypes = [vp]
+    L.cup2d_project.argtypes = [vp, d]
+    L.cup2d_max_abs_vel.argtypes = [vp, ctypes.POINTER(d)]
+    L.cup2d_compute_dt.argtypes = [vp, d, d, ctypes.POINTER(d)]
+    L.cup2d_poisson_solve.argtypes = [vp, d, d, i, i, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(d), ctypes.POINTER(d)]
+    L.cup2d_apply_A.argtypes = [vp, i, i]
+    L.cup2d_precond.argtypes = [vp, i, i]
+    L.cup2d_get_P_inv.argtypes = [vp, vp]
+    L.cup2d_step.argtypes = [vp, d, d, d, d, i, i, ctypes.POINTER(d), ctypes.POINTER(i), ctypes.POINTER(d)]
+    L.cup2d_halo_plan.argtypes = [vp, i, vp, vp, i, vp, vp]
+    L.cup2d_halo_pack.argtypes = [vp, i, i, vp]
+    L.cup2d_halo_unpack.argtypes = [vp, i, i, vp]
+    L.cup2d_halo_pack_vec.argtypes = [vp, vp, i, i, vp]
+    L.cup2d_halo_unpack_vec.argtypes = [vp, vp, i, i, vp]
+    L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, vp, vp]
+    L.cup2d_set_timing.argtypes = [vp, i]
+    L.cup2d_get_timing.argtypes = [vp, i, ctypes.POINTER(d), ctypes.POINTER(i)]
+    _LIB = L
+    return L
+
+
+def check(status, what=""):
+    if status != 0:
+        L = load_library()
+        raise Cup2dError("%s failed with status %d: %s" % (what or "cup2d call", status, L.cup2d_last_error().decode()))

@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's time loop (main.cpp:6576-7290, body-free path) on top of
+the C-ABI.  Names follow the reference: fields tmp/chi/vel/vold/pres/pold/tmpV, computeA-style
+block operators, sim.dt/sim.nu/sim.CFL.  Every method is one or a few C-ABI calls; no arithmetic
+on field data happens in Python.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+from .grid import BlockGrid
+
+
+class Simulation:
+    def __init__(self, nbx, nby=None, extent=1.0, nu=1e-3, cfl=0.5, order="hilbert", device=0, grid=None, h=None):
+        """Uniform grid of nbx x nby blocks of 8x8 cells.  h = extent / max(nbx, nby) / 8 as
+        main.cpp:6338 (sim.h0 at the level of the blocks)."""
+        self.L = _l.load_library()
+        self.grid = grid if grid is not None else BlockGrid(nbx, nby if nby is not None else nbx, order=order)
+        g = self.grid
+        self.h = float(h) if h is not None else float(extent) / max(g.nbx, g.nby) / 8
+        self.nu, self.cfl = float(nu), float(cfl)
+        self.time, self.step_count, self.dt = 0.0, 0, 0.0
+        self._ctx = ctypes.c_void_p()
+        _l.check(self.L.cup2d_create(ctypes.byref(self._ctx), g.nblocks, g.nghost, g.n_inner,
+                                     g.nbr.ctypes.data_as(ctypes.c_void_p), self.h, int(device)), "cup2d_create")
+
+    # ---- lifetime ----------------------------------------------------------------------------
+    def close(self):
+        if self._ctx:
+            self.L.cup2d_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def set_math(self, strict):
+        _l.check(self.L.cup2d_set_math(self._ctx, _l.MATH_STRICT if strict else _l.MATH_FAST), "set_math")
+
+    def set_stream(self, raw_stream):
+        _l.check(self.L.cup2d_set_stream(self._ctx, ctypes.c_void_p(raw_stream)), "set_stream")
+
+    def synchronize(self):
+        _l.check(self.L.cup2d_synchronize(self._ctx), "synchronize")
+
+    def field_ptr(self, field):
+        p = ctypes.c_void_p()
+        _l.check(self.L.cup2d_field_ptr(self._ctx, field, ctypes.byref(p)), "field_ptr")
+        return p.value
+
+    # ---- data movement (global row-major arrays <-> device slabs) --------------------------------
+    def set_field(self, field, a):
+        slab = self.grid.to_blocks(a)
+        assert slab.shape[1] == 64 * _l.FIELD_DIM[field]
+        _l.check(self.L.cup2d_upload_slab(self._ctx, field, slab.ctypes.data_as(ctypes.c_void_p)), "upload_slab")
+
+    def get_field(self, field):
+        dim = _l.FIELD_DIM[field]
+        slab = np.empty((self.grid.nblocks, 64 * dim))
+        _l.check(self.L.cup2d_download_slab(self._ctx, field, slab.ctypes.data_as(ctypes.c_void_p)), "download_slab")
+        return self.grid.from_blocks(slab, dim)
+
+    def set_blocks(self, field, block_arrays):
+        """reference-style upload: one separately allocated array per block (Info::block)"""
+        ptrs = (ctypes.c_void_p * len(block_arrays))(*[b.ctypes.data for b in block_arrays])
+        _l.check(self.L.cup2d_upload(self._ctx, field, ptrs), "upload")
+
+    def get_blocks(self, field):
+        dim = _l.FIELD_DIM[field]
+        blocks = [np.empty(64 * dim) for _ in range(self.grid.nblocks)]
+        ptrs = (ctypes.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
+        _l.check(self.L.cup2d_download(self._ctx, field, ptrs), "download")
+        return blocks
+
+    def fill(self, field, value=0.0):
+        _l.check(self.L.cup2d_fill(self._ctx, field, float(value)), "fill")
+
+    vel = property(lambda s: s.get_field(_l.VEL), lambda s, a: s.set_field(_l.VEL, a))
+    pres = property(lambda s: s.get_field(_l.PRES), lambda s, a: s.set_field(_l.PRES, a))
+    pold = property(lambda s: s.get_field(_l.POLD), lambda s, a: s.set_field(_l.POLD, a))
+    tmp = property(lambda s: s.get_field(_l.TMP), lambda s, a: s.set_field(_l.TMP, a))
+    tmpV = property(lambda s: s.get_field(_l.TMPV), lambda s, a: s.set_field(_l.TMPV, a))
+    chi = property(lambda s: s.get_field(_l.CHI), lambda s, a: s.set_field(_l.CHI, a))
+
+    # ---- block operators (names of the reference functors) -------------------------------------
+    def advect_diffuse_rhs(self, dt, phase=_l.BLOCKS_ALL):
+        """computeA<VectorLab>(KernelAdvectDiffuse(), var.vel, 2): tmpV <- rhs (main.cpp:6616)"""
+        _l.check(self.L.cup2d_advect_diffuse_rhs(self._ctx, self.nu, float(dt), phase), "advect_diffuse_rhs")
+
+    def advect_diffuse_rk2(self, dt):
+        """main.cpp:6607-6642"""
+        _l.check(self.L.cup2d_advect_diffuse_rk2(self._ctx, self.nu, float(dt)), "advect_diffuse_rk2")
+
+    def vorticity(self):
+        """computeA<VectorLab>(KernelVorticity(), var.vel, 2): tmp <- curl vel (main.cpp:4659)"""
+        _l.check(self.L.cup2d_vorticity(self._ctx, _l.BLOCKS_ALL), "vorticity")
+
+    def pressure_rhs(self, dt, use_bodies=False):
+        """computeB<pressure_rhs,...>(.., var.vel, var.tmpV) (main.cpp:7011)"""
+        _l.check(self.L.cup2d_pressure_rhs(self._ctx, float(dt), int(use_bodies), _l.BLOCKS_ALL), "pressure_rhs")
+
+    def laplacian_sub(self):
+        """computeA<ScalarLab>(pressure_rhs1(), var.pold, 1) (main.cpp:7026)"""
+        _l.check(self.L.cup2d_laplacian_sub(self._ctx, _l.BLOCKS_ALL), "laplacian_sub")
+
+    def poisson_rhs(self, dt, use_bodies=False):
+        """main.cpp:7007-7026"""
+        _l.check(self.L.cup2d_poisson_rhs(self._ctx, float(dt), int(use_bodies)), "poisson_rhs")
+
+    def pressure_correction(self, dt):
+        """computeA<ScalarLab>(pressureCorrectionKernel(), var.pres, 1) (main.cpp:7178)"""
+        _l.check(self.L.cup2d_pressure_correction(self._ctx, float(dt), _l.BLOCKS_ALL), "pressure_correction")
+
+    def add_correction(self):
+        """main.cpp:7180-7187"""
+        _l.check(self.L.cup2d_add_correction(self._ctx), "add_correction")
+
+    def project(self, dt):
+        """main.cpp:7120-7187"""
+        _l.check(self.L.cup2d_project(self._ctx, float(dt)), "project")
+
+    def apply_A(self, dst, src):
+        _l.check(self.L.cup2d_apply_A(self._ctx, dst, src), "apply_A")
+
+    def precond(self, dst, src):
+        _l.check(self.L.cup2d_precond(self._ctx, dst, src), "precond")
+
+    def P_inv(self):
+        P = np.empty((64, 64))
+        _l.check(self.L.cup2d_get_P_inv(self._ctx, P.ctypes.data_as(ctypes.c_void_p)), "get_P_inv")
+        return P
+
+    def max_abs_vel(self):
+        v = ctypes.c_double()
+        _l.check(self.L.cup2d_max_abs_vel(self._ctx, ctypes.byref(v)), "max_abs_vel")
+        return v.value
+
+    def compute_dt(self):
+        """main.cpp:6579-6595"""
+        v = ctypes.c_double()
+        _l.check(self.L.cup2d_compute_dt(self._ctx, self.nu, self.cfl, ctypes.byref(v)), "compute_dt")
+        return v.value
+
+    def poisson_solve(self, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000):
+        """sim.mat->solveWithUpdate/NoUpdate (main.cpp:7115-7118): b = tmp, x0 = pres, x -> pres"""
+        it, rs = ctypes.c_int(), ctypes.c_int()
+        e, e0 = ctypes.c_double(), ctypes.c_double()
+        _l.check(self.L.cup2d_poisson_solve(self._ctx, float(tol), float(rel_tol), int(max_restarts), int(max_iter),
+                                            ctypes.byref(it), ctypes.byref(rs), ctypes.byref(e), ctypes.byref(e0)),
+                 "poisson_solve")
+        return dict(iters=it.value, restarts=rs.value, err=e.value, err_init=e0.value)
+
+    def step(self, tol=None, rel_tol=None, max_restarts=None, max_iter=1000):
+        """One pass of the time-loop body.  Like main.cpp:7028-7030 the first ten steps run the
+        solver with zero tolerances unless tolerances are given explicitly."""
+        if tol is None:
+            tol, rel_tol, max_restarts = 0.0, 0.0, 100
+        dt, it, e = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol or 0.0),
+                                   int(100 if max_restarts is None else max_restarts), int(max_iter),
+                                   ctypes.byref(dt), ctypes.byref(it), ctypes.byref(e)), "step")
+        self.dt = dt.value
+        self.time += self.dt
+        self.step_count += 1
+        return dict(dt=dt.value, iters=it.value, err=e.value)
+
+    # ---- instrumentation -----------------------------------------------------------------------
+    def set_timing(self, on=True):
+        _l.check(self.L.cup2d_set_timing(self._ctx, int(on)), "set_timing")
+
+    def get_timing(self, timer):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        _l.check(self.L.cup2d_get_timing(self._ctx, timer, ctypes.byref(ms), ctypes.byref(n)), "get_timing")
+        return ms.value, n.value

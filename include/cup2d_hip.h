@@ -1,0 +1,205 @@
+/* include/cup2d_hip.h -- C-ABI of libcup2d_hip.so, the MI355X (gfx950) backend for CUP2D's
+ * per-block stencil hot path.  Plain C, plain pointers and sizes; no C++/torch types.
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * /root/reference).  The reference crosses to an accelerator through exactly one seam,
+ * cuda.h's C++ class LocalSpMatDnVec (cuda.h:26-79) -- that seam is served by
+ * libcup2d_spmat.so (cup2d_amd/csrc/local_spmat_hip.cpp, same mangled symbols as cuda.cu).
+ * The block-operator call sites of main.cpp (computeA/computeB, main.cpp:3024-3125) are
+ * `static` templates with no linkable symbol, so for them this header is the interface a
+ * maintainer binds instead (INTEGRATION.md shows the edit).
+ *
+ * Data model.  One context owns device-resident slabs for the reference's seven fields
+ * (main.cpp:3264-3278: tmp, chi, vel, vold, pres, pold, tmpV).  A slab is
+ * [nblocks + nghost][8*8*dim] float64 in the reference's own per-block layout
+ * (row-major iy*8+ix, vector components interleaved, main.cpp:510, 5497-5502), blocks in the
+ * caller's order (the reference's Hilbert id order works unchanged).  Topology is a
+ * neighbour table: nbr[b][0..3] = index of the same-level block to the W, E, S, N of block
+ * b, or CUP2D_WALL at a domain wall (free-slip / Neumann, main.cpp:3131-3255).  Indices
+ * >= nblocks address ghost blocks: copies of blocks owned by another rank, filled by
+ * cup2d_halo_unpack.  All arithmetic is FP64 (main.cpp:24).
+ *
+ * Every function returns CUP2D_OK (0) or a negative cup2d_status; nothing aborts and
+ * nothing falls back to the CPU.  Calls are asynchronous on the context's HIP stream
+ * unless they return data to the host.
+ */
+#ifndef CUP2D_HIP_H
+#define CUP2D_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUP2D_BS 8           /* -D_BS_=8, Makefile:11 */
+#define CUP2D_WALL (-1)
+
+typedef struct cup2d_ctx cup2d_ctx;
+
+typedef enum {
+  CUP2D_OK = 0,
+  CUP2D_ERR_ARG = -1,          /* bad argument */
+  CUP2D_ERR_HIP = -2,          /* a HIP runtime call failed: cup2d_last_error() has the text */
+  CUP2D_ERR_NODEVICE = -3,     /* no gfx950 device visible */
+  CUP2D_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (AMR, bodies in solver) */
+  CUP2D_ERR_COMM = -5          /* a communication callback failed */
+} cup2d_status;
+
+/* field ids in the order of var.F[] (main.cpp:3264-3278) */
+typedef enum {
+  CUP2D_TMP = 0,   /* scalar: Poisson rhs / vorticity */
+  CUP2D_CHI = 1,   /* scalar: body indicator */
+  CUP2D_VEL = 2,   /* vector */
+  CUP2D_VOLD = 3,  /* vector */
+  CUP2D_PRES = 4,  /* scalar */
+  CUP2D_POLD = 5,  /* scalar */
+  CUP2D_TMPV = 6,  /* vector: advect-diffuse rhs / udef / pressure-gradient increment */
+  CUP2D_NFIELDS = 7
+} cup2d_field;
+
+/* arithmetic policy of the WENO5 kernel.
+ * STRICT: operation-for-operation the reference expression (main.cpp:162-208, 5493-5502), IEEE
+ *         division, no FMA contraction: bit-identical to the reference CPU functor.
+ * FAST:   same algorithm, weights normalised with one division per reconstruction and FMAs;
+ *         differs from STRICT by round-off only (tolerance stated in tests/test_advect_gpu.py). */
+typedef enum { CUP2D_MATH_FAST = 0, CUP2D_MATH_STRICT = 1 } cup2d_math;
+
+/* which blocks an operator sweeps -- the inner/halo split of computeA (main.cpp:3035-3057) */
+typedef enum { CUP2D_BLOCKS_ALL = 0, CUP2D_BLOCKS_INNER = 1, CUP2D_BLOCKS_HALO = 2 } cup2d_phase;
+
+/* ---------------------------------------------------------------- lifetime --------------- */
+/* Replaces grid construction main.cpp:6508-6541 (per-block calloc) with device slabs.
+ * nblocks owned blocks, nghost ghost blocks, nbr[nblocks][4] (W,E,S,N), h = cell size of the
+ * (uniform) level (main.cpp:693).  n_inner: blocks [0,n_inner) touch no ghost block; pass
+ * nblocks when nghost == 0.  device: HIP device ordinal. */
+int cup2d_create(cup2d_ctx **ctx, int nblocks, int nghost, int n_inner, const int32_t *nbr, double h,
+                 int device);
+void cup2d_destroy(cup2d_ctx *ctx);
+const char *cup2d_last_error(void);
+const char *cup2d_version(void);
+/* run every later call on this hipStream_t (NULL = the context's own stream) */
+int cup2d_set_stream(cup2d_ctx *ctx, void *hip_stream);
+int cup2d_get_stream(cup2d_ctx *ctx, void **hip_stream);
+int cup2d_synchronize(cup2d_ctx *ctx);
+int cup2d_set_math(cup2d_ctx *ctx, int math /* cup2d_math */);
+
+/* ---------------------------------------------------------------- data movement ---------- */
+/* blocks[i] = Info::block of block i (main.cpp:510): nblocks separately allocated 64*dim arrays */
+int cup2d_upload(cup2d_ctx *ctx, int field, const double *const *blocks);
+int cup2d_download(cup2d_ctx *ctx, int field, double *const *blocks);
+/* same, one contiguous [nblocks][64*dim] host array */
+int cup2d_upload_slab(cup2d_ctx *ctx, int field, const double *slab);
+int cup2d_download_slab(cup2d_ctx *ctx, int field, double *slab);
+/* raw device pointer of a slab ([nblocks+nghost][64*dim]) for callers that keep data on the GPU */
+int cup2d_field_ptr(cup2d_ctx *ctx, int field, void **device_ptr);
+int cup2d_fill(cup2d_ctx *ctx, int field, double value);
+int cup2d_copy_field(cup2d_ctx *ctx, int dst_field, int src_field);
+
+/* ---------------------------------------------------------------- block operators -------- */
+/* computeA<VectorLab>(KernelAdvectDiffuse(), var.vel, 2)  main.cpp:6616 (functor 5441-5503):
+ * tmpV = -dt*h*(u.D_weno5)u + nu*dt*Lap5(u) */
+int cup2d_advect_diffuse_rhs(cup2d_ctx *ctx, double nu, double dt, int phase);
+/* the whole RK2 block main.cpp:6607-6642 fused into two kernels:
+ * vold = vel; vel = vold + 0.5*rhs(vel)/h^2; vel = vold + rhs(vel)/h^2.  tmpV is not written. */
+int cup2d_advect_diffuse_rk2(cup2d_ctx *ctx, double nu, double dt);
+/* the two halves of the above for callers that exchange halos in between (multi-GPU):
+ * stage 1: VOLD <- vel + 0.5*rhs(vel)/h^2 is written to the scratch slab; stage 2 reads it. */
+int cup2d_advect_diffuse_stage(cup2d_ctx *ctx, double nu, double dt, int stage /*1|2*/, int phase);
+/* computeA<VectorLab>(KernelVorticity(), var.vel, 2) main.cpp:4659 (functor 3343-3366): tmp = curl(vel) */
+int cup2d_vorticity(cup2d_ctx *ctx, int phase);
+/* computeB<pressure_rhs,..>(.., var.vel, var.tmpV) main.cpp:7011 (functor 6105-6139):
+ * tmp = 0.5h/dt * (div vel - chi * div tmpV).  use_bodies = 0 skips the chi/udef reads (tmpV=0). */
+int cup2d_pressure_rhs(cup2d_ctx *ctx, double dt, int use_bodies, int phase);
+/* computeA<ScalarLab>(pressure_rhs1(), var.pold, 1) main.cpp:7026 (functor 6209-6230): tmp -= Lap5(pold) */
+int cup2d_laplacian_sub(cup2d_ctx *ctx, int phase);
+/* main.cpp:7007-7026 in one call: tmp = pressure_rhs; pold = pres; pres = 0; tmp -= Lap5(pold) */
+int cup2d_poisson_rhs(cup2d_ctx *ctx, double dt, int use_bodies);
+/* computeA<ScalarLab>(pressureCorrectionKernel(), var.pres, 1) main.cpp:7178 (functor 6021-6043):
+ * tmpV = -0.5*dt*h*grad(pres) */
+int cup2d_pressure_correction(cup2d_ctx *ctx, double dt, int phase);
+/* main.cpp:7180-7187: vel += tmpV/h^2 */
+int cup2d_add_correction(cup2d_ctx *ctx);
+/* main.cpp:7120-7187 in one call: pres = x - mean(x); pres += pold - mean(pres);
+ * vel += (-0.5*dt*h*grad pres)/h^2, where x is the solver result (held in PRES). */
+int cup2d_project(cup2d_ctx *ctx, double dt);
+
+/* ---------------------------------------------------------------- scalars ---------------- */
+/* main.cpp:6585-6591: max |vel| over all owned blocks */
+int cup2d_max_abs_vel(cup2d_ctx *ctx, double *umax);
+/* main.cpp:6593-6595 */
+int cup2d_compute_dt(cup2d_ctx *ctx, double nu, double cfl, double *dt);
+
+/* ---------------------------------------------------------------- Poisson solve ---------- */
+/* Replaces getVec + LocalSpMatDnVec::solveWithUpdate/solveNoUpdate (main.cpp:7114-7118,
+ * cuda.cu:403-548) on a same-level block grid, matrix-free: b = TMP, x0 = PRES, result -> PRES.
+ * Preconditioned BiCGSTAB with the reference's update order, breakdown restarts, best-iterate
+ * tracking and Linf stopping rule; block-Jacobi preconditioner P_inv = -(A_loc)^-1
+ * (main.cpp:6451-6488).  max_iter: the reference hard-codes 1000 (cuda.cu:438).
+ * Outputs (may be NULL): iterations run, restarts, Linf residual of the returned iterate,
+ * initial Linf residual. */
+int cup2d_poisson_solve(cup2d_ctx *ctx, double max_error, double max_rel_error, int max_restarts,
+                        int max_iter, int *iters, int *restarts, double *linf, double *linf_init);
+/* y = A x on two scalar fields (A = 5-point graph Laplacian with Neumann walls: the matrix of
+ * main.cpp:7034-7112 on a same-level grid, equal to pressure_rhs1's stencil) */
+int cup2d_apply_A(cup2d_ctx *ctx, int dst_field, int src_field);
+/* z = P_inv p per block (cuda.cu:484-486) on two scalar fields */
+int cup2d_precond(cup2d_ctx *ctx, int dst_field, int src_field);
+/* copy of the 64x64 preconditioner the context uses (row-major) */
+int cup2d_get_P_inv(cup2d_ctx *ctx, double *P_inv_4096);
+
+/* ---------------------------------------------------------------- whole step ------------- */
+/* One pass of the body-free time-loop body main.cpp:6576-7187:
+ * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL. */
+int cup2d_step(cup2d_ctx *ctx, double nu, double cfl, double max_error, double max_rel_error,
+               int max_restarts, int max_iter, double *dt, int *iters, double *linf);
+
+/* ---------------------------------------------------------------- multi-GPU halos -------- */
+/* Replaces sync1/pack/unpack_subregion (main.cpp:1971-2142, 58-110) for same-level faces.
+ * A plan lists, in send-buffer order, (owned block, face) strips to pack and, in
+ * recv-buffer order, (ghost block, face) strips to unpack; face = 0..3 = W,E,S,N edge of the
+ * SOURCE block (a ghost block holds a copy of the remote block's cells at the same positions).
+ * A strip is width x 8 cells x dim doubles, rows in iy order. */
+int cup2d_halo_plan(cup2d_ctx *ctx, int nsend, const int32_t *send_block, const int32_t *send_face,
+                    int nrecv, const int32_t *recv_block, const int32_t *recv_face);
+int cup2d_halo_pack(cup2d_ctx *ctx, int field, int width, double *device_send_buffer);
+int cup2d_halo_unpack(cup2d_ctx *ctx, int field, int width, const double *device_recv_buffer);
+/* same for the solver's internal Krylov vector (which = 0: z, 1: z2) */
+int cup2d_halo_pack_vec(cup2d_ctx *ctx, const double *device_vec, int dim, int width, double *device_send_buffer);
+int cup2d_halo_unpack_vec(cup2d_ctx *ctx, double *device_vec, int dim, int width, const double *device_recv_buffer);
+
+/* Communication callbacks so that one code path serves 1 and N GPUs (MPI_Allreduce /
+ * Isend/Irecv sites main.cpp:6583-6592, 7138, 7162, cuda.cu:371-375, 448-534).
+ * exchange: send_buffer holds nsend strips of `strip_doubles` doubles, recv_buffer must hold
+ *           nrecv strips when the callback's work completes on `stream` (stream-ordered).
+ * allreduce: in-place on a device buffer of `count` doubles, op 0 = sum, 1 = max. */
+typedef int (*cup2d_exchange_fn)(void *user, double *device_send, double *device_recv, int strip_doubles,
+                                 void *hip_stream);
+typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int op, void *hip_stream);
+int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_allreduce_fn allreduce, void *user,
+                   double *device_send_buffer, double *device_recv_buffer);
+
+/* ---------------------------------------------------------------- instrumentation -------- */
+/* HIP-event timing per kernel family, recorded on the context stream around every launch while
+ * enabled (cup2d_set_timing(ctx, 1)); cup2d_get_timing returns accumulated GPU milliseconds and the
+ * number of launches since timing was enabled.  Events are resolved lazily (no extra
+ * synchronisation per launch). */
+typedef enum {
+  CUP2D_T_ADVECT_STAGE = 0, /* fused WENO5 advect-diffuse RK stage (k_advect_diffuse) */
+  CUP2D_T_POISSON_RHS = 1,  /* pressure_rhs + pressure_rhs1 fused */
+  CUP2D_T_SWEEP_A = 2,      /* p update + block-Jacobi preconditioner */
+  CUP2D_T_SWEEP_B = 3,      /* nu = A z + dot */
+  CUP2D_T_SWEEP_C = 4,      /* r update + preconditioner */
+  CUP2D_T_SWEEP_D = 5,      /* t = A z2 + 2 dots */
+  CUP2D_T_SWEEP_E = 6,      /* x, r update + 3 reductions */
+  CUP2D_T_SCALARS = 7,      /* reduction finish + device-side scalar algebra */
+  CUP2D_T_PROJECT = 8,      /* mean removal + pressure-gradient update */
+  CUP2D_T_REDUCE = 9,       /* max|u| (dt) */
+  CUP2D_T_HALO = 10,        /* pack / unpack */
+  CUP2D_T_NTIMERS = 11
+} cup2d_timer;
+int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
+int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUP2D_HIP_H */

@@ -295,6 +295,19 @@ def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, ma
     return out
 
 
+def ref_step_time(n, steps=3, max_iter=50, nu=1e-3, vel=None):
+    """CPU baseline: wall time of one full pass of the reference's own time-loop body
+    (main.cpp:6576-7290; Poisson solve = CPU port of cuda.cu capped at max_iter iterations, since the
+    reference has no CPU solver).  Returns the harness' JSON dict (median over `steps` steps)."""
+    import json
+    if vel is None:
+        vel = taylor_green(n)
+    with tempfile.TemporaryDirectory() as d:
+        _c(vel).tofile(os.path.join(d, "vel.in"))
+        txt = _run_ref("run", n, d, nu=float(nu), steps=int(steps) + 1, maxiter=int(max_iter), dump=0)
+    return json.loads(txt.strip().split("\n")[-1])
+
+
 def ref_bench(n, reps=10, vel=None, dt=1e-4, threads=None):
     """Time the reference functors (OpenMP) -- CPU baseline, kind='reference'."""
     import json

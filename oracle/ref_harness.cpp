@@ -24,6 +24,7 @@
  * File format: raw little-endian float64, global row-major (iy*n+ix),
  * vector fields interleaved (u,v).  n = 8 * 2^levelStart, extent = 1.
  */
+#include <chrono>
 #include <mpi.h>
 /* main.cpp's main() has no return statement: legal for main(), undefined behaviour
  * once renamed.  Its last statement is MPI_Finalize() (main.cpp:7291); route that
@@ -57,6 +58,9 @@ struct HarnessHooks {
   double last_error = 0, last_error_init = 0;
 };
 static HarnessHooks hooks;
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 class BiCGSTABSolver {
 public:
@@ -76,9 +80,28 @@ public:
       for (size_t i = 0; i < ns; i++)
         send_[i] = z[LS_.send_pack_idx_[i]];
     }
-    std::fill(y.begin(), y.begin() + m, 0.0);
-    for (int k = 0; k < LS_.loc_nnz_; k++)
-      y[LS_.loc_cooRowA_int_[k]] += LS_.loc_cooValA_[k] * z[LS_.loc_cooColA_int_[k]];
+    /* rows of the COO list are visited in list order; grouping them by row (stable) keeps each
+     * row's summation order and lets OpenMP threads own disjoint rows (CPU-baseline fairness) */
+    if ((int)csr_ptr_.size() != m + 1 || csr_nnz_ != LS_.loc_nnz_) {
+      csr_ptr_.assign(m + 1, 0);
+      for (int k = 0; k < LS_.loc_nnz_; k++) csr_ptr_[LS_.loc_cooRowA_int_[k] + 1]++;
+      for (int i = 0; i < m; i++) csr_ptr_[i + 1] += csr_ptr_[i];
+      csr_col_.resize(LS_.loc_nnz_);
+      csr_val_.resize(LS_.loc_nnz_);
+      std::vector<int> fill(csr_ptr_.begin(), csr_ptr_.end() - 1);
+      for (int k = 0; k < LS_.loc_nnz_; k++) {
+        int pos = fill[LS_.loc_cooRowA_int_[k]]++;
+        csr_col_[pos] = LS_.loc_cooColA_int_[k];
+        csr_val_[pos] = LS_.loc_cooValA_[k];
+      }
+      csr_nnz_ = LS_.loc_nnz_;
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; i++) {
+      double acc = 0.0;
+      for (int k = csr_ptr_[i]; k < csr_ptr_[i + 1]; k++) acc += csr_val_[k] * z[csr_col_[k]];
+      y[i] = acc;
+    }
     if (size_ > 1) {
       std::vector<MPI_Request> rr(LS_.recv_ranks_.size()), sr(LS_.send_ranks_.size());
       for (size_t i = 0; i < LS_.recv_ranks_.size(); i++)
@@ -111,12 +134,14 @@ public:
   }
   static double amax_abs(const std::vector<double> &v, int m) { /* Idamax + set_amax */
     double a = 0;
+#pragma omp parallel for reduction(max : a) schedule(static)
     for (int i = 0; i < m; i++)
       a = std::max(a, std::fabs(v[i]));
     return a;
   }
   static double dot(const std::vector<double> &a, const std::vector<double> &b, int m) {
     double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
     for (int i = 0; i < m; i++)
       s += a[i] * b[i];
     return s;
@@ -180,22 +205,23 @@ public:
         beta = (rho_curr / (rho_prev + eps)) * (alpha / (omega + eps));
       }
       b1 = -omega;
-      for (int i = 0; i < m; i++)
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < m; i++) {
         p[i] += b1 * nu[i];
-      for (int i = 0; i < m; i++)
         p[i] *= beta;
-      for (int i = 0; i < m; i++)
         p[i] += r[i];
+      }
       precond(p, z);
       spmv(z, nu);
       b1 = dot(rhat, nu, m);
       MPI_Allreduce(MPI_IN_PLACE, &b1, 1, MPI_DOUBLE, MPI_SUM, comm_);
       alpha = rho_curr / (b1 + eps);
-      for (int i = 0; i < m; i++)
-        x[i] += alpha * z[i];
       b1 = -alpha;
-      for (int i = 0; i < m; i++)
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < m; i++) {
+        x[i] += alpha * z[i];
         r[i] += b1 * nu[i];
+      }
       precond(r, z);
       spmv(z, t);
       double r2[2];
@@ -204,11 +230,12 @@ public:
       r2[1] *= r2[1];
       MPI_Allreduce(MPI_IN_PLACE, r2, 2, MPI_DOUBLE, MPI_SUM, comm_);
       omega = r2[0] / (r2[1] + eps);
-      for (int i = 0; i < m; i++)
-        x[i] += omega * z[i];
       b1 = -omega;
-      for (int i = 0; i < m; i++)
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < m; i++) {
+        x[i] += omega * z[i];
         r[i] += b1 * t[i];
+      }
       error = amax_abs(r, m);
       MPI_Allreduce(MPI_IN_PLACE, &error, 1, MPI_DOUBLE, MPI_MAX, comm_);
       if (error < error_opt) {
@@ -237,6 +264,9 @@ private:
   const bool bMean_;
   std::vector<double> P_inv_;
   std::vector<double> send_, recv_;
+  std::vector<int> csr_ptr_, csr_col_;
+  std::vector<double> csr_val_;
+  int csr_nnz_ = -1;
 };
 
 LocalSpMatDnVec::LocalSpMatDnVec(MPI_Comm m_comm, const int BLEN, const bool bMeanConstraint,
@@ -443,9 +473,6 @@ static int run_reference_main(int levelStart, double nu, double cfl, double tend
   return cup2d_reference_main((int)a.size(), argv.data());
 }
 
-static double now_s() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 static void usage() {
   fprintf(stderr,
@@ -466,7 +493,7 @@ int main(int argc, char **argv) {
   const int levelStart = atoi(argv[2]);
   const std::string dir = argv[3];
   double nu = 1e-3, dt = -1, cfl = 0.5, tol = 0, reltol = 0;
-  int steps = 1, reps = 10, restarts = 100, maxiter = -1;
+  int steps = 1, reps = 10, restarts = 100, maxiter = -1, dump = 1;
   for (int i = 4; i < argc; i++) {
     std::string kv = argv[i];
     auto eq = kv.find('=');
@@ -481,6 +508,7 @@ int main(int argc, char **argv) {
     else if (k == "reltol") reltol = atof(v.c_str());
     else if (k == "restarts") restarts = atoi(v.c_str());
     else if (k == "maxiter") maxiter = atoi(v.c_str());
+    else if (k == "dump") dump = atoi(v.c_str());
     else { usage(); return 2; }
   }
   g_n = _BS_ << levelStart;
@@ -498,10 +526,12 @@ int main(int argc, char **argv) {
     auto ic = read_file(dir + "/vel.in", 2 * N);
     FILE *meta = fopen((dir + "/meta.txt").c_str(), "w");
     int solve_count = 0;
+    std::vector<double> t_hook;
     hooks.on_solve = [&](LocalSpMatDnVec *M, bool withUpdate, double e, double re, int mr) {
+      t_hook.push_back(now_s());
       if (solve_count == 0) {
         scatter(var.vel, 2, ic);
-      } else {
+      } else if (dump) {
         char tag[64];
         snprintf(tag, sizeof tag, ".%d", solve_count);
         dump_grid(dir + "/vel_adv" + tag, var.vel, 2);
@@ -523,8 +553,22 @@ int main(int argc, char **argv) {
     fprintf(meta, "final iters %d err %.17g err_init %.17g restarts %d time %.17g steps %d\n", hooks.last_iters,
             hooks.last_error, hooks.last_error_init, hooks.last_restarts, sim.time, sim.step);
     fclose(meta);
-    dump_grid(dir + "/vel.final", var.vel, 2);
-    dump_grid(dir + "/pres.final", var.pres, 1);
+    if (dump) {
+      dump_grid(dir + "/vel.final", var.vel, 2);
+      dump_grid(dir + "/pres.final", var.pres, 1);
+    }
+    /* wall time of one full pass of the loop body = distance between consecutive solve entries */
+    {
+      std::vector<double> d;
+      for (size_t i = 2; i < t_hook.size(); i++) d.push_back(t_hook[i] - t_hook[i - 1]);
+      std::sort(d.begin(), d.end());
+      int threads = 1;
+#ifdef _OPENMP
+      threads = omp_get_max_threads();
+#endif
+      printf("{\"n\": %d, \"threads\": %d, \"timed_steps\": %zu, \"median_step_s\": %.6e, \"maxiter\": %d}\n", g_n,
+             threads, d.size(), d.empty() ? 0.0 : d[d.size() / 2], maxiter);
+    }
     return 0;
   }
 

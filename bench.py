@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(cores, 64))")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +153,8 @@ def main():
         try:
             from oracle import oracle as O
             if O.have_reference():
-                r = O.ref_step_time(args.cpu_n, steps=2, max_iter=args.iters)
+                thr = args.cpu_threads or min(os.cpu_count() or 1, 64)
+                r = O.ref_step_time(args.cpu_n, steps=2, max_iter=args.iters, threads=thr, timeout=150)
                 cpu = {"value": round(args.cpu_n ** 2 / r["median_step_s"] / 1e6, 4), "unit": "Mcell-updates/s",
                        "cores": r["threads"], "kind": "reference",
                        "sample": "reference main.cpp time loop (OpenMP functors; Poisson = CPU port of cuda.cu, %d iters) "

@@ -132,8 +132,9 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   build_P_inv(c->h_Pinv);
   CUP2D_HIP_CHECK(hipMalloc(&c->d_Pinv, BC * BC * sizeof(double)));
   CUP2D_HIP_CHECK(hipMemcpy(c->d_Pinv, c->h_Pinv.data(), BC * BC * sizeof(double), hipMemcpyHostToDevice));
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * MAX_GRID));
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_red, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * PSTRIDE));
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_red_own, sizeof(double) * 8));
+  c->d_red = c->d_red_own;
   CUP2D_HIP_CHECK(hipMalloc(&c->d_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
@@ -148,7 +149,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipFree(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
   (void)hipFree(c->d_vscratch);
-  double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_partials, c->d_red};
+  double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_partials, c->d_red_own};
   for (double *p : kv) (void)hipFree(p);
   (void)hipFree(c->d_sc);
   (void)hipHostFree(c->h_sc);
@@ -280,10 +281,19 @@ int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, in
 }
 int cup2d_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
   CUP2D_CHECK_CTX(c);
-  CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 3));
-  CUP2D_TRY(cup2d_advect_diffuse_stage(c, nu, dt, 1, CUP2D_BLOCKS_ALL));
-  CUP2D_TRY(exchange_halo(c, c->d_vscratch, 2, 3));
-  return cup2d_advect_diffuse_stage(c, nu, dt, 2, CUP2D_BLOCKS_ALL);
+  for (int stage = 1; stage <= 2; stage++) {
+    double *src = stage == 1 ? c->d_field[CUP2D_VEL] : c->d_vscratch;
+    if (overlapped(c)) {  // inner blocks while the face strips are in flight (main.cpp:3035-3057)
+      CUP2D_TRY(exchange_begin(c, src, 2, 3));
+      CUP2D_TRY(cup2d_advect_diffuse_stage(c, nu, dt, stage, CUP2D_BLOCKS_INNER));
+      CUP2D_TRY(exchange_end(c, src, 2, 3));
+      CUP2D_TRY(cup2d_advect_diffuse_stage(c, nu, dt, stage, CUP2D_BLOCKS_HALO));
+    } else {
+      CUP2D_TRY(exchange_halo(c, src, 2, 3));
+      CUP2D_TRY(cup2d_advect_diffuse_stage(c, nu, dt, stage, CUP2D_BLOCKS_ALL));
+    }
+  }
+  return CUP2D_OK;
 }
 int cup2d_vorticity(cup2d_ctx *c, int phase) {
   CUP2D_CHECK_CTX(c);
@@ -454,13 +464,17 @@ int cup2d_halo_unpack_vec(cup2d_ctx *c, double *vec, int dim, int width, const d
   if (!vec || (dim != 1 && dim != 2) || !width_ok(width)) return CUP2D_ERR_ARG;
   return halo_unpack_impl(c, vec, dim, width, buf);
 }
-int cup2d_set_comm(cup2d_ctx *c, cup2d_exchange_fn ex, cup2d_allreduce_fn ar, void *user, double *send, double *recv) {
+int cup2d_set_comm(cup2d_ctx *c, cup2d_exchange_fn ex, cup2d_wait_fn wt, cup2d_allreduce_fn ar, void *user, double *send,
+                   double *recv, double *red) {
   CUP2D_CHECK_CTX(c);
+  if (ex && c->nghost > 0 && (!send || !recv)) { set_error("set_comm: buffers"); return CUP2D_ERR_ARG; }
   c->exchange = ex;
+  c->wait = wt;
   c->allreduce = ar;
   c->comm_user = user;
   c->d_send = send;
   c->d_recv = recv;
+  c->d_red = red ? red : c->d_red_own;
   return CUP2D_OK;
 }
 

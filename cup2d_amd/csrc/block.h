@@ -143,11 +143,11 @@ static __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// one partial per workgroup and slot, written to partials[slot*gridDim.x + blockIdx.x]; order of
-// accumulation is fixed by the launch geometry, so results are run-to-run reproducible
+// one partial per workgroup and slot, written to partials[slot*PSTRIDE + poff + blockIdx.x]; order
+// of accumulation is fixed by the launch geometry, so results are run-to-run reproducible
 template <int N, bool IS_MAX>
 static __device__ __forceinline__ void workgroup_reduce_store(double (&v)[N], double *__restrict__ partials,
-                                                              int slot0) {
+                                                              int slot0, int poff = 0) {
   __shared__ double red[N][WPG];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -159,7 +159,7 @@ static __device__ __forceinline__ void workgroup_reduce_store(double (&v)[N], do
   if (threadIdx.x < N) {
     double a = red[threadIdx.x][0];
     for (int k = 1; k < WPG; k++) a = IS_MAX ? fmax(a, red[threadIdx.x][k]) : a + red[threadIdx.x][k];
-    partials[(size_t)(slot0 + threadIdx.x) * gridDim.x + blockIdx.x] = a;
+    partials[(size_t)(slot0 + threadIdx.x) * PSTRIDE + poff + blockIdx.x] = a;
   }
 }
 

@@ -16,6 +16,7 @@ constexpr int WG = 256;            // threads per workgroup = 4 waves = 4 blocks
 constexpr int WPG = WG / 64;       // waves (= blocks) per workgroup pass
 constexpr int MAX_GRID = 2048;     // persistent grid: 256 CUs x 8 workgroups, multiple of the 8 XCDs
 constexpr int NSLOT = 4;           // reduction slots per launch
+constexpr int PSTRIDE = 2 * MAX_GRID;  // partials per slot: an inner-block and a halo-block launch
 
 void set_error(const char *fmt, ...);
 #define CUP2D_HIP_CHECK(expr)                                                                   \
@@ -89,7 +90,9 @@ struct cup2d_ctx {
   cup2d::HaloPlan plan;
   // communication callbacks
   cup2d_exchange_fn exchange = nullptr;
+  cup2d_wait_fn wait = nullptr;
   cup2d_allreduce_fn allreduce = nullptr;
+  double *d_red_own = nullptr;
   void *comm_user = nullptr;
   double *d_send = nullptr, *d_recv = nullptr;
   // timing: pool of event pairs, resolved lazily
@@ -160,7 +163,11 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
                int *iters, int *restarts, double *linf, double *linf_init);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);
-// exchange ghost strips of a device vector through the comm callback (no-op without ghosts)
+// ghost-strip exchange of a device vector through the comm callbacks (no-ops without ghosts):
+// begin = pack + start transfer; end = wait + unpack.  exchange_halo = begin + end.
+int exchange_begin(cup2d_ctx *c, const double *vec, int dim, int width);
+int exchange_end(cup2d_ctx *c, double *vec, int dim, int width);
 int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
+static inline bool overlapped(const cup2d_ctx *c) { return c->nghost > 0 && c->exchange && c->n_inner < c->nblocks; }
 
 }  // namespace cup2d

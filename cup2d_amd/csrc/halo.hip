@@ -60,15 +60,28 @@ int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double
   return CUP2D_OK;
 }
 
-// pack -> exchange callback -> unpack, all ordered on the context stream
-int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width) {
+// pack + start the transfer (exchange callback)
+int exchange_begin(cup2d_ctx *c, const double *vec, int dim, int width) {
   if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
   CUP2D_TRY(halo_pack_impl(c, vec, dim, width, c->d_send));
   if (c->exchange(c->comm_user, c->d_send, c->d_recv, BS * width * dim, c->stream) != 0) {
     set_error("exchange callback failed");
     return CUP2D_ERR_COMM;
   }
+  return CUP2D_OK;
+}
+// wait for the transfer + unpack into the ghost blocks
+int exchange_end(cup2d_ctx *c, double *vec, int dim, int width) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+    set_error("wait callback failed");
+    return CUP2D_ERR_COMM;
+  }
   return halo_unpack_impl(c, vec, dim, width, c->d_recv);
+}
+int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width) {
+  CUP2D_TRY(exchange_begin(c, vec, dim, width));
+  return exchange_end(c, vec, dim, width);
 }
 
 }  // namespace cup2d

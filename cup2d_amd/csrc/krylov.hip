@@ -101,7 +101,7 @@ template <int NDOT>
 __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, double *__restrict__ y,
                                                 const double *__restrict__ w, const int *__restrict__ nbr,
                                                 const KrylovScalars *__restrict__ sc, double *__restrict__ partials,
-                                                int count) {
+                                                int first, int count, int poff) {
   __shared__ double slabs[WPG][LAB1 * LAB1];
   if (sc->status != 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -115,11 +115,12 @@ __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, do
   for (int g = gr.begin; g < gr.end; g += gr.stride) {
     const int rel = g * WPG + wave;
     if (rel < count) {
-      load_scalar_lab1(x, nbr, rel, lane, slab);
+      const int b = first + rel;
+      load_scalar_lab1(x, nbr, b, lane, slab);
       wave_lds_sync();
       const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
       const double yv = l1 + l2 + l3 + l4 - 4 * l0;
-      const size_t o = (size_t)rel * BC + lane;
+      const size_t o = (size_t)b * BC + lane;
       y[o] = yv;
       const double wv = w[o];
       acc[0] = __builtin_fma(yv, wv, acc[0]);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, do
       wave_lds_sync();
     }
   }
-  workgroup_reduce_store<NDOT, false>(acc, partials, 0);
+  workgroup_reduce_store<NDOT, false>(acc, partials, 0, poff);
 }
 
 // ---- sweep C ----------------------------------------------------------------------------------
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(WG) void k_sweepE(double *__restrict__ x, double *_
 __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__ x, const double *__restrict__ b,
                                                       double *__restrict__ r, double *__restrict__ rhat,
                                                       const int *__restrict__ nbr, double *__restrict__ partials,
-                                                      int count) {
+                                                      int first, int count, int poff) {
   __shared__ double slabs[WPG][LAB1 * LAB1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *slab = slabs[wave];
@@ -196,10 +197,11 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
   for (int g = gr.begin; g < gr.end; g += gr.stride) {
     const int rel = g * WPG + wave;
     if (rel < count) {
-      load_scalar_lab1(x, nbr, rel, lane, slab);
+      const int bk = first + rel;
+      load_scalar_lab1(x, nbr, bk, lane, slab);
       wave_lds_sync();
       const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
-      const size_t o = (size_t)rel * BC + lane;
+      const size_t o = (size_t)bk * BC + lane;
       const double rv = b[o] - (l1 + l2 + l3 + l4 - 4 * l0);
       r[o] = rv;
       rhat[o] = rv;
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
       wave_lds_sync();
     }
   }
-  workgroup_reduce_store<1, false>(s, partials, 0);
-  workgroup_reduce_store<1, true>(m, partials, 2);
+  workgroup_reduce_store<1, false>(s, partials, 0, poff);
+  workgroup_reduce_store<1, true>(m, partials, 2, poff);
 }
 
 // ---- scalar kernels ---------------------------------------------------------------------------
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict
   double a0 = 0, a1 = 0, mx = 0;
   for (int i = threadIdx.x; i < G; i += WG) {
     a0 += partials[i];
-    if (nsum > 1) a1 += partials[G + i];
-    if (with_max) mx = fmax(mx, partials[2 * (size_t)G + i]);
+    if (nsum > 1) a1 += partials[PSTRIDE + i];
+    if (with_max) mx = fmax(mx, partials[2 * PSTRIDE + i]);
   }
   sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
   __syncthreads();
@@ -326,12 +328,30 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   int gridE = (int)((n + WG - 1) / WG);
   if (gridE > c->grid) gridE = c->grid;
 
-  CUP2D_TRY(exchange_halo(c, x, 1, 1));
-  hipLaunchKernelGGL(k_init_residual, dim3(G), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
-                     c->d_partials, nb);
-  CUP2D_HIP_CHECK(hipGetLastError());
-  CUP2D_TRY(finish(c, G, 1, 1, 0, false));
-  // p, nu start at zero (cuda.cu:436-437); status gate: a zero right-hand side converges at once
+  // y = A x over all owned blocks with the halo exchange of x overlapped: inner blocks while the
+  // face strips are in flight, halo blocks after unpack (computeA's split, main.cpp:3035-3057).
+  // Returns the number of per-workgroup partials the launches wrote.
+  const int n_in = overlapped(c) ? c->n_inner : nb, n_ha = nb - n_in;
+  const int G_in = n_in > 0 ? grid_for(c, n_in) : 0, G_ha = n_ha > 0 ? grid_for(c, n_ha) : 0;
+  auto stencil_sweep = [&](double *xin, auto launch) -> int {
+    CUP2D_TRY(exchange_begin(c, xin, 1, 1));
+    if (n_in > 0) launch(0, n_in, 0, G_in);
+    CUP2D_TRY(exchange_end(c, xin, 1, 1));
+    if (n_ha > 0) launch(n_in, n_ha, G_in, G_ha);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    return CUP2D_OK;
+  };
+  const int GP = G_in + G_ha;
+
+  {
+    ProfScope prof(c, CUP2D_T_SWEEP_B);
+    CUP2D_TRY(stencil_sweep(x, [&](int first, int count, int poff, int g) {
+      hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                         c->d_partials, first, count, poff);
+    }));
+  }
+  CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
+  // p, nu start at zero (cuda.cu:436-437)
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
 
@@ -339,24 +359,36 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
     CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->h_sc->status != 0) break;
-    { ProfScope prof(c, CUP2D_T_SWEEP_A);
-    hipLaunchKernelGGL(k_sweepA, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
-                       c->d_Pinv, c->d_sc, nb); }
-    CUP2D_TRY(exchange_halo(c, c->d_z, 1, 1));
-    { ProfScope prof(c, CUP2D_T_SWEEP_B);
-    hipLaunchKernelGGL(k_sweepBD<1>, dim3(G), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
-                       c->d_partials, nb); }
-    CUP2D_TRY(finish(c, G, 1, 0, 1, true));
-    { ProfScope prof(c, CUP2D_T_SWEEP_C);
-    hipLaunchKernelGGL(k_sweepC, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_Pinv, c->d_sc, nb); }
-    CUP2D_TRY(exchange_halo(c, c->d_z2, 1, 1));
-    { ProfScope prof(c, CUP2D_T_SWEEP_D);
-    hipLaunchKernelGGL(k_sweepBD<2>, dim3(G), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
-                       c->d_partials, nb); }
-    CUP2D_TRY(finish(c, G, 2, 0, 2, true));
-    { ProfScope prof(c, CUP2D_T_SWEEP_E);
-    hipLaunchKernelGGL(k_sweepE, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r, c->d_t,
-                       c->d_rhat, c->d_sc, c->d_partials, n); }
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_A);
+      hipLaunchKernelGGL(k_sweepA, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
+                         c->d_Pinv, c->d_sc, nb);
+    }
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_B);
+      CUP2D_TRY(stencil_sweep(c->d_z, [&](int first, int count, int poff, int g) {
+        hipLaunchKernelGGL(k_sweepBD<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
+                           c->d_partials, first, count, poff);
+      }));
+    }
+    CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_C);
+      hipLaunchKernelGGL(k_sweepC, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_Pinv, c->d_sc, nb);
+    }
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_D);
+      CUP2D_TRY(stencil_sweep(c->d_z2, [&](int first, int count, int poff, int g) {
+        hipLaunchKernelGGL(k_sweepBD<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
+                           c->d_partials, first, count, poff);
+      }));
+    }
+    CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_E);
+      hipLaunchKernelGGL(k_sweepE, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r, c->d_t,
+                         c->d_rhat, c->d_sc, c->d_partials, n);
+    }
     CUP2D_HIP_CHECK(hipGetLastError());
     CUP2D_TRY(finish(c, gridE, 2, 1, 3, true));
   }

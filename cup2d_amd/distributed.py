@@ -1,0 +1,223 @@
+"""Domain decomposition of the block grid over the GPUs of one node.
+
+Replaces the reference's rank partitioning + Synchronizer (main.cpp:6494-6504, 1971-2142) for uniform
+grids with a px x py Cartesian split: every rank owns an nbx x nby patch of 8x8 blocks, keeps one ghost
+block per boundary block on each interior side, and exchanges only face strips (3 cell layers for the
+WENO5 stencil, 1 for the 5-point kernels) with at most four peers.  The HIP library packs/unpacks the
+strips and sweeps inner blocks while they are in flight; this module supplies the plan and the two
+communication callbacks (RCCL send/recv and all-reduce through torch.distributed; "nccl" IS RCCL on
+ROCm).  With the "gloo" backend the same code stages through host memory, which is how the path is
+exercised on CPU and on a single-GPU box.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+from .grid import BlockGrid
+from .simulation import Simulation
+
+OPPOSITE = (1, 0, 3, 2)  # W<->E, S<->N
+
+
+def cartesian_dims(world):
+    """px x py with py >= px and both powers of two where possible: 8 -> 2 x 4 (BASELINE.json configs[3])."""
+    px = 1
+    while px * px * 4 <= world and world % (px * 2) == 0:
+        px *= 2
+    if world % px:
+        px = 1
+    return px, world // px
+
+
+class PatchTopology:
+    """Which strips rank (cx, cy) of a px x py decomposition sends to / receives from whom.
+
+    send_block/send_face and recv_block/recv_face are the arrays of cup2d_halo_plan, grouped by peer in
+    side order W, E, S, N and by position along the side; both ends of a link enumerate positions in the
+    same order, so strip k of a message lands in ghost slot k of the opposite side.
+    """
+
+    def __init__(self, nbx, nby, px, py, cx, cy, order="hilbert"):
+        self.px, self.py, self.cx, self.cy = px, py, cx, cy
+        self.rank = cy * px + cx
+        sides = (cx > 0, cx < px - 1, cy > 0, cy < py - 1)
+        self.grid = BlockGrid(nbx, nby, order=order, ghost_sides=sides)
+        g = self.grid
+        peer_of_side = (self.rank - 1, self.rank + 1, self.rank - px, self.rank + px)
+        self.peers = []  # (peer_rank, send_offset, recv_offset, nstrips), offsets in strips
+        sb, sf, rb, rf = [], [], [], []
+        for side in range(4):
+            if not sides[side]:
+                continue
+            npos = nby if side < 2 else nbx
+            soff, roff = len(sb), len(rb)
+            for pos in range(npos):
+                if side == 0:
+                    owned = g.index_of[pos, 0]
+                elif side == 1:
+                    owned = g.index_of[pos, nbx - 1]
+                elif side == 2:
+                    owned = g.index_of[0, pos]
+                else:
+                    owned = g.index_of[nby - 1, pos]
+                sb.append(int(owned))
+                sf.append(side)                          # my blocks' face on that side
+                rb.append(int(g._ghost_id[(side, pos)]))
+                rf.append(OPPOSITE[side])                # the peer's face that touches me
+            self.peers.append((peer_of_side[side], soff, roff, npos))
+        self.send_block = np.asarray(sb, dtype=np.int32)
+        self.send_face = np.asarray(sf, dtype=np.int32)
+        self.recv_block = np.asarray(rb, dtype=np.int32)
+        self.recv_face = np.asarray(rf, dtype=np.int32)
+        self.nsend, self.nrecv = len(sb), len(rb)
+
+
+def strip_cells(face, width):
+    """cell indices (iy*8+ix) of a strip in buffer order -- the layout of halo.hip's strip_cell()"""
+    if face < 2:
+        return [iy * 8 + (k if face == 0 else 8 - width + k) for iy in range(8) for k in range(width)]
+    return [(j if face == 2 else 8 - width + j) * 8 + ix for j in range(width) for ix in range(8)]
+
+
+class TorchComm:
+    """Face-strip exchange and all-reduce over torch.distributed.
+
+    mode "device": tensors are GPU tensors and the backend moves them directly (nccl/RCCL over xGMI);
+                   the exchange runs on a dedicated communication stream and overlaps the inner-block
+                   sweep the library launches between exchange() and wait().
+    mode "staged": GPU tensors staged through host memory (gloo) -- functional path for boxes where
+                   RCCL cannot be used (e.g. two ranks on one GPU).
+    mode "host"  : tensors already live on the host (CPU tests of the plan).
+    """
+
+    MAX_STRIP = 48  # 3 layers x 8 cells x 2 components
+
+    def __init__(self, topo, mode, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.topo, self.mode = torch, dist, topo, mode
+        dev = torch.device("cpu") if mode == "host" else torch.device("cuda", device)
+        self.send = torch.zeros(max(1, topo.nsend) * self.MAX_STRIP, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(max(1, topo.nrecv) * self.MAX_STRIP, dtype=torch.float64, device=dev)
+        self.red = torch.zeros(8, dtype=torch.float64, device=dev)
+        if mode == "staged":
+            self.h_send = torch.zeros_like(self.send, device="cpu").pin_memory()
+            self.h_recv = torch.zeros_like(self.recv, device="cpu").pin_memory()
+            self.h_red = torch.zeros(8, dtype=torch.float64).pin_memory()
+        if mode == "device":
+            self.compute_stream = torch.cuda.Stream(device=dev)
+            self.comm_stream = torch.cuda.Stream(device=dev)
+            self.ev_packed = torch.cuda.Event()
+            self.ev_arrived = torch.cuda.Event()
+        elif mode == "staged":
+            self.compute_stream = torch.cuda.Stream(device=dev)
+        else:
+            self.compute_stream = None
+
+    # ---- point-to-point -----------------------------------------------------------------------
+    def _p2p(self, send, recv, strip_doubles):
+        dist = self.dist
+        ops = []
+        for peer, soff, roff, n in self.topo.peers:
+            ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer))
+        for peer, soff, roff, n in self.topo.peers:
+            ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def exchange(self, strip_doubles):
+        """start moving the packed strips (called after the pack kernel was enqueued)"""
+        torch = self.torch
+        if self.mode == "device":
+            self.ev_packed.record(self.compute_stream)
+            self.comm_stream.wait_event(self.ev_packed)
+            with torch.cuda.stream(self.comm_stream):
+                for r in self._p2p(self.send, self.recv, strip_doubles):
+                    r.wait()
+                self.ev_arrived.record(self.comm_stream)
+        elif self.mode == "staged":
+            ns, nr = self.topo.nsend * strip_doubles, self.topo.nrecv * strip_doubles
+            with torch.cuda.stream(self.compute_stream):
+                self.h_send[:ns].copy_(self.send[:ns], non_blocking=True)
+            self.compute_stream.synchronize()
+            for r in self._p2p(self.h_send, self.h_recv, strip_doubles):
+                r.wait()
+            with torch.cuda.stream(self.compute_stream):
+                self.recv[:nr].copy_(self.h_recv[:nr], non_blocking=True)
+        else:
+            for r in self._p2p(self.send, self.recv, strip_doubles):
+                r.wait()
+
+    def wait(self):
+        if self.mode == "device":
+            self.compute_stream.wait_event(self.ev_arrived)
+
+    # ---- reductions ------------------------------------------------------------------------------
+    def allreduce(self, offset, count, op):
+        torch, dist = self.torch, self.dist
+        rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        if self.mode == "device":
+            with torch.cuda.stream(self.compute_stream):
+                dist.all_reduce(self.red[offset:offset + count], op=rop)
+        elif self.mode == "staged":
+            with torch.cuda.stream(self.compute_stream):
+                self.h_red[offset:offset + count].copy_(self.red[offset:offset + count], non_blocking=True)
+            self.compute_stream.synchronize()
+            dist.all_reduce(self.h_red[offset:offset + count], op=rop)
+            with torch.cuda.stream(self.compute_stream):
+                self.red[offset:offset + count].copy_(self.h_red[offset:offset + count], non_blocking=True)
+        else:
+            dist.all_reduce(self.red[offset:offset + count], op=rop)
+
+
+class DistributedSimulation(Simulation):
+    """One rank's patch of a px x py decomposition; same interface as Simulation.  Fields set/get
+    through .vel/.pres/... are this rank's (nby*8, nbx*8) patch."""
+
+    def __init__(self, nbx, nby, px, py, extent=1.0, nu=1e-3, cfl=0.5, order="hilbert", device=0, mode=None):
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        assert world == px * py, "world size %d != %d x %d" % (world, px, py)
+        self.topo = PatchTopology(nbx, nby, px, py, rank % px, rank // px, order=order)
+        if mode is None:
+            mode = "device" if dist.get_backend() == "nccl" else "staged"
+        h = float(extent) / max(nbx * px, nby * py) / 8  # main.cpp:6338 on the GLOBAL grid
+        super().__init__(nbx, nby, nu=nu, cfl=cfl, device=device, grid=self.topo.grid, h=h)
+        self.comm = TorchComm(self.topo, mode, device)
+        self.set_stream(self.comm.compute_stream.cuda_stream)
+        t = self.topo
+        vp = ctypes.c_void_p
+        _l.check(self.L.cup2d_halo_plan(self._ctx, t.nsend, t.send_block.ctypes.data_as(vp), t.send_face.ctypes.data_as(vp),
+                                        t.nrecv, t.recv_block.ctypes.data_as(vp), t.recv_face.ctypes.data_as(vp)), "halo_plan")
+        red_base = self.comm.red.data_ptr()
+        comm = self.comm
+        self.comm_errors = []
+
+        def _exchange(user, send, recv, strip_doubles, stream):
+            try:
+                comm.exchange(strip_doubles)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not propagate into C
+                self.comm_errors.append(repr(e))
+                return -1
+
+        def _wait(user, stream):
+            try:
+                comm.wait()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.comm_errors.append(repr(e))
+                return -1
+
+        def _allreduce(user, buf, count, op, stream):
+            try:
+                comm.allreduce((buf - red_base) // 8, count, op)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.comm_errors.append(repr(e))
+                return -1
+
+        self._cb = (_l.EXCHANGE_FN(_exchange), _l.WAIT_FN(_wait), _l.ALLREDUCE_FN(_allreduce))  # keep alive
+        _l.check(self.L.cup2d_set_comm(self._ctx, self._cb[0], self._cb[1], self._cb[2], None,
+                                       vp(comm.send.data_ptr()), vp(comm.recv.data_ptr()), vp(red_base)), "set_comm")

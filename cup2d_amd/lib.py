@@ -17,6 +17,7 @@ TIMER_NAMES = ['advect_stage', 'poisson_rhs', 'sweep_A', 'sweep_B', 'sweep_C', '
                'reduce', 'halo']
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+WAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
 
 # every symbol include/cup2d_hip.h declares (tests check the .so exports all of them)
@@ -91,7 +92,7 @@ def load_library():
     L.cup2d_halo_unpack.argtypes = [vp, i, i, vp]
     L.cup2d_halo_pack_vec.argtypes = [vp, vp, i, i, vp]
     L.cup2d_halo_unpack_vec.argtypes = [vp, vp, i, i, vp]
-    L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, ALLREDUCE_FN, vp, vp, vp]
+    L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, WAIT_FN, ALLREDUCE_FN, vp, vp, vp, vp]
     L.cup2d_set_timing.argtypes = [vp, i]
     L.cup2d_get_timing.argtypes = [vp, i, ctypes.POINTER(d), ctypes.POINTER(i)]
     _LIB = L

@@ -168,14 +168,25 @@ int cup2d_halo_unpack_vec(cup2d_ctx *ctx, double *device_vec, int dim, int width
 
 /* Communication callbacks so that one code path serves 1 and N GPUs (MPI_Allreduce /
  * Isend/Irecv sites main.cpp:6583-6592, 7138, 7162, cuda.cu:371-375, 448-534).
- * exchange: send_buffer holds nsend strips of `strip_doubles` doubles, recv_buffer must hold
- *           nrecv strips when the callback's work completes on `stream` (stream-ordered).
- * allreduce: in-place on a device buffer of `count` doubles, op 0 = sum, 1 = max. */
+ * exchange : send_buffer holds nsend strips of `strip_doubles` doubles, packed by work already
+ *            enqueued on `stream`.  The callback starts the transfer (RCCL send/recv, typically on
+ *            its own communication stream ordered after `stream`) and returns without blocking.
+ * wait     : makes `stream` wait until recv_buffer holds the nrecv strips of the last exchange.
+ *            May be NULL when exchange itself orders its completion on `stream`.
+ *            Between the two calls the library sweeps the inner blocks -- the overlap of
+ *            computeA (main.cpp:3035-3057) -- and after wait + unpack the halo blocks.
+ * allreduce: in place on `count` doubles of the device reduction buffer, op 0 = sum, 1 = max,
+ *            ordered on `stream`. */
 typedef int (*cup2d_exchange_fn)(void *user, double *device_send, double *device_recv, int strip_doubles,
                                  void *hip_stream);
+typedef int (*cup2d_wait_fn)(void *user, void *hip_stream);
 typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int op, void *hip_stream);
-int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_allreduce_fn allreduce, void *user,
-                   double *device_send_buffer, double *device_recv_buffer);
+/* device_send_buffer / device_recv_buffer: caller-owned device memory for nsend / nrecv strips of
+ * the widest exchange (3 layers x 8 cells x 2 components = 48 doubles per strip).
+ * device_reduce_buffer: caller-owned 8 doubles used for every reduction handed to allreduce
+ * (NULL keeps the context's own). */
+int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,
+                   void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
 
 /* ---------------------------------------------------------------- instrumentation -------- */
 /* HIP-event timing per kernel family, recorded on the context stream around every launch while

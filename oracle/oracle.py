@@ -210,10 +210,12 @@ def _level(n):
     return lv
 
 
-def _run_ref(mode, n, d, **kw):
+def _run_ref(mode, n, d, _threads=None, _timeout=None, **kw):
     cmd = [REF_HARNESS, mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
     env = dict(os.environ)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    if _threads:
+        env.update(OMP_NUM_THREADS=str(int(_threads)), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=_timeout)
     if r.returncode != 0:
         raise RuntimeError("ref_harness failed (%d): %s" % (r.returncode, r.stderr.decode()[-2000:]))
     return r.stdout.decode()
@@ -295,7 +297,7 @@ def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, ma
     return out
 
 
-def ref_step_time(n, steps=3, max_iter=50, nu=1e-3, vel=None):
+def ref_step_time(n, steps=3, max_iter=50, nu=1e-3, vel=None, threads=None, timeout=None):
     """CPU baseline: wall time of one full pass of the reference's own time-loop body
     (main.cpp:6576-7290; Poisson solve = CPU port of cuda.cu capped at max_iter iterations, since the
     reference has no CPU solver).  Returns the harness' JSON dict (median over `steps` steps)."""
@@ -304,7 +306,8 @@ def ref_step_time(n, steps=3, max_iter=50, nu=1e-3, vel=None):
         vel = taylor_green(n)
     with tempfile.TemporaryDirectory() as d:
         _c(vel).tofile(os.path.join(d, "vel.in"))
-        txt = _run_ref("run", n, d, nu=float(nu), steps=int(steps) + 1, maxiter=int(max_iter), dump=0)
+        txt = _run_ref("run", n, d, _threads=threads, _timeout=timeout, nu=float(nu), steps=int(steps) + 1,
+                       maxiter=int(max_iter), dump=0)
     return json.loads(txt.strip().split("\n")[-1])
 
 

@@ -1,0 +1,143 @@
+"""Worker for the multi-process tests (launched by torch.distributed.run).
+
+cpu mode : world_size ranks on the CPU (gloo): exercises PatchTopology + TorchComm("host") -- strips
+           packed with a numpy restatement of halo.hip's layout land in the right ghost cells, and the
+           all-reduce callbacks reduce what the library would hand them.
+gpu mode : world_size ranks sharing cuda:0 (gloo, host-staged): the full DistributedSimulation
+           (HIP pack/unpack, ghost blocks, overlapped sweeps, reductions through the callbacks)
+           against the CPU oracle on the global grid.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def global_field(gnx, gny, dim, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1, 1, (gny, gnx, dim) if dim > 1 else (gny, gnx))
+
+
+def run_cpu(rank, world, px, py, nbx, nby):
+    import torch
+    import torch.distributed as dist
+    from cup2d_amd.distributed import PatchTopology, TorchComm, strip_cells
+    cx, cy = rank % px, rank // px
+    topo = PatchTopology(nbx, nby, px, py, cx, cy)
+    g = topo.grid
+    comm = TorchComm(topo, "host")
+    for dim, width in ((2, 3), (1, 1)):
+        G = global_field(px * nbx * 8, py * nby * 8, dim, seed=100 + dim).reshape(py * nby * 8, px * nbx * 8, dim)
+        patch = G[cy * nby * 8:(cy + 1) * nby * 8, cx * nbx * 8:(cx + 1) * nbx * 8]
+        slab = np.zeros((g.nblocks + g.nghost, 64, dim))
+        slab[:g.nblocks] = g.to_blocks(patch if dim > 1 else patch[..., 0]).reshape(g.nblocks, 64, dim)
+        sd = 8 * width * dim
+        send = np.zeros(topo.nsend * sd)
+        for k in range(topo.nsend):  # numpy restatement of k_halo<PACK>
+            cells = strip_cells(int(topo.send_face[k]), width)
+            send[k * sd:(k + 1) * sd] = slab[topo.send_block[k], cells].ravel()
+        comm.send[:send.size] = torch.from_numpy(send)
+        comm.exchange(sd)
+        comm.wait()
+        recv = comm.recv[:topo.nrecv * sd].numpy()
+        for k in range(topo.nrecv):  # k_halo<UNPACK>
+            cells = strip_cells(int(topo.recv_face[k]), width)
+            slab[topo.recv_block[k], cells] = recv[k * sd:(k + 1) * sd].reshape(len(cells), dim)
+        # every ghost strip cell must equal the global field at its geometric position
+        checked = 0
+        for gi, (side, pos) in enumerate(g.ghost_coords):
+            gb = g.nblocks + gi
+            bx = cx * nbx + (-1 if side == 0 else nbx if side == 1 else pos)
+            by = cy * nby + (pos if side < 2 else (-1 if side == 2 else nby))
+            blockG = G[by * 8:(by + 1) * 8, bx * 8:(bx + 1) * 8].reshape(64, dim)
+            cells = strip_cells((1, 0, 3, 2)[side], width)
+            assert np.array_equal(slab[gb, cells], blockG[cells]), (rank, side, pos)
+            checked += len(cells)
+        assert checked == topo.nrecv * 8 * width
+    # reductions as the library drives them: sum of 2 at offset 0, max of 1 at offset 2
+    comm.red[:] = torch.tensor([rank + 1.0, 2.0 * rank, -5.0 + rank, 0, 0, 0, 0, 0], dtype=torch.float64)
+    comm.allreduce(0, 2, 0)
+    comm.allreduce(2, 1, 1)
+    assert comm.red[0].item() == world * (world + 1) / 2 and comm.red[1].item() == world * (world - 1)
+    assert comm.red[2].item() == -5.0 + world - 1
+    dist.barrier()
+
+
+def run_gpu(rank, world, px, py, nbx, nby):
+    import torch.distributed as dist
+    from cup2d_amd.distributed import DistributedSimulation
+    from cup2d_amd import lib as L
+    from oracle import oracle as O
+    cx, cy = rank % px, rank // px
+    gnx, gny = px * nbx * 8, py * nby * 8
+    nu = 1e-3
+    vel = O.taylor_green(gnx, noise=0.05, seed=77, ny=gny)
+    h = 1.0 / max(gnx, gny)
+    sl = (slice(cy * nby * 8, (cy + 1) * nby * 8), slice(cx * nbx * 8, (cx + 1) * nbx * 8))
+    sim = DistributedSimulation(nbx, nby, px, py, nu=nu, device=0)
+    assert sim.h == h
+    sim.set_math(True)
+    sim.vel = vel[sl]
+    umax = sim.max_abs_vel()
+    assert umax == np.abs(vel).max()
+    dt = sim.compute_dt()
+    assert dt == O.compute_dt(h, nu, 0.5, umax)
+    # advect-diffuse RK2 with halo-3 exchanges and the inner/halo split: bit-identical to the global oracle
+    sim.advect_diffuse_rk2(dt)
+    ref, _ = O.rk2_advect_diffuse(vel, h, nu, dt)
+    assert np.array_equal(sim.vel, ref[sl]), "rk2 mismatch on rank %d" % rank
+    # Poisson rhs (halo-1 exchanges of vel and pold)
+    rng = np.random.default_rng(5)
+    pres = rng.uniform(-1, 1, (gny, gnx))
+    sim.pres = pres[sl]
+    sim.poisson_rhs(dt)
+    bref = O.laplacian_sub(pres, O.pressure_rhs(ref, h, dt))
+    assert np.array_equal(sim.tmp, bref[sl]), "poisson rhs mismatch"
+    # solve: reductions through the all-reduce callback, Krylov halos overlapped
+    info = sim.poisson_solve(tol=1e-9, rel_tol=0.0, max_restarts=100)
+    xo, io = O.bicgstab(bref, tol=1e-9, max_restarts=100)
+    assert abs(info["iters"] - io["iters"]) <= max(3, io["iters"] // 10), (info, io)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (cx, cy, sim.pres))
+    X = np.zeros((gny, gnx))
+    for (ax, ay, xl) in gathered:
+        X[ay * nby * 8:(ay + 1) * nby * 8, ax * nbx * 8:(ax + 1) * nbx * 8] = xl
+    assert np.abs(bref - O.apply_A(X)).max() <= 1.0001e-9
+    # projection: global mean removal via all-reduce + halo-1 exchange of pres
+    sim.project(dt)
+    pnew = O.pressure_update(X, pres, h)
+    vnew = O.add_scaled(ref, O.pressure_correction(pnew, h, dt), h)
+    assert np.abs(sim.pres - pnew[sl]).max() < 1e-9
+    assert np.abs(sim.vel - vnew[sl]).max() < 1e-9
+    # whole steps
+    sim.vel = vel[sl]
+    sim.fill(L.PRES, 0.0)
+    v, p = vel.copy(), np.zeros((gny, gnx))
+    for _ in range(2):
+        r = sim.step(tol=1e-9, rel_tol=0.0, max_restarts=100)
+        v, p, dt2, _i = O.step(v, p, h, nu, 0.5, tol=1e-9, max_restarts=100)
+        assert abs(r["dt"] - dt2) < 1e-12 * dt2
+    assert np.abs(sim.vel - v[sl]).max() < 1e-7
+    assert not sim.comm_errors, sim.comm_errors
+    dist.barrier()
+    sim.close()
+
+
+def main():
+    import torch.distributed as dist
+    mode = sys.argv[1]
+    px, py, nbx, nby = (int(a) for a in sys.argv[2:6])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == px * py
+    (run_cpu if mode == "cpu" else run_gpu)(rank, world, px, py, nbx, nby)
+    if rank == 0:
+        print("DIST_OK mode=%s world=%d" % (mode, world))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

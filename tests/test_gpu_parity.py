@@ -141,7 +141,9 @@ def test_solver_tolerances_and_zero_tolerance_mode(gpu_lib, oracle, n):
         x = s.pres
         assert abs(info["iters"] - io["iters"]) <= max(3, io["iters"] // 10)
         assert np.abs(b - oracle.apply_A(x)).max() <= 1.0001e-8
-        assert np.abs((x - x.mean()) - (xo - xo.mean())).max() < 1e-6
+        # both satisfy |b - A x|_inf <= 1e-8; the solutions then differ by at most ~|A^-1| * 2e-8, and
+        # |A^-1| ~ (n/pi)^2 for the Neumann Laplacian in cell units
+        assert np.abs((x - x.mean()) - (xo - xo.mean())).max() < 2e-8 * (n / np.pi) ** 2
         # relative tolerance stop (main.cpp -poissonTolRel)
         s.fill(L.PRES, 0.0)
         info = s.poisson_solve(tol=0.0, rel_tol=1e-3, max_restarts=0)

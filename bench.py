@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(cores, 64))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(cores, 16): the reference's per-block loops stop scaling there)")
     args = ap.parse_args()
 
     import torch
@@ -153,7 +153,7 @@ def main():
         try:
             from oracle import oracle as O
             if O.have_reference():
-                thr = args.cpu_threads or min(os.cpu_count() or 1, 64)
+                thr = args.cpu_threads or min(os.cpu_count() or 1, 16)
                 r = O.ref_step_time(args.cpu_n, steps=2, max_iter=args.iters, threads=thr, timeout=150)
                 cpu = {"value": round(args.cpu_n ** 2 / r["median_step_s"] / 1e6, 4), "unit": "Mcell-updates/s",
                        "cores": r["threads"], "kind": "reference",

@@ -119,7 +119,7 @@ def run_gpu(rank, world, px, py, nbx, nby):
     for _ in range(2):
         r = sim.step(tol=1e-9, rel_tol=0.0, max_restarts=100)
         v, p, dt2, _i = O.step(v, p, h, nu, 0.5, tol=1e-9, max_restarts=100)
-        assert abs(r["dt"] - dt2) < 1e-12 * dt2
+        assert abs(r["dt"] - dt2) < 1e-7 * dt2  # step 2's dt follows a projection solved to 1e-9
     assert np.abs(sim.vel - v[sl]).max() < 1e-7
     assert not sim.comm_errors, sim.comm_errors
     dist.barrier()

@@ -14,9 +14,31 @@
 // reads one small struct per iteration to learn whether to stop.
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "block.h"
+#include "precond_mfma.h"
 
 namespace cup2d {
+
+// CUP2D_PRECOND=lds selects the LDS-fed scalar-FMA preconditioner kernels (kept for A/B timing);
+// default is the FP64 MFMA path of precond_mfma.h.
+static bool use_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("CUP2D_PRECOND");
+    v = (e && e[0] == 'l') ? 0 : 1;
+  }
+  return v == 1;
+}
+// grid of the MFMA sweeps: 2 workgroups (8 waves) per CU; every wave keeps P_inv in 128 VGPRs
+static int mfma_grid(const cup2d_ctx *c, int count) {
+  const int ntiles = (count + 15) / 16;
+  int g = (ntiles + WPG - 1) / WPG;
+  if (g > 512) g = 512;
+  if (g >= 8) g -= g % 8;
+  return g < 1 ? 1 : g;
+}
 
 // ---- preconditioner: z_b = P_inv p_b, 64x64 symmetric (cuda.cu:484-486 Dgemm(T,N)) ----------
 // LDS-resident P_inv (32 KiB per workgroup, loaded once per persistent workgroup); lane i
@@ -51,9 +73,14 @@ __global__ __launch_bounds__(WG) void k_precond(const double *__restrict__ in, d
     }
   }
 }
+__global__ void k_precond_mfma(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ Pinv,
+                               int first, int count);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count) {
   if (count <= 0) return CUP2D_OK;
-  hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
+  if (use_mfma())
+    hipLaunchKernelGGL(k_precond_mfma, dim3(mfma_grid(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
+  else
+    hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
@@ -91,6 +118,109 @@ __global__ __launch_bounds__(WG) void k_sweepA(double *__restrict__ p, const dou
       z[o] = precond_row(sP, sv[wave], lane);
       wave_lds_sync();
     }
+  }
+}
+
+
+// ---- MFMA variants of precond / sweep A / sweep C -------------------------------------------------
+__global__ __launch_bounds__(WG, 2) void k_precond_mfma(const double *__restrict__ in, double *__restrict__ out,
+                                                        const double *__restrict__ Pinv, int first, int count) {
+  const int lane = threadIdx.x & 63;
+  PinvFragments P;
+  P.load(Pinv, lane);
+  const int ntiles = (count + 15) / 16;
+  const TileRange tr = tile_range(ntiles);
+  for (int t = tr.begin; t < tr.end; t += tr.stride) {
+    const size_t base = ((size_t)first + (size_t)t * 16) * BC;
+    const int nvalid = min(16, count - t * 16);
+    const bool ok = (lane & 15) < nvalid;
+    double xa[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) xa[ks] = ok ? in[base + a_offset(lane, ks)] : 0.0;
+    v4f64 acc[4];
+    precond_tile(xa, P, acc);
+    store_tile(out, base, nvalid, lane, acc);
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void k_sweepA_mfma(double *__restrict__ p, const double *__restrict__ nu,
+                                                       const double *__restrict__ r, double *__restrict__ rhat,
+                                                       double *__restrict__ z, const double *__restrict__ Pinv,
+                                                       const KrylovScalars *__restrict__ sc, int count) {
+  if (sc->status != 0) return;
+  const int lane = threadIdx.x & 63;
+  PinvFragments P;
+  P.load(Pinv, lane);
+  const double beta = sc->beta, momega = -sc->omega;
+  const int restart = sc->restart_flag;
+  const int ntiles = (count + 15) / 16;
+  const TileRange tr = tile_range(ntiles);
+  for (int t = tr.begin; t < tr.end; t += tr.stride) {
+    const size_t base = (size_t)t * 16 * BC;
+    const int nvalid = min(16, count - t * 16);
+    const bool ok = (lane & 15) < nvalid;
+    double xa[16];
+    if (restart) {  // cuda.cu:461-476
+#pragma unroll
+      for (int ks = 0; ks < 16; ks++) {
+        const size_t o = base + a_offset(lane, ks);
+        const double rv = ok ? r[o] : 0.0;
+        if (ok) { rhat[o] = rv; p[o] = rv; }
+        xa[ks] = rv;
+      }
+    } else {        // cuda.cu:478-483
+      double pv[16], nv[16], rv[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ks++) {
+        const size_t o = base + a_offset(lane, ks);
+        pv[ks] = ok ? p[o] : 0.0;
+        nv[ks] = ok ? nu[o] : 0.0;
+        rv[ks] = ok ? r[o] : 0.0;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 16; ks++) {
+        double v = pv[ks] + momega * nv[ks];
+        v = v * beta;
+        v = v + rv[ks];
+        xa[ks] = v;
+        if (ok) p[base + a_offset(lane, ks)] = v;
+      }
+    }
+    v4f64 acc[4];
+    precond_tile(xa, P, acc);
+    store_tile(z, base, nvalid, lane, acc);
+  }
+}
+
+__global__ __launch_bounds__(WG, 2) void k_sweepC_mfma(double *__restrict__ r, const double *__restrict__ nu,
+                                                       double *__restrict__ z2, const double *__restrict__ Pinv,
+                                                       const KrylovScalars *__restrict__ sc, int count) {
+  if (sc->status != 0) return;
+  const int lane = threadIdx.x & 63;
+  PinvFragments P;
+  P.load(Pinv, lane);
+  const double malpha = -sc->alpha;
+  const int ntiles = (count + 15) / 16;
+  const TileRange tr = tile_range(ntiles);
+  for (int t = tr.begin; t < tr.end; t += tr.stride) {
+    const size_t base = (size_t)t * 16 * BC;
+    const int nvalid = min(16, count - t * 16);
+    const bool ok = (lane & 15) < nvalid;
+    double rv[16], nv[16], xa[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) {
+      const size_t o = base + a_offset(lane, ks);
+      rv[ks] = ok ? r[o] : 0.0;
+      nv[ks] = ok ? nu[o] : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) {
+      xa[ks] = rv[ks] + malpha * nv[ks];  // cuda.cu:499-502
+      if (ok) r[base + a_offset(lane, ks)] = xa[ks];
+    }
+    v4f64 acc[4];
+    precond_tile(xa, P, acc);
+    store_tile(z2, base, nvalid, lane, acc);
   }
 }
 
@@ -215,12 +345,14 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
 }
 
 // ---- scalar kernels ---------------------------------------------------------------------------
+static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage);
 // finish the per-workgroup partials of slots [0,nsum) (sums) and slot 2 (max) into red[0..2]
+// fused_stage >= 0: also run the scalar update of that stage (single-GPU: no all-reduce in between)
 __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict__ partials, int G, int nsum,
-                                                        int with_max, double *__restrict__ red,
-                                                        const KrylovScalars *__restrict__ sc) {
+                                                        int with_max, double *__restrict__ red, KrylovScalars *sc,
+                                                        int guarded, int fused_stage) {
   __shared__ double sm[3][WG];
-  if (sc && sc->status != 0) return;
+  if (guarded && sc->status != 0) return;
   double a0 = 0, a1 = 0, mx = 0;
   for (int i = threadIdx.x; i < G; i += WG) {
     a0 += partials[i];
@@ -237,7 +369,13 @@ __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { red[0] = sm[0][0]; red[1] = sm[1][0]; red[2] = sm[2][0]; }
+  if (threadIdx.x == 0) {
+    red[0] = sm[0][0]; red[1] = sm[1][0]; red[2] = sm[2][0];
+    if (fused_stage >= 0) {
+      const double loc[3] = {sm[0][0], sm[1][0], sm[2][0]};
+      scalars_update(sc, loc, fused_stage);
+    }
+  }
 }
 
 // beginning of an iteration (cuda.cu:440-477): consumes rho = rhat.r and ||r||^2
@@ -260,9 +398,7 @@ static __device__ void begin_iteration(KrylovScalars *sc) {
 // STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
 // STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
 // STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
-__global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (stage != 0 && sc->status != 0) return;
+static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage) {
   switch (stage) {
   case 0:
     sc->err = sc->err_init = sc->err_opt = red[2];
@@ -293,18 +429,24 @@ __global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int
     break;
   }
 }
+__global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (stage != 0 && sc->status != 0) return;
+  scalars_update(sc, red, stage);
+}
 
 static int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded) {
   ProfScope prof(c, CUP2D_T_SCALARS);
+  const bool split = c->allreduce != nullptr;  // N GPUs: local sums -> all-reduce -> scalar update
   hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(WG), 0, c->stream, c->d_partials, G, nsum, with_max, c->d_red,
-                     guarded ? c->d_sc : nullptr);
+                     c->d_sc, guarded ? 1 : 0, split ? -1 : stage);
   CUP2D_HIP_CHECK(hipGetLastError());
-  if (c->allreduce) {
+  if (split) {
     if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
     if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage);
+    CUP2D_HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage);
-  CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
 
@@ -355,14 +497,24 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
 
-  for (int k = 0; k <= max_iter; k++) {
-    CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
-    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->h_sc->status != 0) break;
+  // The loop is driven by the device-side status word: every kernel of an iteration returns at once
+  // when it is non-zero, so the host may look at it only every few iterations (the reference
+  // synchronises four times PER iteration, cuda.cu:445, 491, 513, 533) without changing the result.
+  const int check_every = 4;
+  for (int k = 0; k <= max_iter + check_every; k++) {
+    if (k % check_every == 0 || k >= max_iter) {
+      CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
+      CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (c->h_sc->status != 0) break;
+    }
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      hipLaunchKernelGGL(k_sweepA, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
-                         c->d_Pinv, c->d_sc, nb);
+      if (use_mfma())
+        hipLaunchKernelGGL(k_sweepA_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r,
+                           c->d_rhat, c->d_z, c->d_Pinv, c->d_sc, nb);
+      else
+        hipLaunchKernelGGL(k_sweepA, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
+                           c->d_Pinv, c->d_sc, nb);
     }
     {
       ProfScope prof(c, CUP2D_T_SWEEP_B);
@@ -374,7 +526,11 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
-      hipLaunchKernelGGL(k_sweepC, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_Pinv, c->d_sc, nb);
+      if (use_mfma())
+        hipLaunchKernelGGL(k_sweepC_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2,
+                           c->d_Pinv, c->d_sc, nb);
+      else
+        hipLaunchKernelGGL(k_sweepC, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_Pinv, c->d_sc, nb);
     }
     {
       ProfScope prof(c, CUP2D_T_SWEEP_D);

@@ -2,15 +2,95 @@
 // and the vorticity functor (a19).
 //
 // Reference: KernelAdvectDiffuse::operator() main.cpp:5441-5503 driven by computeA<VectorLab>
-// (main.cpp:3024-3061) and the RK2 glue main.cpp:6607-6642.  Here one wavefront owns one 8x8
-// block (64 cells = 64 lanes), stages the 14x14 ghosted tile in LDS straight from the
-// device-resident slabs through the neighbour table (no host-side BlockLab, no hash maps),
-// and -- in the fused modes -- applies the Runge-Kutta update in the same pass, so the tmpV
-// field and the separate axpy sweep (48 B/cell) of the reference disappear.
+// (main.cpp:3024-3061) and the RK2 glue main.cpp:6607-6642.
+//
+// Mapping.  One wavefront owns one 8x8 block (64 cells = 64 lanes).  The 14x14 ghosted tile is
+// staged in LDS straight from the device-resident slabs through the neighbour table (no host-side
+// BlockLab, no hash maps); the loads of the NEXT block are issued before the current one is
+// computed.  The kernel is FP64-issue bound, not HBM bound, so the work is cut,
+// not the bytes:
+//   * a WENO face value is a function of five cells only (weno.h), so each lane evaluates the
+//     `plus` and `minus` face values about ITS OWN cell once per direction and component (shared
+//     smoothness indicators), the 64 rim centres of the block (centre -1 / centre 8 of every row and
+//     column, both components) are spread over the 64 lanes as one extra reconstruction each, and
+//     the upwind neighbour's value is picked up through LDS: 9 reconstructions per cell, no
+//     divergent upwind branch, where the reference's expression costs 8 (uniform sign) to 16;
+//   * in the fused modes the Runge-Kutta update is applied in the same pass, so the tmpV field and
+//     the separate axpy sweep (48 B/cell) of the reference disappear.
+#include <stdlib.h>
+
 #include "block.h"
 #include "weno.h"
 
 namespace cup2d {
+
+// per-wave LDS: the ghosted tile + the face values handed between lanes
+//   Fx[c][iy][0..8]: index k holds plus about centre k-1 (k = 0..8)   [x direction, component c]
+//   Gx[c][iy][0..8]: index k holds minus about centre k   (k = 0..8)
+//   Fy/Gy[c][0..8][ix]: the same along y
+// The tile rows are LABS = 24 double2 apart, not 14: a ds_read_b128 is serviced in four fixed groups of
+// 16 lanes (MI355X_MICROARCH.md, LDS) and with a 14-slot row stride three lanes of a group share a
+// 16-byte slot (3 LDS cycles per group instead of 1); with 24 every group covers all 16 slots once.
+constexpr int LABS = 24;
+constexpr int FROW = 9;
+struct AdvectLds {
+  double2 lab[LAB3 * LABS];
+  double Fx[2][BS * FROW], Gx[2][BS * FROW];
+  double Fy[2][FROW * BS], Gy[2][FROW * BS];
+};
+
+// registers holding one block's tile while it is in flight from HBM/L2.  Nothing here may touch
+// a loaded value (not even a copy): the first use would put the s_waitcnt right behind the loads and
+// turn the prefetch back into a blocking load.  The wall sign flips are applied in lab3_store.
+struct LabRegs {
+  double2 own, we, sn, old;
+  bool flip_we, flip_sn;
+};
+
+// Branch-free on purpose: lanes 48..63 (no strip cell of their own) re-read their own cell, and a
+// wave past its last block re-reads its current one, so that the loaded registers are never merged
+// with other values at a control-flow join (the compiler would wait for the loads there).
+template <int MODE>
+static __device__ __forceinline__ void lab3_fetch(LabRegs &R, const double2 *__restrict__ f,
+                                                  const double2 *__restrict__ vold, const int4 *__restrict__ nbr4,
+                                                  int b, int lane) {
+  const int4 nb4 = nbr4[b];  // b is wave-uniform: one scalar load
+  const double2 *own = f + (size_t)b * BC;
+  R.own = own[lane];
+  if (MODE == 1) R.old = vold[(size_t)b * BC + lane];
+  const bool strip = lane < 48;
+  const int side = lane >= 24 && strip, t = strip ? lane - 24 * side : 0;
+  {  // W / E strips: 8 rows x 3 columns
+    const int r = t / 3, k = t - 3 * r;
+    const int nb = side ? nb4.y : nb4.x;
+    const int cell_nb = r * BS + (side ? k : 5 + k), cell_own = r * BS + (side ? 7 : 0);
+    const double2 *src = nb >= 0 ? f + (size_t)nb * BC + cell_nb : own + cell_own;
+    R.we = *src;
+    R.flip_we = nb < 0;  // VectorLab::applyBCface, main.cpp:3131-3204: wall-normal component negated
+  }
+  {  // S / N strips: 3 rows x 8 columns
+    const int j = t >> 3, x = t & 7;
+    const int nb = side ? nb4.w : nb4.z;
+    const int cell_nb = (side ? j : 5 + j) * BS + x, cell_own = (side ? 7 : 0) * BS + x;
+    const double2 *src = nb >= 0 ? f + (size_t)nb * BC + cell_nb : own + cell_own;
+    R.sn = *src;
+    R.flip_sn = nb < 0;
+  }
+}
+static __device__ __forceinline__ void lab3_store(const LabRegs &R, int lane, double2 *lab) {
+  const int ix = lane & 7, iy = lane >> 3;
+  lab[(iy + 3) * LABS + ix + 3] = R.own;
+  if (lane < 48) {
+    const int side = lane >= 24, t = lane - 24 * side;
+    const int r = t / 3, k = t - 3 * r;
+    double2 we = R.we, sn = R.sn;
+    if (R.flip_we) we.x = -we.x;
+    if (R.flip_sn) sn.y = -sn.y;
+    lab[(r + 3) * LABS + (side ? 11 + k : k)] = we;
+    const int j = t >> 3, x = t & 7;
+    lab[(side ? 11 + j : j) * LABS + x + 3] = sn;
+  }
+}
 
 // MODE 0: out = rhs                      (the functor alone: tmpV)
 // MODE 1: out = vold + coef * rhs        (RK stage: coef = 0.5/h^2 or 1/h^2, main.cpp:6623, 6639)
@@ -18,42 +98,106 @@ template <class W, int MODE>
 __global__ __launch_bounds__(WG) void k_advect_diffuse(const double2 *__restrict__ vel,
                                                        const double2 *__restrict__ vold,
                                                        double2 *__restrict__ out, const int *__restrict__ nbr,
-                                                       int first, int count, double afac, double dfac, double coef) {
-  __shared__ double2 labs[WPG][LAB3 * LAB3];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double2 *lab = labs[wave];
+                                                       int first, int count, int chunk, double afac, double dfac, double coef) {
+  __shared__ AdvectLds lds[WPG];
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  AdvectLds &L = lds[wave];
+  const int4 *nbr4 = (const int4 *)nbr;
   const int ix = lane & 7, iy = lane >> 3;
-  const GroupRange gr = group_range(count);
-  for (int g = gr.begin; g < gr.end; g += gr.stride) {
-    const int rel = g * WPG + wave;
-    if (rel < count) {
-      const int b = first + rel;
-      load_vector_lab3(vel, nbr, b, lane, lab);
-      wave_lds_sync();
-      double2 xs[7], ys[7];
+  const int c0 = (iy + 3) * LABS + ix + 3;
+
+  // rim assignment of this lane: direction, component, side (0: plus about centre -1, 1: minus
+  // about centre 8), position along the face
+  const int rdir = lane >> 5, rcomp = (lane >> 4) & 1, rside = (lane >> 3) & 1, rpos = lane & 7;
+  const int rc = rside ? 11 : 2;                       // tile coordinate of the rim centre
+  const int rstep = (rside ? -1 : 1) * (rdir ? LABS : 1);  // walk so that s[] is fed mirrored on the high side
+  const int rcen = rdir ? rc * LABS + rpos + 3 : (rpos + 3) * LABS + rc;
+  double *rdst = rdir ? (rside ? &L.Gy[rcomp][8 * BS + rpos] : &L.Fy[rcomp][rpos])
+                      : (rside ? &L.Gx[rcomp][rpos * FROW + 8] : &L.Fx[rcomp][rpos * FROW]);
+
+  const GroupRange gr = chunk > 0 ? group_range_chunked(count, chunk) : group_range(count);
+  int g = gr.begin;
+  bool have = g < gr.end && g * WPG + wave < count;
+  if (!have) return;
+  LabRegs R;
+  lab3_fetch<MODE>(R, vel, vold, nbr4, first + g * WPG + wave, lane);
+  while (have) {
+    const int b = first + g * WPG + wave;
+    lab3_store(R, lane, L.lab);
+    const double2 old = R.old;
+    wave_lds_sync();
+    // prefetch the next block of this wave (its last block is simply fetched twice)
+    g += gr.stride;
+    have = g < gr.end && g * WPG + wave < count;
+    lab3_fetch<MODE>(R, vel, vold, nbr4, have ? first + g * WPG + wave : b, lane);
+
+    // ---- the lane's own centre: cross of half-width 2 ----
+    double2 xs[5], ys[5];
 #pragma unroll
-      for (int k = 0; k < 7; k++) {
-        xs[k] = lab[(iy + 3) * LAB3 + ix + k];
-        ys[k] = lab[(iy + k) * LAB3 + ix + 3];
-      }
-      const double u = xs[3].x, v = xs[3].y;
-      // main.cpp:5493-5496: d/dx upwinds on u, d/dy upwinds on v
-      const double dudx = W::derivative(u, xs[0].x, xs[1].x, xs[2].x, u, xs[4].x, xs[5].x, xs[6].x);
-      const double dudy = W::derivative(v, ys[0].x, ys[1].x, ys[2].x, u, ys[4].x, ys[5].x, ys[6].x);
-      const double dvdx = W::derivative(u, xs[0].y, xs[1].y, xs[2].y, v, xs[4].y, xs[5].y, xs[6].y);
-      const double dvdy = W::derivative(v, ys[0].y, ys[1].y, ys[2].y, v, ys[4].y, ys[5].y, ys[6].y);
-      // main.cpp:5497-5502, same operand order
-      double2 r;
-      r.x = afac * (u * dudx + v * dudy) + dfac * (xs[4].x + xs[2].x + ys[4].x + ys[2].x - 4 * u);
-      r.y = afac * (u * dvdx + v * dvdy) + dfac * (xs[4].y + xs[2].y + ys[4].y + ys[2].y - 4 * v);
-      if (MODE == 1) {
-        const double2 o = vold[(size_t)b * BC + lane];
-        r.x = o.x + r.x * coef;
-        r.y = o.y + r.y * coef;
-      }
-      out[(size_t)b * BC + lane] = r;
-      wave_lds_sync();  // tile is overwritten by the next group
+    for (int k = 0; k < 5; k++) {
+      xs[k] = L.lab[c0 + (k - 2)];
+      ys[k] = L.lab[c0 + (k - 2) * LABS];
     }
+    const double u = xs[2].x, v = xs[2].y;
+    // which face values anybody in this block upwinds on (wave-uniform): x derivatives follow the
+    // sign of u, y derivatives the sign of v (main.cpp:5493-5496)
+    const bool up = u > 0, vp = v > 0;
+    const unsigned long long bu = __ballot(up), bv = __ballot(vp);
+    const bool nPx = bu != 0ull, nMx = bu != ~0ull, nPy = bv != 0ull, nMy = bv != ~0ull;
+    double Pxu, Mxu, Pxv, Mxv, Pyu, Myu, Pyv, Myv;
+    {
+      const double s[5] = {xs[0].x, xs[1].x, xs[2].x, xs[3].x, xs[4].x};
+      W::fluxes(s, nPx, nMx, Pxu, Mxu);
+    }
+    {
+      const double s[5] = {xs[0].y, xs[1].y, xs[2].y, xs[3].y, xs[4].y};
+      W::fluxes(s, nPx, nMx, Pxv, Mxv);
+    }
+    {
+      const double s[5] = {ys[0].x, ys[1].x, ys[2].x, ys[3].x, ys[4].x};
+      W::fluxes(s, nPy, nMy, Pyu, Myu);
+    }
+    {
+      const double s[5] = {ys[0].y, ys[1].y, ys[2].y, ys[3].y, ys[4].y};
+      W::fluxes(s, nPy, nMy, Pyv, Myv);
+    }
+    L.Fx[0][iy * FROW + ix + 1] = Pxu;
+    L.Gx[0][iy * FROW + ix] = Mxu;
+    L.Fx[1][iy * FROW + ix + 1] = Pxv;
+    L.Gx[1][iy * FROW + ix] = Mxv;
+    L.Fy[0][(iy + 1) * BS + ix] = Pyu;
+    L.Gy[0][iy * BS + ix] = Myu;
+    L.Fy[1][(iy + 1) * BS + ix] = Pyv;
+    L.Gy[1][iy * BS + ix] = Myv;
+    // ---- one rim centre per lane ----
+    if (rdir ? (rside ? nMy : nPy) : (rside ? nMx : nPx)) {
+      const double *labd = (const double *)L.lab;
+      const double s0 = labd[2 * (rcen - 2 * rstep) + rcomp], s1 = labd[2 * (rcen - rstep) + rcomp];
+      const double s2 = labd[2 * rcen + rcomp];
+      const double s3 = labd[2 * (rcen + rstep) + rcomp], s4 = labd[2 * (rcen + 2 * rstep) + rcomp];
+      *rdst = W::plus(s0, s1, s2, s3, s4);
+    }
+    wave_lds_sync();
+    // ---- upwind differences (derivative(), main.cpp:202-208) ----
+    // U > 0: plus(c) - plus(c-1)   else: minus(c+1) - minus(c)
+    const double nxu = up ? L.Fx[0][iy * FROW + ix] : L.Gx[0][iy * FROW + ix + 1];
+    const double nxv = up ? L.Fx[1][iy * FROW + ix] : L.Gx[1][iy * FROW + ix + 1];
+    const double nyu = vp ? L.Fy[0][iy * BS + ix] : L.Gy[0][(iy + 1) * BS + ix];
+    const double nyv = vp ? L.Fy[1][iy * BS + ix] : L.Gy[1][(iy + 1) * BS + ix];
+    const double dudx = up ? Pxu - nxu : nxu - Mxu;
+    const double dvdx = up ? Pxv - nxv : nxv - Mxv;
+    const double dudy = vp ? Pyu - nyu : nyu - Myu;
+    const double dvdy = vp ? Pyv - nyv : nyv - Myv;
+    // main.cpp:5497-5502, same operand order
+    double2 r;
+    r.x = afac * (u * dudx + v * dudy) + dfac * (xs[3].x + xs[1].x + ys[3].x + ys[1].x - 4 * u);
+    r.y = afac * (u * dvdx + v * dvdy) + dfac * (xs[3].y + xs[1].y + ys[3].y + ys[1].y - 4 * v);
+    if (MODE == 1) {
+      r.x = old.x + r.x * coef;
+      r.y = old.y + r.y * coef;
+    }
+    out[(size_t)b * BC + lane] = r;
+    wave_lds_sync();  // tile and face values are overwritten by the next block
   }
 }
 
@@ -61,13 +205,16 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
                   double coef, int first, int count) {
   if (count <= 0) return CUP2D_OK;
   const double afac = -dt * c->h, dfac = nu * dt;  // main.cpp:5446-5447
-  const int grid = grid_for(c, count);
   ProfScope prof(c, CUP2D_T_ADVECT_STAGE);
   const double2 *v = (const double2 *)vel, *vo = (const double2 *)vold;
   double2 *o = (double2 *)out;
-#define LAUNCH(Wt, M)                                                                                         \
-  hipLaunchKernelGGL((k_advect_diffuse<Wt, M>), dim3(grid), dim3(WG), 0, c->stream, v, vo, o, c->d_nbr, first, \
-                     count, afac, dfac, coef)
+  // groups (of 4 blocks) per workgroup; CUP2D_ADVECT_CHUNK=0 selects the persistent grid
+  static const int chunk = [] { const char *e = getenv("CUP2D_ADVECT_CHUNK"); return e ? atoi(e) : 16; }();
+#define LAUNCH(Wt, M)                                                                                              \
+  hipLaunchKernelGGL((k_advect_diffuse<Wt, M>),                                                                    \
+                     dim3(chunk > 0 ? chunked_grid(count, chunk)                                                   \
+                                    : resident_grid(c, reinterpret_cast<const void *>(&k_advect_diffuse<Wt, M>), count)), \
+                     dim3(WG), 0, c->stream, v, vo, o, c->d_nbr, first, count, chunk, afac, dfac, coef)
   if (c->math == CUP2D_MATH_STRICT) {
     if (mode == 0) LAUNCH(WenoStrict, 0); else LAUNCH(WenoStrict, 1);
   } else {

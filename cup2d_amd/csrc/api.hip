@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface declared in include/cup2d_hip.h
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -62,6 +63,27 @@ static void build_P_inv(std::vector<double> &P) {
 
 static size_t slab_doubles(const cup2d_ctx *c, int dim) { return (size_t)c->ntotal * BC * dim; }
 
+int resident_grid(cup2d_ctx *c, const void *kernel, int count) {
+  int per_cu = 0;
+  for (auto &e : c->resident)
+    if (e.first == kernel) per_cu = e.second;
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WG, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    if (const char *e = getenv("CUP2D_WGS_PER_CU")) {  // tuning aid: cap the persistent grid
+      const int cap = atoi(e);
+      if (cap >= 1 && cap < per_cu) per_cu = cap;
+    }
+    c->resident.emplace_back(kernel, per_cu);
+  }
+  const int groups = (count + WPG - 1) / WPG;
+  int g = per_cu * (c->num_cus > 0 ? c->num_cus : 256);
+  if (g > c->grid) g = c->grid;
+  if (g > groups) g = groups;
+  if (g >= 8) g -= g % 8;  // equal share per XCD
+  return g < 1 ? 1 : g;
+}
+
 int prof_resolve(cup2d_ctx *c) {
   if (c->prof_used == 0) return CUP2D_OK;
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -113,6 +135,11 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   c->n_inner = n_inner;
   c->h = h;
   c->grid = MAX_GRID;
+  {
+    hipDeviceProp_t prop;
+    CUP2D_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+  }
   CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   CUP2D_HIP_CHECK(hipMalloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
@@ -132,6 +159,18 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   build_P_inv(c->h_Pinv);
   CUP2D_HIP_CHECK(hipMalloc(&c->d_Pinv, BC * BC * sizeof(double)));
   CUP2D_HIP_CHECK(hipMemcpy(c->d_Pinv, c->h_Pinv.data(), BC * BC * sizeof(double), hipMemcpyHostToDevice));
+  {  // T = tridiag(-1, 2, -1) (8x8) = Q diag(lam) Q^T: the factors of A_loc = T (x) I + I (x) T
+    double fd[BC + BS];
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < BS; i++) {
+      for (int k = 0; k < BS; k++) fd[i * BS + k] = sqrt(2.0 / (BS + 1)) * sin((i + 1) * (k + 1) * pi / (BS + 1));
+      fd[BC + i] = 2.0 - 2.0 * cos((i + 1) * pi / (BS + 1));
+    }
+    for (int i = 0; i < BS; i++)  // exact symmetry
+      for (int k = i + 1; k < BS; k++) fd[k * BS + i] = fd[i * BS + k];
+    CUP2D_HIP_CHECK(hipMalloc(&c->d_fd, sizeof fd));
+    CUP2D_HIP_CHECK(hipMemcpy(c->d_fd, fd, sizeof fd, hipMemcpyHostToDevice));
+  }
   CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * PSTRIDE));
   CUP2D_HIP_CHECK(hipMalloc(&c->d_red_own, sizeof(double) * 8));
   c->d_red = c->d_red_own;
@@ -149,7 +188,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipFree(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
   (void)hipFree(c->d_vscratch);
-  double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_partials, c->d_red_own};
+  double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_fd, c->d_partials, c->d_red_own};
   for (double *p : kv) (void)hipFree(p);
   (void)hipFree(c->d_sc);
   (void)hipHostFree(c->h_sc);

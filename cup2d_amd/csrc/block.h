@@ -32,7 +32,22 @@ static __device__ __forceinline__ GroupRange group_range(int count) {
   }
   return r;
 }
-
+// Chunked variant for the FP64-issue-bound kernels: the grid has MORE workgroups than fit on the chip
+// and each one walks `chunk` consecutive groups (stride 1) of its XCD's contiguous range.  VALU issue
+// is arbitrated oldest-wave-first, so with one long-lived wave per slot the oldest wave of a SIMD races
+// ahead and the youngest finishes alone at a third of the issue rate (measured: average wave lifetime
+// 72 % of the kernel time); short-lived workgroups are replaced as they retire, which keeps four waves
+// per SIMD until the end.  launch with chunked_grid().
+static __device__ __forceinline__ GroupRange group_range_chunked(int count, int chunk) {
+  const int groups = (count + WPG - 1) / WPG;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long long lo = (long long)groups * xcd / 8, hi = (long long)groups * (xcd + 1) / 8;
+  GroupRange r;
+  r.begin = (int)lo + slot * chunk;
+  r.end = min((int)hi, r.begin + chunk);
+  r.stride = 1;
+  return r;
+}
 static __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS traffic between lanes of ONE wave needs no s_barrier: a wave's DS operations execute in
@@ -89,14 +104,13 @@ static __device__ __forceinline__ void load_vector_lab3(const double2 *__restric
 constexpr int LAB1 = BS + 2;
 // ghost source for lane 0..31: side 0..3 = W,E,S,N, position 0..7 along the face
 static __device__ __forceinline__ void lab1_slot(int lane, int &side, int &src_cell, int &edge_cell, int &lab_idx) {
+  // branch-free (selects, no switch): the callers keep the result in registers across their block loop
   side = lane >> 3;
   const int q = lane & 7;
-  switch (side) {
-  case 0: src_cell = q * BS + 7; edge_cell = q * BS; lab_idx = (q + 1) * LAB1; break;
-  case 1: src_cell = q * BS; edge_cell = q * BS + 7; lab_idx = (q + 1) * LAB1 + 9; break;
-  case 2: src_cell = 7 * BS + q; edge_cell = q; lab_idx = q + 1; break;
-  default: src_cell = q; edge_cell = 7 * BS + q; lab_idx = 9 * LAB1 + q + 1; break;
-  }
+  const bool horiz = side < 2, hi = side & 1;
+  src_cell = horiz ? q * BS + (hi ? 0 : 7) : (hi ? q : 7 * BS + q);
+  edge_cell = horiz ? q * BS + (hi ? 7 : 0) : (hi ? 7 * BS + q : q);
+  lab_idx = horiz ? (q + 1) * LAB1 + (hi ? 9 : 0) : (hi ? 9 * LAB1 : 0) + q + 1;
 }
 // scalar, Neumann wall (ScalarLab::Neumann2D, main.cpp:3210-3255): ghost = edge cell
 static __device__ __forceinline__ void load_scalar_lab1(const double *__restrict__ f, const int *__restrict__ nbr,
@@ -109,6 +123,35 @@ static __device__ __forceinline__ void load_scalar_lab1(const double *__restrict
     lab1_slot(lane, side, src, edge, li);
     const int nb = nbr[4 * b + side];
     lab[li] = nb >= 0 ? f[(size_t)nb * BC + src] : own[edge];
+  }
+}
+// the same tile split into "issue the global loads" and "write them to LDS", so that a persistent
+// wave can have its NEXT block in flight while it works on the current one
+struct ScalarLab1Regs {
+  double own, ghost;
+};
+static __device__ __forceinline__ ScalarLab1Regs fetch_scalar_lab1(const double *__restrict__ f,
+                                                                   const int4 *__restrict__ nbr4, int b, int lane) {
+  // branch-free (lanes 32..63 re-read their own cell): a loaded register that is merged with another
+  // value at a control-flow join makes the compiler wait for the load right there
+  ScalarLab1Regs R;
+  const int4 nb4 = nbr4[b];  // b is wave-uniform: one scalar load
+  const double *own = f + (size_t)b * BC;
+  R.own = own[lane];
+  int side, src, edge, li;
+  lab1_slot(lane & 31, side, src, edge, li);
+  const int nb = side == 0 ? nb4.x : side == 1 ? nb4.y : side == 2 ? nb4.z : nb4.w;
+  const double *g = lane < 32 ? (nb >= 0 ? f + (size_t)nb * BC + src : own + edge) : own + lane;
+  R.ghost = *g;
+  return R;
+}
+static __device__ __forceinline__ void store_scalar_lab1(const ScalarLab1Regs &R, int lane, double *lab) {
+  const int ix = lane & 7, iy = lane >> 3;
+  lab[(iy + 1) * LAB1 + ix + 1] = R.own;
+  if (lane < 32) {
+    int side, src, edge, li;
+    lab1_slot(lane, side, src, edge, li);
+    lab[li] = R.ghost;
   }
 }
 // vector, free-slip wall

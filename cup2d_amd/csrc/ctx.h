@@ -73,7 +73,9 @@ struct cup2d_ctx {
   int nblocks = 0, nghost = 0, ntotal = 0, n_inner = 0;
   double h = 0;
   int math = CUP2D_MATH_FAST;
-  int grid = 0;  // persistent grid size
+  int grid = 0;  // persistent grid size (upper bound)
+  int num_cus = 0;
+  std::vector<std::pair<const void *, int>> resident;  // kernel -> workgroups per CU (occupancy query, cached)
   int32_t *d_nbr = nullptr;
   double *d_field[CUP2D_NFIELDS] = {nullptr};
   double *d_vscratch = nullptr;  // RK2 mid-point velocity (vector slab)
@@ -81,6 +83,7 @@ struct cup2d_ctx {
   double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_nu = nullptr, *d_t = nullptr;
   double *d_z = nullptr, *d_z2 = nullptr, *d_xopt = nullptr;
   double *d_Pinv = nullptr;
+  double *d_fd = nullptr;  // eigenvectors Q[64] + eigenvalues lam[8] of the 8x8 second-difference matrix
   std::vector<double> h_Pinv;
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
@@ -127,6 +130,20 @@ static inline int grid_for(const cup2d_ctx *c, int count) {
   int g = groups < c->grid ? groups : c->grid;
   if (g >= 8) g -= g % 8;  // equal share per XCD
   return g < 1 ? 1 : g;
+}
+
+// Persistent grid of a kernel whose workgroups loop over blocks: exactly as many workgroups as are
+// resident at once (occupancy query x CUs, multiple of the 8 XCDs), so that every workgroup gets the
+// same share and there is no second, partially filled round of workgroups -- on the FP64-bound WENO5
+// kernel (4 workgroups per CU by registers) a 2048-workgroup grid ran as two rounds with a ragged
+// tail (VALU busy 71 % of the kernel time).  Only speed depends on this number.
+int resident_grid(cup2d_ctx *c, const void *kernel, int count);
+
+// grid of a chunked launch (group_range_chunked): 8 x the slots the largest XCD share needs
+static inline int chunked_grid(int count, int chunk) {
+  const int groups = (count + WPG - 1) / WPG;
+  const int per_xcd = (groups + 7) / 8;  // >= every (hi - lo)
+  return 8 * ((per_xcd + chunk - 1) / chunk);
 }
 
 int prof_resolve(cup2d_ctx *c);

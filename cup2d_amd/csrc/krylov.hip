@@ -21,16 +21,23 @@
 
 namespace cup2d {
 
-// CUP2D_PRECOND=lds selects the LDS-fed scalar-FMA preconditioner kernels (kept for A/B timing);
-// default is the FP64 MFMA path of precond_mfma.h.
-static bool use_mfma() {
+// Three implementations of the block-Jacobi preconditioner z_b = P_inv p_b, selectable with
+// CUP2D_PRECOND for A/B timing (all three apply the same operator; they differ by round-off only):
+//   fd   (default) fast diagonalisation: A_loc = T (x) I + I (x) T with T = tridiag(-1,2,-1) = Q diag(lam) Q^T,
+//                  so P_inv = -(Q (x) Q) diag(1/(lam_i+lam_j)) (Q (x) Q)^T: four 8x8x8 products per block
+//                  (32 FMAs per cell instead of 64), one wave per block, coalesced loads
+//   mfma           dense 64x64 product on v_mfma_f64_16x16x4_f64 (precond_mfma.h), 16 blocks per wave
+//   lds            dense product with P_inv in LDS and scalar FMAs (the first version)
+enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
+static int precond_kind() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("CUP2D_PRECOND");
-    v = (e && e[0] == 'l') ? 0 : 1;
+    v = !e ? PRECOND_FD : (e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD));
   }
-  return v == 1;
+  return v;
 }
+static bool use_mfma() { return precond_kind() == PRECOND_MFMA; }
 // grid of the MFMA sweeps: 2 workgroups (8 waves) per CU; every wave keeps P_inv in 128 VGPRs
 static int mfma_grid(const cup2d_ctx *c, int count) {
   const int ntiles = (count + 15) / 16;
@@ -73,11 +80,149 @@ __global__ __launch_bounds__(WG) void k_precond(const double *__restrict__ in, d
     }
   }
 }
+
+// ---- fast-diagonalisation preconditioner ------------------------------------------------------
+// fd[0..63] = Q[i][k] = sqrt(2/9) sin((i+1)(k+1)pi/9) (symmetric, orthogonal), fd[64..71] = lam_k =
+// 2 - 2cos((k+1)pi/9): the eigen-decomposition of the 8x8 Dirichlet second-difference matrix, built
+// on the host in cup2d_create.  A lane (ix, iy) keeps row ix and row iy of Q in registers.
+struct FdBasis {
+  double qx[BS], qy[BS], sc;
+  __device__ __forceinline__ void load(const double *__restrict__ fd, int ix, int iy) {
+#pragma unroll
+    for (int k = 0; k < BS; k++) {
+      qx[k] = fd[ix * BS + k];
+      qy[k] = fd[iy * BS + k];
+    }
+    sc = -1.0 / (fd[BC + ix] + fd[BC + iy]);
+  }
+};
+// z = P_inv v for the block held one cell per lane; bufA / bufB: 64 doubles of LDS each, private
+// to the wave.  Four small products X Q, Q^T (.), scale, Q (.), (.) Q^T; rows come back as
+// ds_read_b128, columns as ds_read_b64 at immediate offsets.
+static __device__ __forceinline__ double precond_fd(double v, const FdBasis &B, double *bufA, double *bufB, int ix,
+                                                    int iy, int lane) {
+  bufA[lane] = v;
+  wave_lds_sync();
+  double t = 0.0;
+#pragma unroll
+  for (int j = 0; j < BS; j++) t = __builtin_fma(bufA[iy * BS + j], B.qx[j], t);
+  bufB[lane] = t;
+  wave_lds_sync();
+  double y = 0.0;
+#pragma unroll
+  for (int i = 0; i < BS; i++) y = __builtin_fma(bufB[i * BS + ix], B.qy[i], y);
+  y *= B.sc;
+  bufA[lane] = y;
+  wave_lds_sync();
+  double w = 0.0;
+#pragma unroll
+  for (int k = 0; k < BS; k++) w = __builtin_fma(bufA[k * BS + ix], B.qy[k], w);
+  bufB[lane] = w;
+  wave_lds_sync();
+  double z = 0.0;
+#pragma unroll
+  for (int k = 0; k < BS; k++) z = __builtin_fma(bufB[iy * BS + k], B.qx[k], z);
+  wave_lds_sync();
+  return z;
+}
+
+__global__ __launch_bounds__(WG) void k_precond_fd(const double *__restrict__ in, double *__restrict__ out,
+                                                   const double *__restrict__ fd, int first, int count) {
+  __shared__ double buf[WPG][2][BC];
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ix = lane & 7, iy = lane >> 3;
+  FdBasis B;
+  B.load(fd, ix, iy);
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      const size_t o = (size_t)(first + rel) * BC + lane;
+      out[o] = precond_fd(in[o], B, buf[wave][0], buf[wave][1], ix, iy, lane);
+    }
+  }
+}
+
+// sweep A, fast-diagonalisation preconditioner; the next block's p, nu, r are in flight while the
+// current block is transformed
+__global__ __launch_bounds__(WG) void k_sweepA_fd(double *__restrict__ p, const double *__restrict__ nu,
+                                                  const double *__restrict__ r, double *__restrict__ rhat,
+                                                  double *__restrict__ z, const double *__restrict__ fd,
+                                                  const KrylovScalars *__restrict__ sc, int count) {
+  __shared__ double buf[WPG][2][BC];
+  if (sc->status != 0) return;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ix = lane & 7, iy = lane >> 3;
+  FdBasis B;
+  B.load(fd, ix, iy);
+  const double beta = sc->beta, momega = -sc->omega;
+  const int restart = sc->restart_flag;
+  const GroupRange gr = group_range(count);
+  int g = gr.begin;
+  bool have = g < gr.end && g * WPG + wave < count;
+  if (!have) return;
+  // loads are unconditional and never merged with other values at a join, so that the wave does not
+  // wait for its prefetch (a wave past its last block re-reads the current one)
+  size_t o = (size_t)(g * WPG + wave) * BC + lane;
+  double pv = p[o], nv = nu[o], rv = r[o];
+  while (have) {
+    double v;
+    if (restart) {  // cuda.cu:461-476: rhat = r, nu = p = 0  =>  p = r
+      rhat[o] = rv;
+      v = rv;
+    } else {        // cuda.cu:478-483: p += (-omega) nu ; p *= beta ; p += r
+      v = pv + momega * nv;
+      v = v * beta;
+      v = v + rv;
+    }
+    g += gr.stride;
+    have = g < gr.end && g * WPG + wave < count;
+    const size_t on = have ? (size_t)(g * WPG + wave) * BC + lane : o;
+    pv = p[on];
+    nv = nu[on];
+    rv = r[on];
+    p[o] = v;
+    z[o] = precond_fd(v, B, buf[wave][0], buf[wave][1], ix, iy, lane);
+    o = on;
+  }
+}
+
+__global__ __launch_bounds__(WG) void k_sweepC_fd(double *__restrict__ r, const double *__restrict__ nu,
+                                                  double *__restrict__ z2, const double *__restrict__ fd,
+                                                  const KrylovScalars *__restrict__ sc, int count) {
+  __shared__ double buf[WPG][2][BC];
+  if (sc->status != 0) return;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ix = lane & 7, iy = lane >> 3;
+  FdBasis B;
+  B.load(fd, ix, iy);
+  const double malpha = -sc->alpha;
+  const GroupRange gr = group_range(count);
+  int g = gr.begin;
+  bool have = g < gr.end && g * WPG + wave < count;
+  if (!have) return;
+  size_t o = (size_t)(g * WPG + wave) * BC + lane;
+  double rv = r[o], nv = nu[o];
+  while (have) {
+    const double v = rv + malpha * nv;  // cuda.cu:499-502
+    g += gr.stride;
+    have = g < gr.end && g * WPG + wave < count;
+    const size_t on = have ? (size_t)(g * WPG + wave) * BC + lane : o;
+    rv = r[on];
+    nv = nu[on];
+    r[o] = v;
+    z2[o] = precond_fd(v, B, buf[wave][0], buf[wave][1], ix, iy, lane);
+    o = on;
+  }
+}
+
 __global__ void k_precond_mfma(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ Pinv,
                                int first, int count);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count) {
   if (count <= 0) return CUP2D_OK;
-  if (use_mfma())
+  if (precond_kind() == PRECOND_FD)
+    hipLaunchKernelGGL(k_precond_fd, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_fd, first, count);
+  else if (use_mfma())
     hipLaunchKernelGGL(k_precond_mfma, dim3(mfma_grid(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
   else
     hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
@@ -234,28 +379,64 @@ __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, do
                                                 int first, int count, int poff) {
   __shared__ double slabs[WPG][LAB1 * LAB1];
   if (sc->status != 0) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double *slab = slabs[wave];
+  const int4 *nbr4 = (const int4 *)nbr;
   const int ix = lane & 7, iy = lane >> 3;
   const int c0 = (iy + 1) * LAB1 + ix + 1;
   double acc[NDOT];
 #pragma unroll
   for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
+  // Two blocks of this wave are in flight while a third is computed (register double buffer, loop
+  // unrolled by two): 24 B/cell of streaming needs more bytes in flight per wave than one 8x8 block.
   const GroupRange gr = group_range(count);
-  for (int g = gr.begin; g < gr.end; g += gr.stride) {
-    const int rel = g * WPG + wave;
-    if (rel < count) {
-      const int b = first + rel;
-      load_scalar_lab1(x, nbr, b, lane, slab);
-      wave_lds_sync();
+  int g = gr.begin;
+  const auto valid = [&](int gg) { return gg < gr.end && gg * WPG + wave < count; };
+  if (valid(g)) {
+    int b0 = first + g * WPG + wave;
+    int g1 = g + gr.stride;
+    int b1 = valid(g1) ? first + g1 * WPG + wave : b0;
+    ScalarLab1Regs R0 = fetch_scalar_lab1(x, nbr4, b0, lane);
+    double w0 = w[(size_t)b0 * BC + lane];
+    ScalarLab1Regs R1 = fetch_scalar_lab1(x, nbr4, b1, lane);
+    double w1 = w[(size_t)b1 * BC + lane];
+    bool have0 = true, have1 = valid(g1);
+    const auto compute = [&](int b, double wc) {
       const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
       const double yv = l1 + l2 + l3 + l4 - 4 * l0;
-      const size_t o = (size_t)b * BC + lane;
-      y[o] = yv;
-      const double wv = w[o];
-      acc[0] = __builtin_fma(yv, wv, acc[0]);
+      y[(size_t)b * BC + lane] = yv;
+      acc[0] = __builtin_fma(yv, wc, acc[0]);
       if constexpr (NDOT == 2) acc[NDOT - 1] = __builtin_fma(yv, yv, acc[NDOT - 1]);
-      wave_lds_sync();
+    };
+    while (have0) {
+      {
+        store_scalar_lab1(R0, lane, slab);
+        const double wc = w0;
+        const int bc = b0;
+        wave_lds_sync();
+        const int gn = g + 2 * gr.stride;
+        have0 = valid(gn);
+        b0 = have0 ? first + gn * WPG + wave : bc;  // past the end: re-read, branch-free
+        R0 = fetch_scalar_lab1(x, nbr4, b0, lane);
+        w0 = w[(size_t)b0 * BC + lane];
+        compute(bc, wc);
+        wave_lds_sync();
+      }
+      if (!have1) break;
+      {
+        store_scalar_lab1(R1, lane, slab);
+        const double wc = w1;
+        const int bc = b1;
+        wave_lds_sync();
+        const int gn = g + 3 * gr.stride;
+        have1 = valid(gn);
+        b1 = have1 ? first + gn * WPG + wave : bc;
+        R1 = fetch_scalar_lab1(x, nbr4, b1, lane);
+        w1 = w[(size_t)b1 * BC + lane];
+        compute(bc, wc);
+        wave_lds_sync();
+      }
+      g += 2 * gr.stride;
     }
   }
   workgroup_reduce_store<NDOT, false>(acc, partials, 0, poff);
@@ -509,7 +690,10 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     }
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      if (use_mfma())
+      if (precond_kind() == PRECOND_FD)
+        hipLaunchKernelGGL(k_sweepA_fd, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
+                           c->d_fd, c->d_sc, nb);
+      else if (use_mfma())
         hipLaunchKernelGGL(k_sweepA_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r,
                            c->d_rhat, c->d_z, c->d_Pinv, c->d_sc, nb);
       else
@@ -526,7 +710,9 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
-      if (use_mfma())
+      if (precond_kind() == PRECOND_FD)
+        hipLaunchKernelGGL(k_sweepC_fd, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_fd, c->d_sc, nb);
+      else if (use_mfma())
         hipLaunchKernelGGL(k_sweepC_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2,
                            c->d_Pinv, c->d_sc, nb);
       else

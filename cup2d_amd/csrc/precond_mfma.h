@@ -11,7 +11,8 @@
 // as 4 (n-tiles) x 16 (k-steps) MFMAs D(16x16) += A(16x4) B(4x16) with
 //     A[i = blk][kk]  = X[blk][4*ks + kk]          lane l holds  i = l % 16, kk = l / 16
 //     B[kk][j = n]    = P[4*ks + kk][16*nt + j]    lane l holds kk = l / 16,  j = l % 16
-//     D[i][j]                                      lane l, v = 0..3 holds i = 4*(l/16) + v, j = l % 16
+//     D[i][j]                                      lane l, v = 0..3 holds i = (l/16) + 4*v, j = l % 16
+//       (the f64 MFMA's own C/D map; NOT the 4*(l/16)+v map of the f32/bf16 16x16 shapes)
 // The B operands (all of P_inv: 64 doubles per lane, 128 VGPRs) are loaded once per wave and stay in
 // registers while the wave streams tiles; the A operands come straight from global memory in fragment
 // layout (per k-step each lane reads one double; a tile's 8 KiB are consumed completely).
@@ -48,13 +49,13 @@ static __device__ __forceinline__ void precond_tile(const double (&xa)[16], cons
     for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], P.b[ks][nt], acc[nt], 0, 0, 0);
 }
 
-// store the D fragments of a tile: lane l, v -> block 4*(l/16)+v, cell 16*nt + l%16
+// store the D fragments of a tile: lane l, v -> block (l/16)+4*v, cell 16*nt + l%16
 static __device__ __forceinline__ void store_tile(double *__restrict__ z, size_t tile_base, int nvalid, int lane,
                                                   const v4f64 (&acc)[4]) {
   const int j = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int v = 0; v < 4; v++) {
-    const int blk = 4 * q + v;
+    const int blk = q + 4 * v;
     if (blk < nvalid) {
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) z[tile_base + (size_t)blk * BC + 16 * nt + j] = acc[nt][v];

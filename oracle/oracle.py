@@ -14,7 +14,12 @@ import os
 import subprocess
 import tempfile
 
-import numpy as np
+# The restatement's OpenMP loops are tiny; on a 256-hardware-thread GPU host an unset OMP_NUM_THREADS
+# makes every parallel region a 256-thread rendezvous (the solver tests then take minutes, not
+# seconds).  libgomp reads this when it is first loaded, so set it before anything imports it.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
+
+import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")

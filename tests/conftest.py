@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))  # see oracle/oracle.py
+
 import numpy as np
 import pytest
 

@@ -99,7 +99,11 @@ def run_gpu(rank, world, px, py, nbx, nby):
     # solve: reductions through the all-reduce callback, Krylov halos overlapped
     info = sim.poisson_solve(tol=1e-9, rel_tol=0.0, max_restarts=100)
     xo, io = O.bicgstab(bref, tol=1e-9, max_restarts=100)
-    assert abs(info["iters"] - io["iters"]) <= max(3, io["iters"] // 10), (info, io)
+    # BiCGSTAB's iteration count is chaotic in the round-off of its dot products (the decomposition
+    # changes their summation order; the reference's cuBLAS order is itself unspecified): demand the
+    # same convergence, not the same count
+    assert abs(info["iters"] - io["iters"]) <= max(5, io["iters"] // 4), (info, io)
+    assert info["err"] <= 1e-9
     gathered = [None] * world
     dist.all_gather_object(gathered, (cx, cy, sim.pres))
     X = np.zeros((gny, gnx))

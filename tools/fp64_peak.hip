@@ -1,0 +1,86 @@
+// tools/fp64_peak.hip -- measures the FP64 VALU issue ceilings that bound the WENO5 kernel
+// (development aid).  Build: hipcc --offload-arch=gfx950 -O3 tools/fp64_peak.hip -o tools/fp64_peak.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(double *out, int iters, double a, double b) {
+  double x[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = a + threadIdx.x * 1e-9 + i;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (OP == 0) x[i] = __builtin_fma(x[i], a, b);
+      if (OP == 1) x[i] = x[i] * a;
+      if (OP == 2) x[i] = x[i] + b;
+      if (OP == 3) x[i] = __builtin_amdgcn_rcp(x[i]);
+      if (OP == 4) { x[i] = __builtin_fma(x[i], a, b); asm volatile("v_mov_b32 %0, %0" : "+v"(it)); }
+    }
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += x[i];
+  if (s == 12345.678) out[0] = s;
+}
+
+template <int OP>
+static void run(const char *name, int wgs) {
+  double *d;
+  hipMalloc(&d, 8);
+  const int iters = 4096;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k<OP><<<wgs, 256>>>(d, 16, 1.0000001, 1e-9);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k<OP><<<wgs, 256>>>(d, iters, 1.0000001, 1e-9);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  double inst = (double)wgs * 256 * iters * 8;  // lane-instructions
+  double cyc = ms * 1e-3 * 2.4e9 / ((double)wgs * 4 / 1024.0 * iters * 8);  // cycles per wave-instr per SIMD at 2.4 GHz
+  printf("%-10s wgs=%5d  %.3f ms  %.2f T lane-instr/s  (%.2f cyc/wave-instr/SIMD @2.4GHz)\n", name, wgs, ms, inst / ms / 1e9,
+         cyc);
+  hipFree(d);
+}
+
+// accuracy of v_rcp_f64 and of one / two Newton steps on it (decides how many the WENO weights need)
+__global__ void k_rcp_acc(double *err) {
+  double e0 = 0, e1 = 0, e2 = 0;
+  for (int i = 0; i < 4096; i++) {
+    const double d = 1.0 + (threadIdx.x * 4096 + i) * (1.0 / (256.0 * 4096.0)) * 0.999;  // [1,2)
+    const double exact = 1.0 / d;
+    double r = __builtin_amdgcn_rcp(d);
+    e0 = fmax(e0, fabs(r - exact) / exact);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    e1 = fmax(e1, fabs(r - exact) / exact);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    e2 = fmax(e2, fabs(r - exact) / exact);
+  }
+  err[threadIdx.x * 3 + 0] = e0; err[threadIdx.x * 3 + 1] = e1; err[threadIdx.x * 3 + 2] = e2;
+}
+static void rcp_accuracy() {
+  double *d, h[768];
+  hipMalloc(&d, sizeof h);
+  k_rcp_acc<<<1, 256>>>(d);
+  hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+  double m[3] = {0, 0, 0};
+  for (int i = 0; i < 256; i++) for (int j = 0; j < 3; j++) if (h[3 * i + j] > m[j]) m[j] = h[3 * i + j];
+  printf("v_rcp_f64 max rel err: raw %.3e  +1 Newton %.3e  +2 Newton %.3e\n", m[0], m[1], m[2]);
+  hipFree(d);
+}
+
+int main() {
+  rcp_accuracy();
+  for (int wgs : {1024, 2048, 4096}) {
+    run<0>("fma_f64", wgs);
+    run<1>("mul_f64", wgs);
+    run<2>("add_f64", wgs);
+    run<3>("rcp_f64", wgs);
+    run<4>("fma+mov", wgs);
+  }
+  return 0;
+}

@@ -12,9 +12,10 @@ N > 1 : weak scaling, each rank owns a 4096^2-cell patch of a px x py Cartesian 
         (configs[3] is the 2x4 case), face halos packed by HIP kernels and exchanged with RCCL
         send/recv (torch.distributed "nccl"), reductions by all-reduce.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (fused advect-diffuse stage kernel, the
-north-star kernel, timed live with HIP events on its launch stream), "kernels" (per-family GPU time),
-"cpu_baseline" (the reference's own loop on the host cores, bounded sample).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (the dominant kernel of the timed region by GPU
+time, timed live with HIP events on its launch stream), "roofline_north_star" (the fused WENO5
+advect-diffuse stage, the kernel BASELINE.json's target names), "roofline_all" (every kernel family),
+"kernels" (per-family GPU time), "cpu_baseline" (the reference's own loop on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -54,6 +55,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50, help="BiCGSTAB iterations per step")
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(cores, 16): the reference's per-block loops stop scaling there)")
     args = ap.parse_args()
@@ -102,19 +104,28 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    sim.set_timing(True)
-    sync()
-    t0 = time.perf_counter()
-    iters = 0
-    for _ in range(args.steps):
-        iters += one_step()["iters"]
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
+    def timed_steps(with_kernel_timers):
+        sim.set_timing(with_kernel_timers)
+        sync()
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(args.steps):
+            its += one_step()["iters"]
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, its
+
+    # Timed region: EXACTLY --steps steps.  Per-kernel HIP-event pairs are recorded on the launch stream
+    # inside it in SAMPLED mode (every launch outside the solver, every 8th BiCGSTAB iteration: a pair costs
+    # ~4 us of stream time, so full instrumentation would cost 10 % of the step); the roofline objects are
+    # computed from those samples.  The same K steps are repeated afterwards without any events and
+    # reported as ms_per_step_no_kernel_timers.
+    elapsed, iters = timed_steps(0 if args.no_kernel_timers else 2)
     cells_rank = n * n
     cells = cells_rank * world
     value = cells * args.steps / elapsed / 1e6
@@ -123,29 +134,85 @@ def main():
         ms, calls = sim.get_timing(i)
         timers[name] = {"ms_total": round(ms, 4), "launches": calls, "ms_avg": round(ms / calls, 5) if calls else None}
     sim.set_timing(False)
+    elapsed_plain = None
+    if not args.no_kernel_timers:
+        elapsed_plain, _ = timed_steps(False)
 
-    # roofline of the north-star kernel: fused WENO5 advect-diffuse RK stage.  Algorithmic bytes per
-    # cell: stage 1 reads vel 16 B (vold == vel) + writes 16 B = 32; stage 2 reads mid 16
-    # + vold 16 + writes 16 = 48; average 40 B/cell/launch.  ~574 FP64 flops/cell (32 of them divisions)
-    # in the reference's formulation.
-    adv = timers["advect_stage"]
-    roofline = None
-    if adv["launches"]:
-        t_launch = adv["ms_total"] / adv["launches"] * 1e-3
-        gbs = 40.0 * cells_rank / t_launch / 1e9
-        roofline = {"kernel": "k_advect_diffuse (fused RK stage)", "bound": "hbm", "achieved": round(gbs, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_cell": 40.0, "avg_launch_ms": round(t_launch * 1e3, 4),
-                    "mcells_per_s": round(cells_rank / t_launch / 1e6, 1),
-                    "fp64_frac_at_574_flop_per_cell": round(574.0 * cells_rank / t_launch / 1e12 / FP64_PEAK_TFLOPS, 4)}
-    # one BiCGSTAB iteration = sweeps A..E; algorithmic bytes/cell: A 40, B 24, C 32, D 24, E 56 = 176
-    it_ms = sum(timers[k]["ms_total"] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E", "scalars"))
+    # ---- rooflines --------------------------------------------------------------------------------
+    # Algorithmic (compulsory) bytes per cell and launch of every kernel family, FP64, halo re-reads
+    # excluded (DESIGN.md section 4 derives each line):
+    #   advect_stage  stage 1 reads vel 16 + writes mid 16 = 32; stage 2 reads mid 16 + vel 16, writes 16 = 48; mean 40
+    #   poisson_rhs   reads vel 16 + pold 8, writes tmp 8 = 32
+    #   sweep_A       reads p, nu, r 24 + writes p, z 16 = 40      sweep_C  reads r, nu 16 + writes r, z2 16 = 32
+    #   sweep_B / D   reads z (z2) 8 + rhat (r) 8, writes nu (t) 8 = 24
+    #   sweep_E       reads x, z, z2, r, t, rhat 48 + writes x, r 16 = 64
+    ALGO_BYTES = {"advect_stage": 40.0, "poisson_rhs": 32.0, "sweep_A": 40.0, "sweep_B": 24.0, "sweep_C": 32.0,
+                  "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0}
+    KERNEL_OF = {"advect_stage": "k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>",
+                 "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1>",
+                 "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2>", "sweep_E": "k_sweepE", "init_residual": "k_init_residual"}
+    # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on
+    # gfx950), summarised by tools/prof_summary.py from the same bench command: profiles/<tag>_pmc_traffic.json
+    traffic_tab, traffic_src = {}, None
+    prof_dir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(prof_dir):
+        cands = sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_traffic.json"))
+        if cands:
+            traffic_src = "profiles/" + cands[-1]
+            try:
+                traffic_tab = json.load(open(os.path.join(prof_dir, cands[-1])))["kernels"]
+            except Exception:
+                traffic_tab = {}
+
+    def roofline_of(fam):
+        t = timers[fam]
+        if not t["launches"] or fam not in ALGO_BYTES:
+            return None
+        sec = t["ms_total"] / t["launches"] * 1e-3
+        gbs = ALGO_BYTES[fam] * cells_rank / sec / 1e9
+        tr = traffic_tab.get(KERNEL_OF[fam], {}).get("hbm_bytes") if n == 4096 and world == 1 else None
+        return {"kernel": KERNEL_OF[fam], "family": fam, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_source": traffic_src if tr else None,
+                "bytes_per_cell": ALGO_BYTES[fam], "avg_launch_ms": round(sec * 1e3, 4), "launches": t["launches"],
+                "share_of_gpu_time": None}
+
+    # GPU time per step of a family = its (sampled) average launch x launches per step
+    per_step = {"advect_stage": 2, "poisson_rhs": 1, "init_residual": 1, "project": 1, "reduce": 3,
+                "sweep_A": args.iters, "sweep_B": args.iters, "sweep_C": args.iters, "sweep_D": args.iters,
+                "sweep_E": args.iters, "scalars": 3 * args.iters + 1, "halo": 0}
+    step_ms = {f: (timers[f]["ms_avg"] or 0.0) * per_step.get(f, 0) for f in timers}
+    gpu_ms = sum(step_ms.values()) or 1.0
+    all_roof = {}
+    for fam in ALGO_BYTES:
+        r = roofline_of(fam)
+        if r:
+            r["share_of_gpu_time"] = round(step_ms[fam] / gpu_ms, 4)
+            all_roof[fam] = r
+    # "roofline": the dominant kernel of the timed region (largest share of GPU time)
+    dominant = max(all_roof, key=lambda f: step_ms[f]) if all_roof else None
+    roofline = all_roof.get(dominant)
+    # the north-star kernel (fused WENO5 advect-diffuse RK stage) is FP64-issue bound, not HBM bound: next to the
+    # HBM fraction report the FP64 instruction rate against the measured VALU ceiling (tools/fp64_peak.hip:
+    # 32 T lane-instr/s sustained on this chip; 39.3 T at the nominal 2.4 GHz) -- DESIGN.md section 4.1
+    north = dict(all_roof["advect_stage"]) if "advect_stage" in all_roof else None
+    if north:
+        sec = north["avg_launch_ms"] * 1e-3
+        # FP64 VALU instructions executed per cell in a block whose velocity components do not change sign
+        # (counted in the gfx950 ISA of advect.hip; SQ_INSTS_VALU measures 314 VALU instructions of all kinds)
+        fp64_per_cell = 241.0 if args.math == "fast" else 565.0
+        rate = fp64_per_cell * cells_rank / sec / 1e12
+        north.update({"mcells_per_s": round(cells_rank / sec / 1e6, 1), "fp64_instr_per_cell": fp64_per_cell,
+                      "fp64_T_lane_instr_per_s": round(rate, 2), "fp64_frac_of_measured_ceiling_32T": round(rate / 32.0, 4),
+                      "fp64_frac_of_nominal_39.3T": round(rate / 39.3, 4)})
+    # one BiCGSTAB iteration = sweeps A..E + 3 scalar kernels (sum of the sampled average durations)
+    it_bytes = sum(ALGO_BYTES[k] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E"))
     solver = None
-    if iters:
-        t_it = it_ms / iters * 1e-3
-        solver = {"iterations": iters, "ms_per_iteration": round(t_it * 1e3, 4), "bytes_per_cell_iteration": 176,
-                  "achieved_GBs": round(176.0 * cells_rank / t_it / 1e9, 1),
-                  "frac_hbm": round(176.0 * cells_rank / t_it / 1e9 / HBM_PEAK_GBS, 4),
+    if iters and all(timers[k]["launches"] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E", "scalars")):
+        t_it = (sum(timers[k]["ms_avg"] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")) +
+                3 * timers["scalars"]["ms_avg"]) * 1e-3
+        solver = {"iterations": iters, "ms_per_iteration": round(t_it * 1e3, 4), "bytes_per_cell_iteration": it_bytes,
+                  "achieved_GBs": round(it_bytes * cells_rank / t_it / 1e9, 1),
+                  "frac_hbm": round(it_bytes * cells_rank / t_it / 1e9 / HBM_PEAK_GBS, 4),
                   "mcell_iterations_per_s": round(cells_rank / t_it / 1e6, 1)}
 
     cpu = None
@@ -173,13 +240,16 @@ def main():
         out = {
             "metric": "Mcell-updates/sec (advect-diffuse+Poisson sweep) at 4096^2",
             "value": round(value, 3), "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_no_kernel_timers": round(elapsed_plain / args.steps * 1e3, 3) if elapsed_plain else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d uniform cells per GPU (%d^2 8x8 blocks), nu=1e-3, CFL 0.5; step = dt + RK2 WENO5 "
                                    "advect-diffuse + Poisson rhs + %d BiCGSTAB iters (block-Jacobi) + projection"
                                    % (n, n, n // 8, args.iters),
                        "global_cells": cells, "parallelism": par, "math": args.math, "bicgstab_iters_per_step": args.iters},
-            "roofline": roofline, "solver": solver, "kernels": timers, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
+            "kernels": timers, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     sim.close()

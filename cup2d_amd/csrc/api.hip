@@ -177,6 +177,8 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   CUP2D_HIP_CHECK(hipMalloc(&c->d_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_status, sizeof(int) * cup2d_ctx::SOLVE_AHEAD));
+  for (auto &e : c->solve_ev) CUP2D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = c;
   return CUP2D_OK;
 }
@@ -193,6 +195,8 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipFree(c->d_sc);
   (void)hipHostFree(c->h_sc);
   (void)hipHostFree(c->h_red);
+  (void)hipHostFree(c->h_status);
+  for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
   (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -528,7 +532,8 @@ int cup2d_set_timing(cup2d_ctx *c, int enabled) {
   }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->prof_used = 0;
-  c->timing = enabled ? 1 : 0;
+  c->timing = enabled == 2 ? 2 : (enabled ? 1 : 0);
+  c->prof_sample = true;
   for (int i = 0; i < CUP2D_T_NTIMERS; i++) { c->t_ms[i] = 0; c->t_calls[i] = 0; }
   return CUP2D_OK;
 }

@@ -89,6 +89,9 @@ struct cup2d_ctx {
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
   cup2d::KrylovScalars *d_sc = nullptr;
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned
+  static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)
+  int *h_status = nullptr;               // pinned [SOLVE_AHEAD], written by the last scalar kernel of an iteration
+  hipEvent_t solve_ev[SOLVE_AHEAD] = {nullptr};
   double *h_red = nullptr;               // pinned [8]
   cup2d::HaloPlan plan;
   // communication callbacks
@@ -99,7 +102,8 @@ struct cup2d_ctx {
   void *comm_user = nullptr;
   double *d_send = nullptr, *d_recv = nullptr;
   // timing: pool of event pairs, resolved lazily
-  int timing = 0;
+  int timing = 0;          // 0 off, 1 every launch, 2 sampled (every launch outside the solver, every 8th iteration inside)
+  bool prof_sample = true; // sampled mode: record the launches issued now
   std::vector<hipEvent_t> prof_ev;
   std::vector<int> prof_id;
   int prof_used = 0;
@@ -152,7 +156,7 @@ struct ProfScope {
   cup2d_ctx *c;
   int slot;
   ProfScope(cup2d_ctx *c_, int id) : c(c_), slot(-1) {
-    if (!c->timing) return;
+    if (!c->timing || (c->timing == 2 && !c->prof_sample)) return;
     if ((size_t)(2 * c->prof_used + 2) > c->prof_ev.size()) (void)prof_resolve(c);
     slot = c->prof_used++;
     c->prof_id[slot] = id;

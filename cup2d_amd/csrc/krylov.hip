@@ -531,7 +531,7 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
 // fused_stage >= 0: also run the scalar update of that stage (single-GPU: no all-reduce in between)
 __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict__ partials, int G, int nsum,
                                                         int with_max, double *__restrict__ red, KrylovScalars *sc,
-                                                        int guarded, int fused_stage) {
+                                                        int guarded, int fused_stage, int *host_status) {
   __shared__ double sm[3][WG];
   if (guarded && sc->status != 0) return;
   double a0 = 0, a1 = 0, mx = 0;
@@ -555,6 +555,8 @@ __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict
     if (fused_stage >= 0) {
       const double loc[3] = {sm[0][0], sm[1][0], sm[2][0]};
       scalars_update(sc, loc, fused_stage);
+      // end of an iteration: tell the host (pinned, device-visible word) whether the loop is over
+      if (fused_stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -610,22 +612,23 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
     break;
   }
 }
-__global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage) {
+__global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (stage != 0 && sc->status != 0) return;
   scalars_update(sc, red, stage);
+  if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded) {
+static int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr) {
   ProfScope prof(c, CUP2D_T_SCALARS);
   const bool split = c->allreduce != nullptr;  // N GPUs: local sums -> all-reduce -> scalar update
   hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(WG), 0, c->stream, c->d_partials, G, nsum, with_max, c->d_red,
-                     c->d_sc, guarded ? 1 : 0, split ? -1 : stage);
+                     c->d_sc, guarded ? 1 : 0, split ? -1 : stage, host_status);
   CUP2D_HIP_CHECK(hipGetLastError());
   if (split) {
     if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
     if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage);
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage, host_status);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
   return CUP2D_OK;
@@ -667,7 +670,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   const int GP = G_in + G_ha;
 
   {
-    ProfScope prof(c, CUP2D_T_SWEEP_B);
+    ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
     CUP2D_TRY(stencil_sweep(x, [&](int first, int count, int poff, int g) {
       hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
                          c->d_partials, first, count, poff);
@@ -679,15 +682,24 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
 
   // The loop is driven by the device-side status word: every kernel of an iteration returns at once
-  // when it is non-zero, so the host may look at it only every few iterations (the reference
-  // synchronises four times PER iteration, cuda.cu:445, 491, 513, 533) without changing the result.
-  const int check_every = 4;
-  for (int k = 0; k <= max_iter + check_every; k++) {
-    if (k % check_every == 0 || k >= max_iter) {
-      CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
-      CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-      if (c->h_sc->status != 0) break;
+  // when it is non-zero, so iterations may be enqueued speculatively.  The host never drains the
+  // stream inside the loop (the reference synchronises four times PER iteration, cuda.cu:445, 491,
+  // 513, 533): it stays at most AHEAD iterations in front of the GPU by waiting on the event recorded
+  // AHEAD iterations ago, and learns the outcome of that iteration from a pinned word its last
+  // scalar kernel wrote.  At most AHEAD iterations of early-returning kernels are wasted.
+  static const int AHEAD = [] {
+    const char *e = getenv("CUP2D_SOLVE_AHEAD");
+    const int v = e ? atoi(e) : 4;
+    return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
+  }();
+  for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
+  for (int k = 0; k <= max_iter + AHEAD; k++) {
+    const int slot = k % AHEAD;
+    if (k >= AHEAD) {
+      CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
+      if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
+    c->prof_sample = (k % 8 == 0) && k < max_iter;  // sampled timing: an event pair costs ~4 us of stream time
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       if (precond_kind() == PRECOND_FD)
@@ -732,8 +744,12 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
                          c->d_rhat, c->d_sc, c->d_partials, n);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
-    CUP2D_TRY(finish(c, gridE, 2, 1, 3, true));
+    CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
+    CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
+  c->prof_sample = true;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   // cuda.cu:546-547: return x_opt (with the synchronisation the reference omits)
   if (!c->h_sc->x_is_best)
     CUP2D_HIP_CHECK(hipMemcpyAsync(x, c->d_xopt, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

@@ -179,6 +179,7 @@ class Simulation:
 
     # ---- instrumentation -----------------------------------------------------------------------
     def set_timing(self, on=True):
+        """False/0 off, True/1 every launch, 2 sampled (see include/cup2d_hip.h)"""
         _l.check(self.L.cup2d_set_timing(self._ctx, int(on)), "set_timing")
 
     def get_timing(self, timer):

@@ -189,10 +189,12 @@ int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wai
                    void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
 
 /* ---------------------------------------------------------------- instrumentation -------- */
-/* HIP-event timing per kernel family, recorded on the context stream around every launch while
- * enabled (cup2d_set_timing(ctx, 1)); cup2d_get_timing returns accumulated GPU milliseconds and the
- * number of launches since timing was enabled.  Events are resolved lazily (no extra
- * synchronisation per launch). */
+/* HIP-event timing per kernel family, recorded on the context stream around the launches:
+ * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every launch outside the solver, every 8th
+ * BiCGSTAB iteration inside it (an event pair costs ~4 us of stream time; 16 of them per iteration are
+ * 10 % of a 4096^2 step, sampled they are ~1 %); (ctx, 0) off.  cup2d_get_timing returns accumulated GPU
+ * milliseconds and the number of timed launches since timing was enabled.  Events are resolved lazily
+ * (no extra synchronisation per launch). */
 typedef enum {
   CUP2D_T_ADVECT_STAGE = 0, /* fused WENO5 advect-diffuse RK stage (k_advect_diffuse) */
   CUP2D_T_POISSON_RHS = 1,  /* pressure_rhs + pressure_rhs1 fused */
@@ -205,7 +207,8 @@ typedef enum {
   CUP2D_T_PROJECT = 8,      /* mean removal + pressure-gradient update */
   CUP2D_T_REDUCE = 9,       /* max|u| (dt) */
   CUP2D_T_HALO = 10,        /* pack / unpack */
-  CUP2D_T_NTIMERS = 11
+  CUP2D_T_INIT_RESIDUAL = 11, /* r = b - A x0 + its reductions (once per solve) */
+  CUP2D_T_NTIMERS = 12
 } cup2d_timer;
 int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);

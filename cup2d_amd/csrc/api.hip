@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "ctx.h"
 
 namespace cup2d {
@@ -135,6 +137,8 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   c->n_inner = n_inner;
   c->h = h;
   c->grid = MAX_GRID;
+  if (const char *e = getenv("CUP2D_PRECOND"))  // A/B timing aid; cup2d_set_precond is the API
+    c->precond = e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD);
   {
     hipDeviceProp_t prop;
     CUP2D_HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -158,6 +162,9 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   }
   build_P_inv(c->h_Pinv);
   CUP2D_HIP_CHECK(hipMalloc(&c->d_Pinv, BC * BC * sizeof(double)));
+  // the dense kernels read d_Pinv[k][n] as the coefficient of input k in output n, i.e. the transpose of
+  // the row-major matrix the caller means (cuda.cu:484-486 Dgemm(T,N) on a column-major view); the
+  // built-in matrix is exactly symmetric
   CUP2D_HIP_CHECK(hipMemcpy(c->d_Pinv, c->h_Pinv.data(), BC * BC * sizeof(double), hipMemcpyHostToDevice));
   {  // T = tridiag(-1, 2, -1) (8x8) = Q diag(lam) Q^T: the factors of A_loc = T (x) I + I (x) T
     double fd[BC + BS];
@@ -197,6 +204,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipHostFree(c->h_red);
   (void)hipHostFree(c->h_status);
   for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
+  (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
   (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
   (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -424,6 +432,7 @@ static bool scalar_field(int f) { return field_ok(f) && dim_of(f) == 1; }
 int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {
   CUP2D_CHECK_CTX(c);
   if (!scalar_field(dst) || !scalar_field(src) || dst == src) { set_error("apply_A: fields"); return CUP2D_ERR_ARG; }
+  if (c->mat.active) return launch_matvec(c, c->d_field[src], c->d_field[dst]);
   CUP2D_TRY(exchange_halo(c, c->d_field[src], 1, 1));
   return launch_laplacian(c, c->d_field[src], c->d_field[dst], 0, 0, c->nblocks);
 }
@@ -436,6 +445,112 @@ int cup2d_get_P_inv(cup2d_ctx *c, double *P) {
   CUP2D_CHECK_CTX(c);
   if (!P) return CUP2D_ERR_ARG;
   memcpy(P, c->h_Pinv.data(), BC * BC * sizeof(double));
+  return CUP2D_OK;
+}
+
+int cup2d_set_precond(cup2d_ctx *c, int kind) {
+  CUP2D_CHECK_CTX(c);
+  if (kind != PRECOND_LDS && kind != PRECOND_MFMA && kind != PRECOND_FD) { set_error("set_precond: kind %d", kind); return CUP2D_ERR_ARG; }
+  if (kind == PRECOND_FD && c->custom_Pinv) {
+    set_error("set_precond: fast diagonalisation applies only the built-in -(A_loc)^-1");
+    return CUP2D_ERR_ARG;
+  }
+  c->precond = kind;
+  return CUP2D_OK;
+}
+int cup2d_set_P_inv(cup2d_ctx *c, const double *P) {
+  CUP2D_CHECK_CTX(c);
+  if (!P) return CUP2D_ERR_ARG;
+  std::vector<double> builtin;
+  build_P_inv(builtin);
+  double dmax = 0, amax = 0;
+  for (int i = 0; i < BC * BC; i++) {
+    dmax = fmax(dmax, fabs(P[i] - builtin[i]));
+    amax = fmax(amax, fabs(builtin[i]));
+  }
+  // main.cpp:6451-6488 always passes -(A_loc)^-1 (its Cholesky differs from ours by round-off): keep the
+  // fast-diagonalisation kernels for it; anything else goes through the dense 64x64 product
+  c->custom_Pinv = !(dmax <= 1e-12 * amax);
+  if (c->custom_Pinv && c->precond == PRECOND_FD) c->precond = PRECOND_MFMA;
+  c->h_Pinv.assign(P, P + BC * BC);
+  std::vector<double> T(BC * BC);
+  for (int i = 0; i < BC; i++)
+    for (int j = 0; j < BC; j++) T[j * BC + i] = P[i * BC + j];
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  CUP2D_HIP_CHECK(hipMemcpy(c->d_Pinv, T.data(), BC * BC * sizeof(double), hipMemcpyHostToDevice));
+  return CUP2D_OK;
+}
+
+// ---- assembled operator ---------------------------------------------------------------------------
+int cup2d_clear_matrix(cup2d_ctx *c) {
+  CUP2D_CHECK_CTX(c);
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
+  c->mat = SellMatrix();
+  return CUP2D_OK;
+}
+int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *row, const int32_t *col, const double *val) {
+  CUP2D_CHECK_CTX(c);
+  const long long m = (long long)c->nblocks * BC;
+  if (halo < 0 || nnz < 0 || (nnz && (!row || !col || !val))) { set_error("set_matrix_coo: bad argument"); return CUP2D_ERR_ARG; }
+  if ((long long)halo > (long long)c->nghost * BC) {
+    set_error("set_matrix_coo: halo %d does not fit %d ghost blocks", halo, c->nghost);
+    return CUP2D_ERR_ARG;
+  }
+  std::vector<int> cnt((size_t)m, 0);
+  for (long long k = 0; k < nnz; k++) {
+    if (row[k] < 0 || row[k] >= m || col[k] < 0 || col[k] >= m + halo) {
+      set_error("set_matrix_coo: entry %lld (%d, %d) outside %lld x %lld", k, row[k], col[k], m, m + halo);
+      return CUP2D_ERR_ARG;
+    }
+    cnt[row[k]]++;
+  }
+  std::vector<long long> ptr((size_t)c->nblocks + 1, 0);
+  for (int s = 0; s < c->nblocks; s++) {
+    int w = 0;
+    for (int l = 0; l < BC; l++) w = cnt[(size_t)s * BC + l] > w ? cnt[(size_t)s * BC + l] : w;
+    ptr[s + 1] = ptr[s] + (long long)w * BC;
+  }
+  const size_t entries = (size_t)ptr[c->nblocks];
+  std::vector<int32_t> ecol(entries);
+  std::vector<double> eval(entries, 0.0);
+  for (int s = 0; s < c->nblocks; s++)  // padding: own row, coefficient 0
+    for (long long e = ptr[s]; e < ptr[s + 1]; e++) ecol[e] = s * BC + (int)((e - ptr[s]) & 63);
+  std::fill(cnt.begin(), cnt.end(), 0);
+  for (long long k = 0; k < nnz; k++) {  // list order within a row is kept
+    const int r = row[k], s = r >> 6, l = r & 63;
+    const size_t e = (size_t)ptr[s] + (size_t)cnt[r]++ * BC + l;
+    ecol[e] = col[k];
+    eval[e] = val[k];
+  }
+  CUP2D_TRY(cup2d_clear_matrix(c));
+  SellMatrix &M = c->mat;
+  CUP2D_HIP_CHECK(hipMalloc(&M.d_ptr, ptr.size() * sizeof(long long)));
+  CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
+  if (entries) {
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_col, entries * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_val, entries * sizeof(double)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval.data(), entries * sizeof(double), hipMemcpyHostToDevice));
+  }
+  M.entries = entries;
+  M.halo = halo;
+  M.active = true;
+  return CUP2D_OK;
+}
+int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
+  CUP2D_CHECK_CTX(c);
+  if (nsend < 0 || (nsend && !idx)) return CUP2D_ERR_ARG;
+  for (int i = 0; i < nsend; i++)
+    if (idx[i] < 0 || idx[i] >= c->nblocks * BC) { set_error("set_gather: idx[%d] = %d", i, idx[i]); return CUP2D_ERR_ARG; }
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  (void)hipFree(c->mat.d_gather);
+  c->mat.d_gather = nullptr;
+  c->mat.ngather = nsend;
+  if (nsend) {
+    CUP2D_HIP_CHECK(hipMalloc(&c->mat.d_gather, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(c->mat.d_gather, idx, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   return CUP2D_OK;
 }
 
@@ -510,7 +625,8 @@ int cup2d_halo_unpack_vec(cup2d_ctx *c, double *vec, int dim, int width, const d
 int cup2d_set_comm(cup2d_ctx *c, cup2d_exchange_fn ex, cup2d_wait_fn wt, cup2d_allreduce_fn ar, void *user, double *send,
                    double *recv, double *red) {
   CUP2D_CHECK_CTX(c);
-  if (ex && c->nghost > 0 && (!send || !recv)) { set_error("set_comm: buffers"); return CUP2D_ERR_ARG; }
+  // stencil mode unpacks from `recv`; in matrix mode the received entries land in the vector itself
+  if (ex && c->nghost > 0 && (!send || (!recv && !c->mat.active))) { set_error("set_comm: buffers"); return CUP2D_ERR_ARG; }
   c->exchange = ex;
   c->wait = wt;
   c->allreduce = ar;

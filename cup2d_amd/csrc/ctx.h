@@ -64,6 +64,25 @@ struct HaloPlan {
   int32_t *d_recv_block = nullptr, *d_recv_face = nullptr;
 };
 
+// General sparse Poisson operator (the matrix of main.cpp:7034-7112 as LocalSpMatDnVec hands it over,
+// cuda.cu:206-296) in sliced-ELL form with slices of 64 rows: one slice = the 64 rows of one 8x8 block
+// = one wavefront.  Entry k of row (slice s, lane l) sits at ptr[s] + 64*k + l, so a wave reads
+// columns and values with unit stride; every slice is as wide as its longest row (5 on a same-level
+// block, more where coarse-fine interpolation rows exist), padded with (col = own row, val = 0).
+// Columns >= 64*nblocks address halo entries appended to the Krylov vector (cuda.cu:344-402).
+struct SellMatrix {
+  bool active = false;
+  int halo = 0;
+  size_t entries = 0;
+  long long *d_ptr = nullptr;  // [nblocks + 1]
+  int32_t *d_col = nullptr;
+  double *d_val = nullptr;
+  int ngather = 0;             // send_buff_pack (cuda.cu:338-343): d_send[i] = vec[gather[i]]
+  int32_t *d_gather = nullptr;
+};
+
+enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
+
 }  // namespace cup2d
 
 struct cup2d_ctx {
@@ -94,6 +113,9 @@ struct cup2d_ctx {
   hipEvent_t solve_ev[SOLVE_AHEAD] = {nullptr};
   double *h_red = nullptr;               // pinned [8]
   cup2d::HaloPlan plan;
+  cup2d::SellMatrix mat;
+  int precond = cup2d::PRECOND_FD;  // block-Jacobi implementation (krylov.hip); FD needs the built-in P_inv
+  bool custom_Pinv = false;         // cup2d_set_P_inv installed something else than -(A_loc)^-1
   // communication callbacks
   cup2d_exchange_fn exchange = nullptr;
   cup2d_wait_fn wait = nullptr;
@@ -179,6 +201,8 @@ int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, d
 int launch_axpy_field(cup2d_ctx *c, double *y, const double *x, double a, size_t n);
 int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
+int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the installed SellMatrix
+int matrix_exchange(cup2d_ctx *c, double *vec);         // fill vec[m .. m+halo) from the neighbour ranks
 int project_impl(cup2d_ctx *c, double dt);
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,
                int *iters, int *restarts, double *linf, double *linf_init);

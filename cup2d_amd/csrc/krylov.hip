@@ -28,16 +28,8 @@ namespace cup2d {
 //                  (32 FMAs per cell instead of 64), one wave per block, coalesced loads
 //   mfma           dense 64x64 product on v_mfma_f64_16x16x4_f64 (precond_mfma.h), 16 blocks per wave
 //   lds            dense product with P_inv in LDS and scalar FMAs (the first version)
-enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
-static int precond_kind() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("CUP2D_PRECOND");
-    v = !e ? PRECOND_FD : (e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD));
-  }
-  return v;
-}
-static bool use_mfma() { return precond_kind() == PRECOND_MFMA; }
+// (enum PRECOND_* in ctx.h; the context's default comes from CUP2D_PRECOND, cup2d_set_precond overrides it)
+static bool use_mfma(const cup2d_ctx *c) { return c->precond == PRECOND_MFMA; }
 // grid of the MFMA sweeps: 2 workgroups (8 waves) per CU; every wave keeps P_inv in 128 VGPRs
 static int mfma_grid(const cup2d_ctx *c, int count) {
   const int ntiles = (count + 15) / 16;
@@ -220,9 +212,9 @@ __global__ void k_precond_mfma(const double *__restrict__ in, double *__restrict
                                int first, int count);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count) {
   if (count <= 0) return CUP2D_OK;
-  if (precond_kind() == PRECOND_FD)
+  if (c->precond == PRECOND_FD)
     hipLaunchKernelGGL(k_precond_fd, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_fd, first, count);
-  else if (use_mfma())
+  else if (use_mfma(c))
     hipLaunchKernelGGL(k_precond_mfma, dim3(mfma_grid(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
   else
     hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
@@ -525,6 +517,112 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
   workgroup_reduce_store<1, true>(m, partials, 2, poff);
 }
 
+// ---- general sparse operator (sliced ELL, ctx.h SellMatrix) --------------------------------------
+// The same sweeps with y = A x taken from the assembled matrix instead of the 5-point stencil: what
+// the reference does with cusparseSpMV on its COO arrays (cuda.cu:344-402).  One wave per slice (= per
+// 8x8 block), lane = row; columns/values are read with unit stride, x is gathered (L2-resident on a
+// block grid: a row's columns are its own block and the four blocks around it).
+//   MODE 0: y = A x                                      (cup2d_apply_A)
+//   MODE 1: y = A x ; partial(w.y)                       (sweep B, w = rhat)
+//   MODE 2: y = A x ; partial(y.w, y.y)                  (sweep D, w = r)
+//   MODE 3: r = rhat = b - A x ; partial(r.r), max|r|    (initial residual; y = r, w = b, y2 = rhat)
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_sell(const double *__restrict__ x, double *__restrict__ y,
+                                             const double *__restrict__ w, double *__restrict__ y2,
+                                             const long long *__restrict__ sptr, const int32_t *__restrict__ col,
+                                             const double *__restrict__ val, const KrylovScalars *__restrict__ sc,
+                                             double *__restrict__ partials, int count, int poff) {
+  if ((MODE == 1 || MODE == 2) && sc->status != 0) return;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double acc[2] = {0.0, 0.0}, mx[1] = {0.0};
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int s = g * WPG + wave;
+    if (s < count) {
+      const long long base = sptr[s];
+      const int width = (int)((sptr[s + 1] - base) >> 6);
+      const int32_t *cp = col + base + lane;
+      const double *vp = val + base + lane;
+      double a = 0.0;
+      int k = 0;
+      for (; k + 4 <= width; k += 4) {  // four independent gathers in flight
+        const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
+        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        a = __builtin_fma(v0, x0, a);
+        a = __builtin_fma(v1, x1, a);
+        a = __builtin_fma(v2, x2, a);
+        a = __builtin_fma(v3, x3, a);
+      }
+      for (; k < width; k++) a = __builtin_fma(vp[k * 64], x[cp[k * 64]], a);
+      const size_t o = (size_t)s * BC + lane;
+      if (MODE == 3) {
+        const double rv = w[o] - a;
+        y[o] = rv;
+        y2[o] = rv;
+        acc[0] = __builtin_fma(rv, rv, acc[0]);
+        mx[0] = fmax(mx[0], fabs(rv));
+      } else {
+        y[o] = a;
+        if (MODE == 1) acc[0] = __builtin_fma(a, w[o], acc[0]);
+        if (MODE == 2) {
+          acc[0] = __builtin_fma(a, w[o], acc[0]);
+          acc[1] = __builtin_fma(a, a, acc[1]);
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    double a1[1] = {acc[0]};
+    workgroup_reduce_store<1, false>(a1, partials, 0, poff);
+  }
+  if (MODE == 2) workgroup_reduce_store<2, false>(acc, partials, 0, poff);
+  if (MODE == 3) {
+    double a1[1] = {acc[0]};
+    workgroup_reduce_store<1, false>(a1, partials, 0, poff);
+    workgroup_reduce_store<1, true>(mx, partials, 2, poff);
+  }
+}
+
+// send_buff_pack (cuda.cu:338-343): buf[i] = vec[idx[i]]
+__global__ __launch_bounds__(WG) void k_gather(const double *__restrict__ vec, const int32_t *__restrict__ idx,
+                                               double *__restrict__ buf, int n) {
+  for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) buf[i] = vec[idx[i]];
+}
+
+// Halo of a Krylov vector in matrix mode (cuda.cu:356-380): gather the entries the neighbour ranks
+// need, hand them to the exchange callback, which delivers the entries this rank needs straight into
+// vec[m .. m+halo) (the "device_recv" argument of the callback), and wait for them.
+int matrix_exchange(cup2d_ctx *c, double *vec) {
+  const SellMatrix &M = c->mat;
+  if (!M.active || !c->exchange || (M.ngather == 0 && M.halo == 0)) return CUP2D_OK;
+  ProfScope prof(c, CUP2D_T_HALO);
+  if (M.ngather > 0) {
+    int grid = (M.ngather + WG - 1) / WG;
+    if (grid > c->grid) grid = c->grid;
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(WG), 0, c->stream, vec, M.d_gather, c->d_send, M.ngather);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  if (c->exchange(c->comm_user, c->d_send, vec + (size_t)c->nblocks * BC, 1, c->stream) != 0) {
+    set_error("exchange callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+    set_error("wait callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  return CUP2D_OK;
+}
+
+int launch_matvec(cup2d_ctx *c, double *x, double *y) {
+  const SellMatrix &M = c->mat;
+  CUP2D_TRY(matrix_exchange(c, x));
+  hipLaunchKernelGGL(k_sell<0>, dim3(grid_for(c, c->nblocks)), dim3(WG), 0, c->stream, x, y, nullptr, nullptr, M.d_ptr,
+                     M.d_col, M.d_val, nullptr, nullptr, c->nblocks, 0);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // ---- scalar kernels ---------------------------------------------------------------------------
 static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage);
 // finish the per-workgroup partials of slots [0,nsum) (sums) and slot 2 (max) into red[0..2]
@@ -659,7 +757,15 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   // Returns the number of per-workgroup partials the launches wrote.
   const int n_in = overlapped(c) ? c->n_inner : nb, n_ha = nb - n_in;
   const int G_in = n_in > 0 ? grid_for(c, n_in) : 0, G_ha = n_ha > 0 ? grid_for(c, n_ha) : 0;
+  const bool matrix = c->mat.active;
+  const SellMatrix &M = c->mat;
   auto stencil_sweep = [&](double *xin, auto launch) -> int {
+    if (matrix) {  // assembled operator: halo entries first, then one sweep over all slices
+      CUP2D_TRY(matrix_exchange(c, xin));
+      launch(0, nb, 0, G);
+      CUP2D_HIP_CHECK(hipGetLastError());
+      return CUP2D_OK;
+    }
     CUP2D_TRY(exchange_begin(c, xin, 1, 1));
     if (n_in > 0) launch(0, n_in, 0, G_in);
     CUP2D_TRY(exchange_end(c, xin, 1, 1));
@@ -667,13 +773,17 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     CUP2D_HIP_CHECK(hipGetLastError());
     return CUP2D_OK;
   };
-  const int GP = G_in + G_ha;
+  const int GP = matrix ? G : G_in + G_ha;
 
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
     CUP2D_TRY(stencil_sweep(x, [&](int first, int count, int poff, int g) {
-      hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
-                         c->d_partials, first, count, poff);
+      if (matrix)
+        hipLaunchKernelGGL(k_sell<3>, dim3(g), dim3(WG), 0, c->stream, x, c->d_r, b, c->d_rhat, M.d_ptr, M.d_col, M.d_val,
+                           c->d_sc, c->d_partials, count, poff);
+      else
+        hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                           c->d_partials, first, count, poff);
     }));
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
@@ -702,10 +812,10 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     c->prof_sample = (k % 8 == 0) && k < max_iter;  // sampled timing: an event pair costs ~4 us of stream time
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      if (precond_kind() == PRECOND_FD)
+      if (c->precond == PRECOND_FD)
         hipLaunchKernelGGL(k_sweepA_fd, dim3(G), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r, c->d_rhat, c->d_z,
                            c->d_fd, c->d_sc, nb);
-      else if (use_mfma())
+      else if (use_mfma(c))
         hipLaunchKernelGGL(k_sweepA_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_p, c->d_nu, c->d_r,
                            c->d_rhat, c->d_z, c->d_Pinv, c->d_sc, nb);
       else
@@ -715,16 +825,20 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     {
       ProfScope prof(c, CUP2D_T_SWEEP_B);
       CUP2D_TRY(stencil_sweep(c->d_z, [&](int first, int count, int poff, int g) {
-        hipLaunchKernelGGL(k_sweepBD<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
-                           c->d_partials, first, count, poff);
+        if (matrix)
+          hipLaunchKernelGGL(k_sell<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, nullptr, M.d_ptr,
+                             M.d_col, M.d_val, c->d_sc, c->d_partials, count, poff);
+        else
+          hipLaunchKernelGGL(k_sweepBD<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
+                             c->d_partials, first, count, poff);
       }));
     }
     CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
-      if (precond_kind() == PRECOND_FD)
+      if (c->precond == PRECOND_FD)
         hipLaunchKernelGGL(k_sweepC_fd, dim3(G), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2, c->d_fd, c->d_sc, nb);
-      else if (use_mfma())
+      else if (use_mfma(c))
         hipLaunchKernelGGL(k_sweepC_mfma, dim3(mfma_grid(c, nb)), dim3(WG), 0, c->stream, c->d_r, c->d_nu, c->d_z2,
                            c->d_Pinv, c->d_sc, nb);
       else
@@ -733,8 +847,12 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     {
       ProfScope prof(c, CUP2D_T_SWEEP_D);
       CUP2D_TRY(stencil_sweep(c->d_z2, [&](int first, int count, int poff, int g) {
-        hipLaunchKernelGGL(k_sweepBD<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
-                           c->d_partials, first, count, poff);
+        if (matrix)
+          hipLaunchKernelGGL(k_sell<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, nullptr, M.d_ptr, M.d_col,
+                             M.d_val, c->d_sc, c->d_partials, count, poff);
+        else
+          hipLaunchKernelGGL(k_sweepBD<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
+                             c->d_partials, first, count, poff);
       }));
     }
     CUP2D_TRY(finish(c, GP, 2, 0, 2, true));

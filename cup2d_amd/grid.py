@@ -108,3 +108,43 @@ class BlockGrid:
         out[self.coords[:, 1], self.coords[:, 0]] = slab
         out = out.transpose(0, 2, 1, 3, 4).reshape(self.ny, self.nx, dim)
         return np.ascontiguousarray(out[..., 0] if dim == 1 else out)
+
+    # ---- Poisson matrix of main.cpp:7034-7112 on this same-level grid ---------------------------
+    def poisson_coo(self):
+        """Local COO triplets (row, col, val) of the matrix the reference assembles for this block
+        grid, rows/columns numbered 64*block + 8*iy + ix in device block order: 1 towards every
+        existing neighbour cell, -(their number) on the diagonal, nothing across a domain wall
+        (main.cpp:7075-7105 with the same-level branch of Solver::makeFlux, main.cpp:5946-5951).
+        Columns of ghost blocks (index >= nblocks) address halo entries, block-wise."""
+        nb = self.nblocks
+        cell = np.arange(BS * BS)
+        ix, iy = cell % BS, cell // BS
+        rows, cols = [], []
+        base = (np.arange(nb) * BS * BS)[:, None]
+        me = base + cell[None, :]
+        # (dx, dy, side of nbr, mirrored cell in the neighbouring block)
+        for dx, dy, side in ((-1, 0, 0), (1, 0, 1), (0, -1, 2), (0, 1, 3)):
+            jx, jy = ix + dx, iy + dy
+            inside = (jx >= 0) & (jx < BS) & (jy >= 0) & (jy < BS)
+            # in-block neighbours
+            r = me[:, inside]
+            c = base + (jy[inside] * BS + jx[inside])[None, :]
+            rows.append(r.ravel())
+            cols.append(c.ravel())
+            # across the face
+            edge = ~inside
+            nbr = self.nbr[:, side].astype(np.int64)
+            has = nbr >= 0
+            r = me[has][:, edge]
+            c = nbr[has][:, None] * BS * BS + (((jy[edge] + BS) % BS) * BS + (jx[edge] + BS) % BS)[None, :]
+            rows.append(r.ravel())
+            cols.append(c.ravel())
+        rows = np.concatenate(rows)
+        cols = np.concatenate(cols)
+        vals = np.ones(rows.size)
+        deg = np.bincount(rows, minlength=nb * BS * BS).astype(np.float64)
+        allr = np.arange(nb * BS * BS)
+        rows = np.concatenate([rows, allr])
+        cols = np.concatenate([cols, allr])
+        vals = np.concatenate([vals, -deg])
+        return rows.astype(np.int32), cols.astype(np.int32), vals

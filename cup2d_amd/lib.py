@@ -30,7 +30,9 @@ SYMBOLS = [
     "cup2d_max_abs_vel", "cup2d_compute_dt", "cup2d_poisson_solve", "cup2d_apply_A", "cup2d_precond",
     "cup2d_get_P_inv", "cup2d_step", "cup2d_halo_plan", "cup2d_halo_pack", "cup2d_halo_unpack",
     "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_timing", "cup2d_get_timing",
+    "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather",
 ]
+PRECOND_LDS, PRECOND_MFMA, PRECOND_FD = 0, 1, 2
 
 
 class Cup2dError(RuntimeError):
@@ -86,6 +88,11 @@ def load_library():
     L.cup2d_apply_A.argtypes = [vp, i, i]
     L.cup2d_precond.argtypes = [vp, i, i]
     L.cup2d_get_P_inv.argtypes = [vp, vp]
+    L.cup2d_set_P_inv.argtypes = [vp, vp]
+    L.cup2d_set_precond.argtypes = [vp, i]
+    L.cup2d_set_matrix_coo.argtypes = [vp, i, ctypes.c_longlong, vp, vp, vp]
+    L.cup2d_clear_matrix.argtypes = [vp]
+    L.cup2d_set_gather.argtypes = [vp, i, vp]
     L.cup2d_step.argtypes = [vp, d, d, d, d, i, i, ctypes.POINTER(d), ctypes.POINTER(i), ctypes.POINTER(d)]
     L.cup2d_halo_plan.argtypes = [vp, i, vp, vp, i, vp, vp]
     L.cup2d_halo_pack.argtypes = [vp, i, i, vp]

@@ -143,6 +143,28 @@ class Simulation:
         _l.check(self.L.cup2d_get_P_inv(self._ctx, P.ctypes.data_as(ctypes.c_void_p)), "get_P_inv")
         return P
 
+    def set_P_inv(self, P):
+        """the P_inv argument of LocalSpMatDnVec's constructor (cuda.h:28-29)"""
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(64, 64)
+        _l.check(self.L.cup2d_set_P_inv(self._ctx, P.ctypes.data_as(ctypes.c_void_p)), "set_P_inv")
+
+    def set_precond(self, kind):
+        _l.check(self.L.cup2d_set_precond(self._ctx, int(kind)), "set_precond")
+
+    def set_matrix_coo(self, row, col, val, halo=0):
+        """Assembled Poisson operator (what main.cpp:7034-7112 pushes into LocalSpMatDnVec), local
+        int32 indices in device block order; poisson_solve / apply_A use it instead of the stencil."""
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        assert row.shape == col.shape == val.shape and row.ndim == 1
+        _l.check(self.L.cup2d_set_matrix_coo(self._ctx, int(halo), row.size, row.ctypes.data_as(ctypes.c_void_p),
+                                             col.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p)),
+                 "set_matrix_coo")
+
+    def clear_matrix(self):
+        _l.check(self.L.cup2d_clear_matrix(self._ctx), "clear_matrix")
+
     def max_abs_vel(self):
         v = ctypes.c_double()
         _l.check(self.L.cup2d_max_abs_vel(self._ctx, ctypes.byref(v)), "max_abs_vel")

@@ -145,6 +145,33 @@ int cup2d_apply_A(cup2d_ctx *ctx, int dst_field, int src_field);
 int cup2d_precond(cup2d_ctx *ctx, int dst_field, int src_field);
 /* copy of the 64x64 preconditioner the context uses (row-major) */
 int cup2d_get_P_inv(cup2d_ctx *ctx, double *P_inv_4096);
+/* Install the caller's block preconditioner: the P_inv argument of LocalSpMatDnVec's constructor
+ * (cuda.h:28-29, uploaded at cuda.cu:136-139), row-major 64x64, applied as z_b = P_inv p_b.  The matrix
+ * main.cpp:6451-6488 builds (-(A_loc)^-1, recognised up to round-off) keeps the fast-diagonalisation
+ * kernels; any other matrix is applied as a dense 64x64 product on the FP64 matrix cores. */
+int cup2d_set_P_inv(cup2d_ctx *ctx, const double *P_inv_4096);
+/* implementation of the block-Jacobi product: all three apply the same operator (round-off apart) */
+typedef enum { CUP2D_PRECOND_LDS = 0, CUP2D_PRECOND_MFMA = 1, CUP2D_PRECOND_FD = 2 } cup2d_precond_kind;
+int cup2d_set_precond(cup2d_ctx *ctx, int kind);
+
+/* ---------------------------------------------------------------- assembled operator ----- */
+/* The seam the reference itself crosses (cuda.h LocalSpMatDnVec): instead of the 5-point stencil on
+ * the neighbour table, cup2d_poisson_solve / cup2d_apply_A use the COO matrix the caller assembled
+ * (main.cpp:7034-7112) -- needed for coarse-fine rows.  Replaces BiCGSTABSolver::updateAll's upload +
+ * cuSPARSE descriptors (cuda.cu:206-296) and the SpMV pair of cuda.cu:344-402.
+ * row/col are LOCAL int32 indices as produced by LocalSpMatDnVec::make (cuda.cu:661-688): rows in
+ * [0, 64*nblocks), columns in [0, 64*nblocks + halo); columns >= 64*nblocks address halo entries
+ * that the exchange callback (cup2d_set_comm) delivers behind the vector.  halo <= 64*nghost.
+ * Local and boundary triplets (cuda.cu's loc_/bd_ lists) go in one list.  The matrix is converted
+ * to sliced-ELL on the host; order of a row's entries is kept. */
+int cup2d_set_matrix_coo(cup2d_ctx *ctx, int halo, long long nnz, const int32_t *row, const int32_t *col,
+                         const double *val);
+/* back to the matrix-free stencil; also drops the gather list */
+int cup2d_clear_matrix(cup2d_ctx *ctx);
+/* send_pack_idx_ of cuda.h:76 / send_buff_pack cuda.cu:338-343: before every operator application
+ * device_send_buffer[i] = vec[idx[i]], i < nsend, is handed to the exchange callback with
+ * strip_doubles = 1 and device_recv = &vec[64*nblocks].  Call after cup2d_set_matrix_coo. */
+int cup2d_set_gather(cup2d_ctx *ctx, int nsend, const int32_t *idx);
 
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:

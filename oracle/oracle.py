@@ -24,6 +24,9 @@ import numpy as np  # noqa: E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
 REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+# the same reference main.cpp linked against THIS repository's cuda.h implementation
+# (cup2d_amd/libcup2d_spmat.so) instead of the CPU restatement: the drop-in test of seam B1 (needs a GPU)
+REF_HARNESS_HIP = os.path.join(_HERE, "_ref", "ref_harness_hip")
 
 _lib = None
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -215,11 +218,17 @@ def _level(n):
     return lv
 
 
-def _run_ref(mode, n, d, _threads=None, _timeout=None, **kw):
-    cmd = [REF_HARNESS, mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
+def have_reference_hip():
+    return os.path.exists(REF_HARNESS_HIP) and os.access(REF_HARNESS_HIP, os.X_OK)
+
+
+def _run_ref(mode, n, d, _threads=None, _timeout=None, _hip=False, _env=None, **kw):
+    cmd = [REF_HARNESS_HIP if _hip else REF_HARNESS, mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
     env = dict(os.environ)
     if _threads:
         env.update(OMP_NUM_THREADS=str(int(_threads)), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    if _env:
+        env.update(_env)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=_timeout)
     if r.returncode != 0:
         raise RuntimeError("ref_harness failed (%d): %s" % (r.returncode, r.stderr.decode()[-2000:]))
@@ -255,8 +264,9 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
     return out
 
 
-def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None):
-    """BiCGSTAB (CPU port of cuda.cu) on the matrix the reference assembles; also returns A*x0."""
+def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, hip=False, env=None):
+    """BiCGSTAB (CPU port of cuda.cu) on the matrix the reference assembles; also returns A*x0.
+    hip=True: the solve goes through libcup2d_spmat.so on the GPU instead (A*x0 is then None)."""
     b = _c(b)
     n = b.shape[0]
     with tempfile.TemporaryDirectory() as d:
@@ -266,15 +276,16 @@ def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None)
         kw = dict(tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
         if max_iter is not None:
             kw["maxiter"] = int(max_iter)
-        _run_ref("solve", n, d, **kw)
+        _run_ref("solve", n, d, _hip=hip, _env=env, **kw)
         x = np.fromfile(os.path.join(d, "x.out")).reshape(n, n)
-        ax0 = np.fromfile(os.path.join(d, "Ax0.out")).reshape(n, n)
+        ax0 = None if hip else np.fromfile(os.path.join(d, "Ax0.out")).reshape(n, n)
         s = np.fromfile(os.path.join(d, "solve_scalars.out"))
     return x, ax0, dict(iters=int(s[0]), err=s[1], err_init=s[2], restarts=int(s[3]), seconds=s[4])
 
 
-def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None):
-    """The reference's own time loop (main.cpp:6576-7290) from the IC vel0 for `steps` steps."""
+def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None, hip=False, env=None):
+    """The reference's own time loop (main.cpp:6576-7290) from the IC vel0 for `steps` steps.
+    hip=True: with sim.mat served by libcup2d_spmat.so (GPU) instead of the CPU restatement."""
     vel0 = _c(vel0)
     n = vel0.shape[0]
     d = keep or tempfile.mkdtemp()
@@ -282,7 +293,7 @@ def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, ma
     kw = dict(nu=float(nu), cfl=float(cfl), steps=int(steps), tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
     if max_iter is not None:
         kw["maxiter"] = int(max_iter)
-    _run_ref("run", n, d, **kw)
+    _run_ref("run", n, d, _hip=hip, _env=env, **kw)
     out = dict(vel=np.fromfile(os.path.join(d, "vel.final")).reshape(n, n, 2),
                pres=np.fromfile(os.path.join(d, "pres.final")).reshape(n, n), steps=[])
     meta = open(os.path.join(d, "meta.txt")).read().strip().split("\n")

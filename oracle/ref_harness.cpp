@@ -62,6 +62,7 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+#ifndef HARNESS_HIP_SPMAT
 class BiCGSTABSolver {
 public:
   BiCGSTABSolver(MPI_Comm comm, LocalSpMatDnVec &ls, int BLEN, bool bMean,
@@ -376,6 +377,33 @@ void LocalSpMatDnVec::solveNoUpdate(const double e, const double re, const int m
   solver_->main_loop(e, re, mr);
 }
 
+#else
+/* Drop-in variant (oracle/_ref/ref_harness_hip): NOTHING of cuda.h is implemented here.  The
+ * reference's main.cpp is linked against cup2d_amd/libcup2d_spmat.so -- this repository's MI355X
+ * implementation of LocalSpMatDnVec -- exactly as upstream links it against cuda.o.  The two solve
+ * entry points are intercepted at link time (ld --wrap on their mangled names) only to run the
+ * harness hook (IC injection / dumps) before the real call. */
+extern "C" void cup2d_spmat_last_stats(int *iters, int *restarts, double *err, double *err_init, int *structured);
+static void fetch_stats() {
+  int s = 0;
+  cup2d_spmat_last_stats(&hooks.last_iters, &hooks.last_restarts, &hooks.last_error, &hooks.last_error_init, &s);
+}
+extern "C" {
+void __real__ZN15LocalSpMatDnVec15solveWithUpdateEddi(LocalSpMatDnVec *, double, double, int);
+void __real__ZN15LocalSpMatDnVec13solveNoUpdateEddi(LocalSpMatDnVec *, double, double, int);
+void __wrap__ZN15LocalSpMatDnVec15solveWithUpdateEddi(LocalSpMatDnVec *M, double e, double re, int mr) {
+  if (hooks.on_solve) hooks.on_solve(M, true, e, re, mr);
+  __real__ZN15LocalSpMatDnVec15solveWithUpdateEddi(M, e, re, mr);
+  fetch_stats();
+}
+void __wrap__ZN15LocalSpMatDnVec13solveNoUpdateEddi(LocalSpMatDnVec *M, double e, double re, int mr) {
+  if (hooks.on_solve) hooks.on_solve(M, false, e, re, mr);
+  __real__ZN15LocalSpMatDnVec13solveNoUpdateEddi(M, e, re, mr);
+  fetch_stats();
+}
+}
+#endif
+
 /* ------------------------------------------------------------------------ */
 /* harness proper                                                           */
 /* ------------------------------------------------------------------------ */
@@ -514,6 +542,9 @@ int main(int argc, char **argv) {
   g_n = _BS_ << levelStart;
   const size_t N = (size_t)g_n * g_n;
   hooks.forced_max_iter = maxiter;
+#ifdef HARNESS_HIP_SPMAT
+  if (maxiter >= 0) setenv("CUP2D_SPMAT_MAX_ITER", std::to_string(maxiter).c_str(), 1);
+#endif
 
   if (mode == "run") {
     /* The reference's own time loop.  Step 0 runs on all-zero fields; the IC is
@@ -670,6 +701,7 @@ int main(int argc, char **argv) {
     if (file_exists(dir + "/x0.in")) x0 = read_file(dir + "/x0.in", N);
     global_to_blockvec(bg, mat->get_b());
     global_to_blockvec(x0, mat->get_x());
+#ifndef HARNESS_HIP_SPMAT
     /* A*x0 through the reference-assembled COO matrix, for operator parity */
     hooks.matvec_only = true;
     mat->solveNoUpdate(0, 0, 0);
@@ -678,6 +710,7 @@ int main(int argc, char **argv) {
       auto ax = blockvec_to_global(mat->get_x());
       write_file(dir + "/Ax0.out", ax.data(), ax.size());
     }
+#endif
     global_to_blockvec(x0, mat->get_x());
     double t0 = now_s();
     mat->solveNoUpdate(tol, reltol, restarts);

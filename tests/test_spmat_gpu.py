@@ -1,0 +1,148 @@
+"""GPU tests of seam B1: the reference's own main.cpp linked against libcup2d_spmat.so (this repository's
+LocalSpMatDnVec on MI355X) reproduces the reference time loop; the assembled-operator path (sliced ELL)
+agrees with the matrix-free stencil; custom block preconditioners; ranks sharing the GPU over MPI."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "spmat_driver")
+MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.parametrize("force_matrix", [False, True])
+def test_reference_time_loop_with_hip_spmat(gpu_lib, oracle, force_matrix):
+    """main.cpp:6576-7290, every line the reference's own, with sim.mat -> libcup2d_spmat.so:
+    3 steps from the golden initial condition must land on the golden state (which the reference
+    produced with the CPU restatement of cuda.cu behind the same seam)."""
+    assert oracle.have_reference_hip(), "oracle/_ref/ref_harness_hip was not shipped"
+    G = golden("run_n32_3steps.npz")
+    env = {"CUP2D_SPMAT_FORCE_MATRIX": "1"} if force_matrix else None
+    R = oracle.ref_run(G["vel0"], float(G["nu"]), steps=3, tol=1e-11, rel_tol=0.0, max_restarts=100, hip=True, env=env)
+    assert np.allclose([s["dt"] for s in R["steps"]], G["dts"], rtol=1e-12, atol=0)
+    assert np.abs(R["vel"] - G["vel"]).max() < 1e-10
+    assert np.abs(R["pres"] - G["pres"]).max() < 1e-8
+    for k in range(3):
+        assert np.abs(R["steps"][k]["b"] - G["b"][k]).max() < 1e-9
+
+
+@pytest.mark.parametrize("force_matrix", [False, True])
+def test_reference_assembled_system_solved_by_hip_spmat(gpu_lib, oracle, force_matrix):
+    assert oracle.have_reference_hip()
+    G = golden("poisson_n32.npz")
+    env = {"CUP2D_SPMAT_FORCE_MATRIX": "1"} if force_matrix else None
+    x, _, info = oracle.ref_solve(G["b"], x0=G["x0"], tol=1e-10, rel_tol=0.0, max_restarts=100, hip=True, env=env)
+    assert abs(info["iters"] - int(G["iters"])) <= 3
+    assert abs(info["err_init"] - float(G["err_init"])) < 1e-12
+    assert np.abs(G["b"] - oracle.apply_A(x)).max() <= 1.0001e-10
+    assert np.abs(x - G["x"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("order,nbx,nby", [("hilbert", 8, 8), ("rowmajor", 5, 3)])
+def test_assembled_operator_equals_stencil(gpu_lib, oracle, order, nbx, nby):
+    import cup2d_amd
+    from cup2d_amd import lib as L
+    from cup2d_amd.grid import BlockGrid
+    g = BlockGrid(nbx, nby, order=order)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (g.ny, g.nx))
+    b = rng.uniform(-1, 1, (g.ny, g.nx))
+    b -= b.mean()
+    with cup2d_amd.Simulation(nbx, nby, grid=g, h=1.0 / g.nx) as s:
+        s.pres = x
+        s.apply_A(L.TMP, L.PRES)
+        y_stencil = s.tmp
+        s.tmp = b
+        s.fill(L.PRES, 0.0)
+        i_st = s.poisson_solve(tol=1e-9)
+        x_st = s.pres
+        # the same operator as an assembled matrix, entries shuffled
+        r, c, v = g.poisson_coo()
+        perm = rng.permutation(r.size)
+        s.set_matrix_coo(r[perm], c[perm], v[perm])
+        s.pres = x
+        s.apply_A(L.TMP, L.PRES)
+        y_mat = s.tmp
+        assert np.abs(y_mat - y_stencil).max() <= 4e-15 * 8  # different summation order only
+        assert np.abs(y_mat - oracle.apply_A(x)).max() <= 4e-15 * 8
+        s.tmp = b
+        s.fill(L.PRES, 0.0)
+        i_mat = s.poisson_solve(tol=1e-9)
+        x_mat = s.pres
+        assert i_mat["err"] <= 1e-9 and i_st["err"] <= 1e-9
+        assert abs(i_mat["iters"] - i_st["iters"]) <= max(5, i_st["iters"] // 4)
+        assert np.abs(b - oracle.apply_A(x_mat)).max() <= 1.0001e-9
+        assert np.abs((x_mat - x_mat.mean()) - (x_st - x_st.mean())).max() < 2e-9 * (max(g.nx, g.ny) / np.pi) ** 2
+        # a matrix that is NOT the stencil: scale one block's rows -> different operator, applied as given
+        v2 = v.copy()
+        v2[(r // 64) == 3] *= 0.5
+        s.set_matrix_coo(r, c, v2)
+        s.pres = x
+        s.apply_A(L.TMP, L.PRES)
+        want = g.to_blocks(oracle.apply_A(x))
+        want[3] *= 0.5
+        assert np.abs(g.to_blocks(s.tmp) - want).max() <= 4e-15 * 8
+        s.clear_matrix()
+        s.apply_A(L.TMP, L.PRES)
+        assert np.array_equal(s.tmp, y_stencil)
+
+
+def test_preconditioner_kinds_and_custom_P(gpu_lib, oracle):
+    import cup2d_amd
+    from cup2d_amd import lib as L
+    n = 64
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (n, n))
+    with cup2d_amd.Simulation(n // 8) as s:
+        s.pres = x
+        P = s.P_inv()
+        want = oracle.precond(x, P)
+        for kind in (L.PRECOND_FD, L.PRECOND_MFMA, L.PRECOND_LDS):
+            s.set_precond(kind)
+            s.precond(L.TMP, L.PRES)
+            assert np.abs(s.tmp - want).max() < 1e-14, kind
+        # the reference's own Cholesky-built matrix (round-off away from ours) keeps fast diagonalisation
+        s.set_precond(L.PRECOND_FD)
+        s.set_P_inv(oracle.P_inv())
+        s.precond(L.TMP, L.PRES)
+        assert np.abs(s.tmp - want).max() < 1e-14
+        # a caller-supplied, non-symmetric P: applied as z_b = P p_b (cuda.cu:484-486), densely
+        Q = P + 0.01 * rng.uniform(-1, 1, (64, 64))
+        s.set_P_inv(Q)
+        blocks = s.grid.to_blocks(x)
+        want_q = s.grid.from_blocks(blocks @ Q.T, 1)
+        for kind in (L.PRECOND_MFMA, L.PRECOND_LDS):
+            s.set_precond(kind)
+            s.precond(L.TMP, L.PRES)
+            assert np.abs(s.tmp - want_q).max() < 1e-13, kind
+        with pytest.raises(cup2d_amd.Cup2dError):
+            s.set_precond(L.PRECOND_FD)
+        # and the solver converges with it
+        b = rng.uniform(-1, 1, (n, n))
+        b -= b.mean()
+        s.tmp = b
+        s.fill(L.PRES, 0.0)
+        info = s.poisson_solve(tol=1e-8)
+        assert info["err"] <= 1e-8 and np.abs(b - oracle.apply_A(s.pres)).max() <= 1.0001e-8
+
+
+@pytest.mark.parametrize("ranks,env", [(1, {}), (1, {"CUP2D_SPMAT_FORCE_MATRIX": "1"}), (2, {}), (3, {})])
+def test_spmat_ranks_share_the_gpu(gpu_lib, ranks, env):
+    """LocalSpMatDnVec driven like main.cpp:7034-7131 from 1-3 MPI ranks on this GPU: 1 rank takes the
+    matrix-free path (or the assembled one when forced), several ranks the assembled operator with the
+    host-staged MPI halo of cuda.cu:365-380."""
+    assert os.path.exists(DRIVER) and os.path.exists(MPIEXEC), "spmat_driver / mpiexec not shipped"
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([MPIEXEC, "-n", str(ranks), DRIVER, "solve", "6", "4", "1e-9"], capture_output=True, text=True,
+                         timeout=300, env=e)
+    assert out.returncode == 0 and "SOLVE_OK" in out.stdout, out.stdout + out.stderr
+    structured = ranks == 1 and not env
+    assert ("structured %d" % int(structured)) in out.stdout

@@ -28,6 +28,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_SOLVER = "sweeps"    # flipped to "fused" once its GPU parity run is green
+DEFAULT_FINISH = "launch"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
@@ -54,6 +56,10 @@ def main():
     ap.add_argument("--n", type=int, default=4096, help="cells per side of one rank's patch")
     ap.add_argument("--iters", type=int, default=50, help="BiCGSTAB iterations per step")
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--solver", default=DEFAULT_SOLVER, choices=["sweeps", "fused"],
+                    help="organisation of a BiCGSTAB iteration (include/cup2d_hip.h cup2d_solver_kind)")
+    ap.add_argument("--finish", default=DEFAULT_FINISH, choices=["launch", "kernel"],
+                    help="reduction finish + scalar update: own launch, or by the last workgroup of the sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
@@ -89,6 +95,8 @@ def main():
         vel = synthetic_velocity(n, n, 0, 0, n, n, seed=20250117)
         par = "single"
     sim.set_math(args.math == "strict")
+    fused = args.solver == "fused" and world == 1  # ghost blocks: the library itself falls back to the five sweeps
+    sim.set_solver(fused=fused, finish_in_kernel=args.finish == "kernel")
     sim.vel = vel
     del vel
 
@@ -146,11 +154,22 @@ def main():
     #   sweep_A       reads p, nu, r 24 + writes p, z 16 = 40      sweep_C  reads r, nu 16 + writes r, z2 16 = 32
     #   sweep_B / D   reads z (z2) 8 + rhat (r) 8, writes nu (t) 8 = 24
     #   sweep_E       reads x, z, z2, r, t, rhat 48 + writes x, r 16 = 64
+    #   fused solver (krylov_fused.hip): sweep_A = A+B in one launch: reads p, nu, r, rhat 32 + writes p', nu' 16 = 48
+    #   sweep_C = C+D: reads r, nu 16 + writes s, t 16 = 32     sweep_E: reads y, p, s, t, rhat 40 + writes y, r 16 = 56
     ALGO_BYTES = {"advect_stage": 40.0, "poisson_rhs": 32.0, "sweep_A": 40.0, "sweep_B": 24.0, "sweep_C": 32.0,
                   "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0}
+    mk = "true" if args.finish == "kernel" and world == 1 else "false"
     KERNEL_OF = {"advect_stage": "k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>",
-                 "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1>",
-                 "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2>", "sweep_E": "k_sweepE", "init_residual": "k_init_residual"}
+                 "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1, %s>" % mk,
+                 "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2, %s>" % mk, "sweep_E": "k_sweepE<%s>" % mk,
+                 "init_residual": "k_init_residual"}
+    sweeps = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")
+    if fused:
+        ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 32.0, "sweep_E": 56.0})
+        del ALGO_BYTES["sweep_B"], ALGO_BYTES["sweep_D"]
+        KERNEL_OF.update({"sweep_A": "k_fused<0, %s>" % mk, "sweep_C": "k_fused<1, %s>" % mk, "sweep_E": "k_sweepE_y<%s>" % mk})
+        sweeps = ("sweep_A", "sweep_C", "sweep_E")
+    finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on
     # gfx950), summarised by tools/prof_summary.py from the same bench command: profiles/<tag>_pmc_traffic.json
     traffic_tab, traffic_src = {}, None
@@ -179,7 +198,9 @@ def main():
     # GPU time per step of a family = its (sampled) average launch x launches per step
     per_step = {"advect_stage": 2, "poisson_rhs": 1, "init_residual": 1, "project": 1, "reduce": 3,
                 "sweep_A": args.iters, "sweep_B": args.iters, "sweep_C": args.iters, "sweep_D": args.iters,
-                "sweep_E": args.iters, "scalars": 3 * args.iters + 1, "halo": 0}
+                "sweep_E": args.iters, "scalars": finish_launches * args.iters + 1, "halo": 0}
+    if fused:
+        per_step["sweep_B"] = per_step["sweep_D"] = 0
     step_ms = {f: (timers[f]["ms_avg"] or 0.0) * per_step.get(f, 0) for f in timers}
     gpu_ms = sum(step_ms.values()) or 1.0
     all_roof = {}
@@ -205,11 +226,10 @@ def main():
                       "fp64_T_lane_instr_per_s": round(rate, 2), "fp64_frac_of_measured_ceiling_32T": round(rate / 32.0, 4),
                       "fp64_frac_of_nominal_39.3T": round(rate / 39.3, 4)})
     # one BiCGSTAB iteration = sweeps A..E + 3 scalar kernels (sum of the sampled average durations)
-    it_bytes = sum(ALGO_BYTES[k] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E"))
+    it_bytes = sum(ALGO_BYTES[k] for k in sweeps)
     solver = None
-    if iters and all(timers[k]["launches"] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E", "scalars")):
-        t_it = (sum(timers[k]["ms_avg"] for k in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")) +
-                3 * timers["scalars"]["ms_avg"]) * 1e-3
+    if iters and all(timers[k]["launches"] for k in sweeps + ("scalars",)):
+        t_it = (sum(timers[k]["ms_avg"] for k in sweeps) + finish_launches * timers["scalars"]["ms_avg"]) * 1e-3
         solver = {"iterations": iters, "ms_per_iteration": round(t_it * 1e3, 4), "bytes_per_cell_iteration": it_bytes,
                   "achieved_GBs": round(it_bytes * cells_rank / t_it / 1e9, 1),
                   "frac_hbm": round(it_bytes * cells_rank / t_it / 1e9 / HBM_PEAK_GBS, 4),
@@ -247,7 +267,8 @@ def main():
             "config": {"workload": "%dx%d uniform cells per GPU (%d^2 8x8 blocks), nu=1e-3, CFL 0.5; step = dt + RK2 WENO5 "
                                    "advect-diffuse + Poisson rhs + %d BiCGSTAB iters (block-Jacobi) + projection"
                                    % (n, n, n // 8, args.iters),
-                       "global_cells": cells, "parallelism": par, "math": args.math, "bicgstab_iters_per_step": args.iters},
+                       "global_cells": cells, "parallelism": par, "math": args.math, "bicgstab_iters_per_step": args.iters,
+                       "solver": "fused" if fused else "sweeps", "finish": "kernel" if mk == "true" else "launch"},
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "kernels": timers, "cpu_baseline": cpu,
         }

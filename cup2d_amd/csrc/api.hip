@@ -137,6 +137,8 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   c->n_inner = n_inner;
   c->h = h;
   c->grid = MAX_GRID;
+  if (const char *e = getenv("CUP2D_SOLVER")) c->solver = e[0] == 'f' ? CUP2D_SOLVER_FUSED : CUP2D_SOLVER_SWEEPS;
+  if (const char *e = getenv("CUP2D_FINISH_IN_KERNEL")) c->finish_in_kernel = atoi(e) != 0;
   if (const char *e = getenv("CUP2D_PRECOND"))  // A/B timing aid; cup2d_set_precond is the API
     c->precond = e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD);
   {
@@ -181,6 +183,8 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * PSTRIDE));
   CUP2D_HIP_CHECK(hipMalloc(&c->d_red_own, sizeof(double) * 8));
   c->d_red = c->d_red_own;
+  CUP2D_HIP_CHECK(hipMalloc(&c->d_ticket, sizeof(unsigned)));
+  CUP2D_HIP_CHECK(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
   CUP2D_HIP_CHECK(hipMalloc(&c->d_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
@@ -199,6 +203,9 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipFree(c->d_vscratch);
   double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_fd, c->d_partials, c->d_red_own};
   for (double *p : kv) (void)hipFree(p);
+  double *fv[] = {c->d_p2, c->d_nu2, c->d_s, c->d_y, c->d_yopt};
+  for (double *p : fv) (void)hipFree(p);
+  (void)hipFree(c->d_ticket);
   (void)hipFree(c->d_sc);
   (void)hipHostFree(c->h_sc);
   (void)hipHostFree(c->h_red);
@@ -426,7 +433,16 @@ int cup2d_poisson_solve(cup2d_ctx *c, double max_error, double max_rel_error, in
                         int *restarts, double *linf, double *linf_init) {
   CUP2D_CHECK_CTX(c);
   if (max_iter < 0) { set_error("poisson_solve: max_iter"); return CUP2D_ERR_ARG; }
+  if (c->solver == CUP2D_SOLVER_FUSED && fused_supported(c))
+    return solve_fused_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
   return solve_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
+}
+int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
+  CUP2D_CHECK_CTX(c);
+  if (kind != CUP2D_SOLVER_SWEEPS && kind != CUP2D_SOLVER_FUSED) { set_error("set_solver: kind %d", kind); return CUP2D_ERR_ARG; }
+  c->solver = kind;
+  c->finish_in_kernel = finish_in_kernel != 0;
+  return CUP2D_OK;
 }
 static bool scalar_field(int f) { return field_ok(f) && dim_of(f) == 1; }
 int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {

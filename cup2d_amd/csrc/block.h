@@ -188,7 +188,9 @@ static __device__ __forceinline__ double wave_max(double v) {
 }
 // one partial per workgroup and slot, written to partials[slot*PSTRIDE + poff + blockIdx.x]; order
 // of accumulation is fixed by the launch geometry, so results are run-to-run reproducible
-template <int N, bool IS_MAX>
+// COHERENT: agent-scope (write-through) stores, for partials that a workgroup of the SAME launch reads
+// back (krylov_common.h arrive_last)
+template <int N, bool IS_MAX, bool COHERENT = false>
 static __device__ __forceinline__ void workgroup_reduce_store(double (&v)[N], double *__restrict__ partials,
                                                               int slot0, int poff = 0) {
   __shared__ double red[N][WPG];
@@ -202,7 +204,9 @@ static __device__ __forceinline__ void workgroup_reduce_store(double (&v)[N], do
   if (threadIdx.x < N) {
     double a = red[threadIdx.x][0];
     for (int k = 1; k < WPG; k++) a = IS_MAX ? fmax(a, red[threadIdx.x][k]) : a + red[threadIdx.x][k];
-    partials[(size_t)(slot0 + threadIdx.x) * PSTRIDE + poff + blockIdx.x] = a;
+    double *dst = partials + (size_t)(slot0 + threadIdx.x) * PSTRIDE + poff + blockIdx.x;
+    if (COHERENT) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = a;
   }
 }
 

@@ -104,6 +104,12 @@ struct cup2d_ctx {
   double *d_Pinv = nullptr;
   double *d_fd = nullptr;  // eigenvectors Q[64] + eigenvalues lam[8] of the 8x8 second-difference matrix
   std::vector<double> h_Pinv;
+  // tile-fused solver (krylov_fused.hip): ping-pong copies of p and nu, s = r - alpha nu, and the
+  // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
+  double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
+  int solver = 0;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
+  int finish_in_kernel = 0;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
+  unsigned *d_ticket = nullptr;  // arrival counter of arrive_last, zero between launches
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
   cup2d::KrylovScalars *d_sc = nullptr;
@@ -206,6 +212,12 @@ int matrix_exchange(cup2d_ctx *c, double *vec);         // fill vec[m .. m+halo)
 int project_impl(cup2d_ctx *c, double dt);
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,
                int *iters, int *restarts, double *linf, double *linf_init);
+// the tile-fused variant (krylov_fused.hip); fused_supported: same-level stencil, no ghost blocks
+bool fused_supported(const cup2d_ctx *c);
+int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,
+                     int *iters, int *restarts, double *linf, double *linf_init);
+// reduction finish + scalar update of `stage` as its own launch(es) (+ all-reduce callback with N GPUs)
+int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);
 // ghost-strip exchange of a device vector through the comm callbacks (no-ops without ghosts):

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "block.h"
+#include "krylov_common.h"
 #include "precond_mfma.h"
 
 namespace cup2d {
@@ -364,11 +365,13 @@ __global__ __launch_bounds__(WG, 2) void k_sweepC_mfma(double *__restrict__ r, c
 // ---- sweeps B and D: y = A x with fused dot products -----------------------------------------
 // NDOT = 1: partial(w.y)            (B: w = rhat)
 // NDOT = 2: partial(y.w, y.y)       (D: w = r)
-template <int NDOT>
+// MERGE: the last workgroup to arrive finishes the reduction and runs the scalar update (stage NDOT) in
+// this launch (krylov_common.h arrive_last); only for a single launch over all blocks (poff == 0)
+template <int NDOT, bool MERGE>
 __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, double *__restrict__ y,
                                                 const double *__restrict__ w, const int *__restrict__ nbr,
-                                                const KrylovScalars *__restrict__ sc, double *__restrict__ partials,
-                                                int first, int count, int poff) {
+                                                KrylovScalars *sc, double *partials, int first, int count, int poff,
+                                                double *red, unsigned *ticket) {
   __shared__ double slabs[WPG][LAB1 * LAB1];
   if (sc->status != 0) return;
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -431,7 +434,8 @@ __global__ __launch_bounds__(WG) void k_sweepBD(const double *__restrict__ x, do
       g += 2 * gr.stride;
     }
   }
-  workgroup_reduce_store<NDOT, false>(acc, partials, 0, poff);
+  workgroup_reduce_store<NDOT, false, MERGE>(acc, partials, 0, poff);
+  if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, NDOT, 0, red, sc, NDOT, nullptr);
 }
 
 // ---- sweep C ----------------------------------------------------------------------------------
@@ -460,11 +464,12 @@ __global__ __launch_bounds__(WG) void k_sweepC(double *__restrict__ r, const dou
 }
 
 // ---- sweep E ----------------------------------------------------------------------------------
+template <bool MERGE>
 __global__ __launch_bounds__(WG) void k_sweepE(double *__restrict__ x, double *__restrict__ xopt,
                                                const double *__restrict__ z, const double *__restrict__ z2,
                                                double *__restrict__ r, const double *__restrict__ t,
-                                               const double *__restrict__ rhat, const KrylovScalars *__restrict__ sc,
-                                               double *__restrict__ partials, size_t n) {
+                                               const double *__restrict__ rhat, KrylovScalars *sc, double *partials,
+                                               size_t n, double *red, unsigned *ticket, int *host_status) {
   if (sc->status != 0) return;
   const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega;
   const int save = sc->x_is_best;
@@ -481,8 +486,9 @@ __global__ __launch_bounds__(WG) void k_sweepE(double *__restrict__ x, double *_
     s[1] = __builtin_fma(rv, rv, s[1]);
     m[0] = fmax(m[0], fabs(rv));
   }
-  workgroup_reduce_store<2, false>(s, partials, 0);
-  workgroup_reduce_store<1, true>(m, partials, 2);
+  workgroup_reduce_store<2, false, MERGE>(s, partials, 0);
+  workgroup_reduce_store<1, true, MERGE>(m, partials, 2);
+  if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, 2, 1, red, sc, 3, host_status);
 }
 
 // ---- initial residual: r = b - A x0, rhat = r, partial(r.r, max|r|) (cuda.cu:412-436) ---------
@@ -515,6 +521,14 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
   }
   workgroup_reduce_store<1, false>(s, partials, 0, poff);
   workgroup_reduce_store<1, true>(m, partials, 2, poff);
+}
+
+// r = rhat = b - A x over all owned blocks in one launch (no ghost blocks): the fused solver's entry
+int launch_init_residual(cup2d_ctx *c, const double *x, const double *b, int G) {
+  hipLaunchKernelGGL(k_init_residual, dim3(G), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr, c->d_partials, 0,
+                     c->nblocks, 0);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
 }
 
 // ---- general sparse operator (sliced ELL, ctx.h SellMatrix) --------------------------------------
@@ -624,92 +638,16 @@ int launch_matvec(cup2d_ctx *c, double *x, double *y) {
 }
 
 // ---- scalar kernels ---------------------------------------------------------------------------
-static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage);
+// (the recurrences themselves: krylov_common.h)
 // finish the per-workgroup partials of slots [0,nsum) (sums) and slot 2 (max) into red[0..2]
 // fused_stage >= 0: also run the scalar update of that stage (single-GPU: no all-reduce in between)
 __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict__ partials, int G, int nsum,
                                                         int with_max, double *__restrict__ red, KrylovScalars *sc,
                                                         int guarded, int fused_stage, int *host_status) {
-  __shared__ double sm[3][WG];
   if (guarded && sc->status != 0) return;
-  double a0 = 0, a1 = 0, mx = 0;
-  for (int i = threadIdx.x; i < G; i += WG) {
-    a0 += partials[i];
-    if (nsum > 1) a1 += partials[PSTRIDE + i];
-    if (with_max) mx = fmax(mx, partials[2 * PSTRIDE + i]);
-  }
-  sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
-  __syncthreads();
-  for (int s = WG / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
-      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
-      sm[2][threadIdx.x] = fmax(sm[2][threadIdx.x], sm[2][threadIdx.x + s]);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    red[0] = sm[0][0]; red[1] = sm[1][0]; red[2] = sm[2][0];
-    if (fused_stage >= 0) {
-      const double loc[3] = {sm[0][0], sm[1][0], sm[2][0]};
-      scalars_update(sc, loc, fused_stage);
-      // end of an iteration: tell the host (pinned, device-visible word) whether the loop is over
-      if (fused_stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  finish_reduce<false>(partials, G, nsum, with_max, red, sc, fused_stage, host_status);
 }
 
-// beginning of an iteration (cuda.cu:440-477): consumes rho = rhat.r and ||r||^2
-static __device__ void begin_iteration(KrylovScalars *sc) {
-  if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
-  const bool serious_breakdown = sc->rho_curr * sc->rho_curr < 1e-16 * sc->rr * sc->rhat2;
-  sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta
-  sc->restart_flag = 0;
-  if (serious_breakdown && sc->max_restarts > 0) {
-    sc->restarts++;
-    if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
-    sc->restart_flag = 1;
-    sc->rhat2 = sc->rr;     // rhat = r
-    sc->rho_curr = sc->rr;  // Dnrm2(rhat)^2
-    sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;  // breakdown_update
-    sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
-  }
-}
-// STAGE 0: after k_init_residual  red = {r.r, -, max|r|}
-// STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
-// STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
-// STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
-static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage) {
-  switch (stage) {
-  case 0:
-    sc->err = sc->err_init = sc->err_opt = red[2];
-    sc->x_is_best = 1;
-    sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
-    begin_iteration(sc);
-    break;
-  case 1:
-    sc->alpha = sc->rho_curr / (red[0] + sc->eps);
-    break;
-  case 2:
-    sc->omega = red[0] / (red[1] + sc->eps);
-    break;
-  case 3:
-    sc->iter++;
-    sc->err = red[2];
-    if (sc->err < sc->err_opt) {
-      sc->err_opt = sc->err;
-      sc->x_is_best = 1;
-      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
-    } else {
-      sc->x_is_best = 0;
-    }
-    sc->rho_prev = sc->rho_curr;  // set_rho
-    sc->rho_curr = red[0];
-    sc->rr = red[1];
-    begin_iteration(sc);
-    break;
-  }
-}
 __global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (stage != 0 && sc->status != 0) return;
@@ -717,7 +655,7 @@ __global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int
   if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-static int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr) {
+int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status) {
   ProfScope prof(c, CUP2D_T_SCALARS);
   const bool split = c->allreduce != nullptr;  // N GPUs: local sums -> all-reduce -> scalar update
   hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(WG), 0, c->stream, c->d_partials, G, nsum, with_max, c->d_red,
@@ -774,6 +712,9 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     return CUP2D_OK;
   };
   const int GP = matrix ? G : G_in + G_ha;
+  // finish of the fused reductions inside the sweep itself (last workgroup to arrive) instead of a
+  // single-workgroup kernel: one launch over all blocks, no all-reduce in between
+  const bool merge = c->finish_in_kernel && !c->allreduce && !matrix && n_ha == 0;
 
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
@@ -828,12 +769,15 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
         if (matrix)
           hipLaunchKernelGGL(k_sell<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, nullptr, M.d_ptr,
                              M.d_col, M.d_val, c->d_sc, c->d_partials, count, poff);
+        else if (merge)
+          hipLaunchKernelGGL((k_sweepBD<1, true>), dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr,
+                             c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);
         else
-          hipLaunchKernelGGL(k_sweepBD<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr, c->d_sc,
-                             c->d_partials, first, count, poff);
+          hipLaunchKernelGGL((k_sweepBD<1, false>), dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr,
+                             c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);
       }));
     }
-    CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
+    if (!merge) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       if (c->precond == PRECOND_FD)
@@ -850,19 +794,26 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
         if (matrix)
           hipLaunchKernelGGL(k_sell<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, nullptr, M.d_ptr, M.d_col,
                              M.d_val, c->d_sc, c->d_partials, count, poff);
+        else if (merge)
+          hipLaunchKernelGGL((k_sweepBD<2, true>), dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr,
+                             c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);
         else
-          hipLaunchKernelGGL(k_sweepBD<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr, c->d_sc,
-                             c->d_partials, first, count, poff);
+          hipLaunchKernelGGL((k_sweepBD<2, false>), dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr,
+                             c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);
       }));
     }
-    CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
+    if (!merge) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_E);
-      hipLaunchKernelGGL(k_sweepE, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r, c->d_t,
-                         c->d_rhat, c->d_sc, c->d_partials, n);
+      if (merge)
+        hipLaunchKernelGGL(k_sweepE<true>, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r,
+                           c->d_t, c->d_rhat, c->d_sc, c->d_partials, n, c->d_red, c->d_ticket, &c->h_status[slot]);
+      else
+        hipLaunchKernelGGL(k_sweepE<false>, dim3(gridE), dim3(WG), 0, c->stream, x, c->d_xopt, c->d_z, c->d_z2, c->d_r,
+                           c->d_t, c->d_rhat, c->d_sc, c->d_partials, n, c->d_red, c->d_ticket, &c->h_status[slot]);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
-    CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
+    if (!merge) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
     CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;

@@ -1,0 +1,132 @@
+// krylov_common.h -- device-side pieces shared by the five-sweep solver (krylov.hip) and the tile-fused
+// solver (krylov_fused.hip): the scalar recurrences of BiCGSTABSolver::main (cuda.cu:303-330, 440-545)
+// and the finish of a fused reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "block.h"
+
+namespace cup2d {
+
+// beginning of an iteration (cuda.cu:440-477): consumes rho = rhat.r and ||r||^2
+static __device__ void begin_iteration(KrylovScalars *sc) {
+  if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
+  const bool serious_breakdown = sc->rho_curr * sc->rho_curr < 1e-16 * sc->rr * sc->rhat2;
+  sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta
+  sc->restart_flag = 0;
+  if (serious_breakdown && sc->max_restarts > 0) {
+    sc->restarts++;
+    if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
+    sc->restart_flag = 1;
+    sc->rhat2 = sc->rr;     // rhat = r
+    sc->rho_curr = sc->rr;  // Dnrm2(rhat)^2
+    sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;  // breakdown_update
+    sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
+  }
+}
+// STAGE 0: after k_init_residual  red = {r.r, -, max|r|}
+// STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
+// STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
+// STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
+static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage) {
+  switch (stage) {
+  case 0:
+    sc->err = sc->err_init = sc->err_opt = red[2];
+    sc->x_is_best = 1;
+    sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
+    begin_iteration(sc);
+    break;
+  case 1:
+    sc->alpha = sc->rho_curr / (red[0] + sc->eps);
+    break;
+  case 2:
+    sc->omega = red[0] / (red[1] + sc->eps);
+    break;
+  case 3:
+    sc->iter++;
+    sc->err = red[2];
+    if (sc->err < sc->err_opt) {
+      sc->err_opt = sc->err;
+      sc->x_is_best = 1;
+      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
+    } else {
+      sc->x_is_best = 0;
+    }
+    sc->rho_prev = sc->rho_curr;  // set_rho
+    sc->rho_curr = red[0];
+    sc->rr = red[1];
+    begin_iteration(sc);
+    break;
+  }
+}
+
+// Finish of a fused reduction by ONE workgroup: sums the per-workgroup partials of slots [0,nsum) and
+// takes the max of slot 2, in a fixed order (thread t takes partials t, t+256, ...; then a binary tree),
+// so the result does not depend on which workgroup runs it.  fused_stage >= 0: also runs the scalar
+// update of that stage.  COHERENT: read the partials with agent-scope loads (the caller is a workgroup of
+// the SAME launch that produced them, see arrive_last).
+template <bool COHERENT>
+static __device__ __forceinline__ void finish_reduce(const double *partials, int G, int nsum, int with_max,
+                                                     double *red, KrylovScalars *sc, int fused_stage,
+                                                     int *host_status) {
+  __shared__ double sm[3][WG];
+  const auto ld = [&](const double *p) -> double {
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+  };
+  double a0 = 0, a1 = 0, mx = 0;
+  for (int i = threadIdx.x; i < G; i += WG) {
+    a0 += ld(partials + i);
+    if (nsum > 1) a1 += ld(partials + PSTRIDE + i);
+    if (with_max) mx = fmax(mx, ld(partials + 2 * PSTRIDE + i));
+  }
+  sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = WG / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+      sm[2][threadIdx.x] = fmax(sm[2][threadIdx.x], sm[2][threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    red[0] = sm[0][0]; red[1] = sm[1][0]; red[2] = sm[2][0];
+    if (fused_stage >= 0) {
+      const double loc[3] = {sm[0][0], sm[1][0], sm[2][0]};
+      scalars_update(sc, loc, fused_stage);
+      // end of an iteration: tell the host (pinned, device-visible word) whether the loop is over
+      if (fused_stage == 3 && host_status)
+        __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// "The last workgroup to arrive finishes the reduction" -- removes the single-workgroup finish kernel
+// (8.6 us + a kernel boundary, three times per BiCGSTAB iteration).  Every workgroup of the launch calls
+// this once after it has stored its partials (workgroup_reduce_store with COHERENT = true: agent-scope
+// stores); exactly one call per launch returns true, in all threads of that workgroup, and only after
+// every other workgroup's partials are visible to agent-scope loads.  The counter is re-armed to zero by
+// the last arriver, so consecutive launches on one stream can share it.
+// Ordering (MI355X_MICROARCH.md, "valid forms"): partial stores -> __syncthreads -> lane-0 release fence
+// at agent scope -> explicit vmcnt(0) (the compiler may drop its own) -> relaxed agent atomic ticket;
+// the last arriver: agent acquire fence -> __syncthreads -> agent-scope loads.
+static __device__ __forceinline__ bool arrive_last(unsigned *counter) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == gridDim.x - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+}  // namespace cup2d

@@ -151,6 +151,11 @@ class Simulation:
     def set_precond(self, kind):
         _l.check(self.L.cup2d_set_precond(self._ctx, int(kind)), "set_precond")
 
+    def set_solver(self, fused=False, finish_in_kernel=False):
+        """organisation of a BiCGSTAB iteration (include/cup2d_hip.h cup2d_solver_kind)"""
+        _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)),
+                 "set_solver")
+
     def set_matrix_coo(self, row, col, val, halo=0):
         """Assembled Poisson operator (what main.cpp:7034-7112 pushes into LocalSpMatDnVec), local
         int32 indices in device block order; poisson_solve / apply_A use it instead of the stencil."""

@@ -154,6 +154,18 @@ int cup2d_set_P_inv(cup2d_ctx *ctx, const double *P_inv_4096);
 typedef enum { CUP2D_PRECOND_LDS = 0, CUP2D_PRECOND_MFMA = 1, CUP2D_PRECOND_FD = 2 } cup2d_precond_kind;
 int cup2d_set_precond(cup2d_ctx *ctx, int kind);
 
+/* Organisation of one BiCGSTAB iteration (all variants run the recurrences of cuda.cu:403-548; they differ in
+ * how many times a vector crosses HBM and by round-off):
+ *   CUP2D_SOLVER_SWEEPS five fused sweeps, z and z2 stored (184 B/cell/iteration); every configuration.
+ *   CUP2D_SOLVER_FUSED  tile-fused: P_inv on the FP64 matrix cores recomputed on tile edges, sweeps A+B and
+ *                       C+D one launch each, x accumulated as x0 + P_inv y (136 B/cell/iteration); same-level
+ *                       stencil on one GPU -- elsewhere (ghost blocks, assembled matrix) SWEEPS is used.
+ * finish_in_kernel != 0: the last workgroup of a reducing sweep finishes the reduction and updates the device
+ * scalars instead of a separate single-workgroup launch (ignored when an all-reduce callback is installed).
+ * Defaults come from CUP2D_SOLVER (sweeps|fused) and CUP2D_FINISH_IN_KERNEL (0|1) at cup2d_create. */
+typedef enum { CUP2D_SOLVER_SWEEPS = 0, CUP2D_SOLVER_FUSED = 1 } cup2d_solver_kind;
+int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
+
 /* ---------------------------------------------------------------- assembled operator ----- */
 /* The seam the reference itself crosses (cuda.h LocalSpMatDnVec): instead of the 5-point stencil on
  * the neighbour table, cup2d_poisson_solve / cup2d_apply_A use the COO matrix the caller assembled

@@ -108,14 +108,16 @@ static __device__ __forceinline__ void finish_reduce(const double *partials, int
 // stores); exactly one call per launch returns true, in all threads of that workgroup, and only after
 // every other workgroup's partials are visible to agent-scope loads.  The counter is re-armed to zero by
 // the last arriver, so consecutive launches on one stream can share it.
-// Ordering (MI355X_MICROARCH.md, "valid forms"): partial stores -> __syncthreads -> lane-0 release fence
-// at agent scope -> explicit vmcnt(0) (the compiler may drop its own) -> relaxed agent atomic ticket;
-// the last arriver: agent acquire fence -> __syncthreads -> agent-scope loads.
+// Ordering (MI355X_MICROARCH.md, "handoff-flag", drained sc1 form): the partials are agent-scope
+// (write-through, sc1) stores issued by wave 0 -> __syncthreads -> lane 0 drains its wave's stores with an
+// explicit vmcnt(0) -> relaxed agent atomic ticket; the last arriver reads the partials with agent-scope
+// (sc1) loads after an agent acquire.  NO agent-scope RELEASE fence: it lowers to buffer_wbl2, a write-back
+// of the XCD's whole L2, and 2048 workgroups issuing one each at the end of a streaming sweep doubled the
+// sweep's duration (measured: sweep B 103 -> 205 us at 4096^2).
 static __device__ __forceinline__ bool arrive_last(unsigned *counter) {
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = t == gridDim.x - 1;

@@ -78,7 +78,7 @@ struct FusedArgs {
 template <int MODE, bool MERGE>
 __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                  const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
-                                                 int count, double *red, unsigned *ticket) {
+                                                 int count, double *red, unsigned *ticket, int dbg) {
   __shared__ FusedLds lds[WPG];
   if (sc->status != 0) return;
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -115,11 +115,16 @@ __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__re
     const int nb = si < nvalid ? nbr[4 * (b0 + si) + ss] : CUP2D_WALL;
     const bool is_ring = si < nvalid && nb >= 0 && (nb < b0 || nb >= b0 + nvalid);
     const unsigned long long rmask = __ballot(is_ring);
-    const int nring = __popcll(rmask);
+    int nring = __popcll(rmask);
     if (is_ring) {
       const int slot = __popcll(rmask & ((1ull << lane) - 1ull));
       L.ring_nb[slot] = nb;
       L.ring_dst[slot] = lane;
+    }
+    if (dbg & 1) {  // timing experiment (CUP2D_FUSED_DBG): no ring at all -- WRONG results
+      nring = 0;
+#pragma unroll
+      for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = 0.0;
     }
     wave_lds_sync();
     // ---- ring: z on the edges of the blocks around the tile, 16 entries per pass ----
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__re
         for (int e = 0; e < 8; e++) L.S[(h + e) * XS + lane] = form_v(ra[e], rb[e], rc[e]);
       }
       wave_lds_sync();
-      tile_precond(L.S, P, lane);
+      if (!(dbg & 2)) tile_precond(L.S, P, lane);  // dbg 2: ring loads but no ring MFMA -- WRONG results
       // entry e feeds slot dst = block*4 + side with the OPPOSITE edge of the neighbour block
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__re
       }
     }
     wave_lds_sync();
-    tile_precond(L.S, P, lane);
+    if (!(dbg & 4)) tile_precond(L.S, P, lane);  // dbg 4: no tile MFMA -- WRONG results
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
     if (si < nvalid && !is_ring) {
@@ -294,6 +299,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   if (gridF >= 8) gridF -= gridF % 8;
   if (gridF < 1) gridF = 1;
   const bool merge = c->finish_in_kernel && !c->allreduce;
+  static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
@@ -325,10 +331,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
       if (merge)
         hipLaunchKernelGGL((k_fused<0, true>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket);
+                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
       else
         hipLaunchKernelGGL((k_fused<0, false>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket);
+                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
     if (!merge) CUP2D_TRY(finish(c, gridF, 1, 0, 1, true));
@@ -337,10 +343,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
       if (merge)
         hipLaunchKernelGGL((k_fused<1, true>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket);
+                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
       else
         hipLaunchKernelGGL((k_fused<1, false>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket);
+                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
     if (!merge) CUP2D_TRY(finish(c, gridF, 2, 0, 2, true));

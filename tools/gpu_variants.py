@@ -16,7 +16,10 @@ from cup2d_amd import lib as L  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 VARIANTS = [("sweeps", False), ("sweeps", True), ("fused", False), ("fused", True)]
+if os.environ.get("VARIANTS"):  # e.g. VARIANTS=fused0,sweeps1
+    VARIANTS = [(v[:-1], v[-1] == "1") for v in os.environ["VARIANTS"].split(",")]
 ok = True
+SKIP_CHECK = os.environ.get("SKIP_CHECK") == "1"
 
 n = 128
 rng = np.random.default_rng(3)
@@ -24,7 +27,7 @@ b = rng.uniform(-1, 1, (n, n))
 b -= b.mean()
 xo, io = O.bicgstab(b, tol=1e-10, max_restarts=100, max_iter=400)
 with cup2d_amd.Simulation(n // 8) as s:
-    for kind, fin in VARIANTS:
+    for kind, fin in ([] if SKIP_CHECK else VARIANTS):
         s.set_solver(fused=kind == "fused", finish_in_kernel=fin)
         s.tmp = b
         s.fill(L.PRES, 0.0)

@@ -28,8 +28,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_SOLVER = "sweeps"    # flipped to "fused" once its GPU parity run is green
-DEFAULT_FINISH = "launch"
+DEFAULT_SOLVER = "fused"     # the library's default; "sweeps" = the five-sweep organisation
+DEFAULT_FINISH = "kernel"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 
@@ -172,16 +172,16 @@ def main():
     finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on
     # gfx950), summarised by tools/prof_summary.py from the same bench command: profiles/<tag>_pmc_traffic.json
-    traffic_tab, traffic_src = {}, None
+    traffic_tab, traffic_src = {}, {}
     prof_dir = os.path.join(ROOT, "profiles")
-    if os.path.isdir(prof_dir):
-        cands = sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_traffic.json"))
-        if cands:
-            traffic_src = "profiles/" + cands[-1]
+    if os.path.isdir(prof_dir):  # every committed summary; kernels are looked up by name (a later file wins)
+        for f in sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_traffic.json")):
             try:
-                traffic_tab = json.load(open(os.path.join(prof_dir, cands[-1])))["kernels"]
+                for k, v in json.load(open(os.path.join(prof_dir, f)))["kernels"].items():
+                    traffic_tab[k] = v
+                    traffic_src[k] = "profiles/" + f
             except Exception:
-                traffic_tab = {}
+                pass
 
     def roofline_of(fam):
         t = timers[fam]
@@ -191,7 +191,8 @@ def main():
         gbs = ALGO_BYTES[fam] * cells_rank / sec / 1e9
         tr = traffic_tab.get(KERNEL_OF[fam], {}).get("hbm_bytes") if n == 4096 and world == 1 else None
         return {"kernel": KERNEL_OF[fam], "family": fam, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_source": traffic_src if tr else None,
+                "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr,
+                "traffic_source": traffic_src.get(KERNEL_OF[fam]) if tr else None,
                 "bytes_per_cell": ALGO_BYTES[fam], "avg_launch_ms": round(sec * 1e3, 4), "launches": t["launches"],
                 "share_of_gpu_time": None}
 

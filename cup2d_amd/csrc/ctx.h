@@ -107,8 +107,8 @@ struct cup2d_ctx {
   // tile-fused solver (krylov_fused.hip): ping-pong copies of p and nu, s = r - alpha nu, and the
   // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
   double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
-  int solver = 0;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
-  int finish_in_kernel = 0;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
+  int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
+  int finish_in_kernel = 1;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
   unsigned *d_ticket = nullptr;  // arrival counter of arrive_last, zero between launches
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback

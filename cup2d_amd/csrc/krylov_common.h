@@ -74,13 +74,15 @@ static __device__ __forceinline__ void finish_reduce(const double *partials, int
     if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
   };
-  double a0 = 0, a1 = 0, mx = 0;
-  for (int i = threadIdx.x; i < G; i += WG) {
-    a0 += ld(partials + i);
-    if (nsum > 1) a1 += ld(partials + PSTRIDE + i);
-    if (with_max) mx = fmax(mx, ld(partials + 2 * PSTRIDE + i));
+  if (threadIdx.x < WG) {  // the first 256 threads (callers may run wider workgroups): the order is fixed
+    double a0 = 0, a1 = 0, mx = 0;
+    for (int i = threadIdx.x; i < G; i += WG) {
+      a0 += ld(partials + i);
+      if (nsum > 1) a1 += ld(partials + PSTRIDE + i);
+      if (with_max) mx = fmax(mx, ld(partials + 2 * PSTRIDE + i));
+    }
+    sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
   }
-  sm[0][threadIdx.x] = a0; sm[1][threadIdx.x] = a1; sm[2][threadIdx.x] = mx;
   __syncthreads();
   for (int s = WG / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {

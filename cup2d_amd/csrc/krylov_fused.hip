@@ -32,31 +32,54 @@
 
 namespace cup2d {
 
-constexpr int TB = 16;  // blocks per tile
-constexpr int XS = 66;  // LDS stride of one block in the staging tile: the A-operand reads of a half-wave
-                        // (block = lane%16, k = 4ks + lane/16) then fall on 32 distinct 8-byte banks
+constexpr int TB = 16;   // blocks per tile
+constexpr int XS = 66;   // LDS stride of one block in the staging tile: the A-operand reads of a half-wave
+                         // (block = lane%16, k = 4ks + lane/16) then fall on 32 distinct 8-byte banks
+constexpr int FWG = 512;         // threads per workgroup of the fused sweeps: 8 waves, ONE workgroup per CU
+constexpr int FWAVES = FWG / 64;
+#ifndef CUP2D_FUSED_NT
+#define CUP2D_FUSED_NT 0  // 1: AB 195 -> 189 us at 4096^2 but its HBM reads 40 -> 50 B/cell (ring re-reads miss L2)
+#endif
+constexpr bool NT_LOADS = CUP2D_FUSED_NT != 0;
+#ifndef CUP2D_FUSED_NTS
+#define CUP2D_FUSED_NTS 1
+#endif
+constexpr bool NT_STORES = CUP2D_FUSED_NTS != 0;  // outputs are not re-read in the sweep: do not let them evict the inputs the ring re-reads need
+constexpr int PL_DOUBLES = 16 * 4 * 64;  // P_inv as MFMA B fragments: [k-step][n-tile][lane]
 
 struct FusedLds {
-  double S[TB * XS];     // v of 16 blocks, then (same storage) z of those blocks
+  double S[TB * XS];       // v of 16 blocks, then (same storage) z of those blocks
   double GE[TB * 4 * BS];  // z on the ghost edges of the tile's blocks: [block][W,E,S,N][position]
-  int ring_nb[TB * 4];   // neighbour block of ring entry e ...
-  int ring_dst[TB * 4];  // ... and the slot (block * 4 + side) it feeds
+  int ring_nb[TB * 4];     // neighbour block of ring entry e ...
+  int ring_dst[TB * 4];    // ... and the slot (block * 4 + side) it feeds
 };
+constexpr size_t FUSED_LDS_BYTES = PL_DOUBLES * sizeof(double) + FWAVES * sizeof(FusedLds);
 
 // cell (iy*8+ix) at position q of the edge on side s (W, E, S, N) of a block
 static __device__ __forceinline__ int edge_cell(int s, int q) {
   return s == 0 ? q * BS : s == 1 ? q * BS + (BS - 1) : s == 2 ? q : (BS - 1) * BS + q;
 }
 
-// S (v, block-major) -> Z = V P_inv -> S (z, block-major).  Same MFMA sequence as k_sweepA_mfma /
-// k_sweepC_mfma (precond_tile), so z is bit-identical to the unfused MFMA preconditioner.
-static __device__ __forceinline__ void tile_precond(double *S, const PinvFragments &P, int lane) {
+// S (v, block-major) -> Z = V P_inv -> S (z, block-major) on v_mfma_f64_16x16x4_f64 with the fragment maps
+// of precond_mfma.h.  The B operands (P_inv) come from LDS, one conflict-free ds_read_b64 per MFMA: in
+// registers they cost every wave 128 VGPRs -- the first version of this kernel had nothing left to keep
+// loads in flight with (2 waves per SIMD, 234 VGPRs) and ran latency-bound at 3.3 TB/s.  Same k order and
+// operands as precond_tile, so z is bit-identical to the unfused MFMA preconditioner.
+static __device__ __forceinline__ void tile_precond(double *S, const double *PL, int lane, bool skip) {
   double xa[16];
   const int ablk = lane & 15, akk = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
   v4f64 acc[4];
-  precond_tile(xa, P, acc);
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (!skip) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++)
+        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+  }
   wave_lds_sync();  // every lane has read its operands before the tile is overwritten
 #pragma unroll
   for (int v = 0; v < 4; v++)
@@ -71,21 +94,49 @@ struct FusedArgs {
   double *vout, *yout;            // AB: p', nu'      CD: s, t
 };
 
+// one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)
+template <int NW, int N, bool COHERENT>
+static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double *partials) {
+  __shared__ double red[N][NW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double w = wave_sum(v[i]);
+    if (lane == 0) red[i][wave] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    double a = red[threadIdx.x][0];
+    for (int k = 1; k < NW; k++) a += red[threadIdx.x][k];
+    double *dst = partials + (size_t)threadIdx.x * PSTRIDE + blockIdx.x;
+    if (COHERENT) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = a;
+  }
+}
+
 // MODE 0 (sweeps A+B): v = p' = beta (p - omega nu) + r   (cuda.cu:478-483; restart: p' = rhat = r, 461-476)
 //                      y = nu' = A P_inv p' ; partial(rhat . nu')                       (484-488)
 // MODE 1 (sweeps C+D): v = s  = r - alpha nu'                                            (499-502)
 //                      y = t  = A P_inv s  ; partial(t . s, t . t)                      (503-509)
+// A tile is a chain of JOBS of 16 blocks each -- ceil(nring/16) ring passes, then the tile itself -- and a job
+// is two batches of 8 blocks.  The global loads of a batch are issued one batch ahead of their use, across
+// job boundaries, so a wave always has 8 blocks x {3|2} vectors in flight while it stages, multiplies,
+// gathers; the w operand of the dot product (rhat) is requested before the tile's MFMA.
 template <int MODE, bool MERGE>
-__global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
-                                                 const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
-                                                 int count, double *red, unsigned *ticket, int dbg) {
-  __shared__ FusedLds lds[WPG];
+__global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
+                                                  const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
+                                                  int count, double *red, unsigned *ticket, int dbg) {
+  extern __shared__ double fsm[];
   if (sc->status != 0) return;
+  double *PL = fsm;
+  for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
+    const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
+    PL[idx] = Pinv[(4 * ks + (l >> 4)) * BC + 16 * nt + (l & 15)];
+  }
+  __syncthreads();
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  FusedLds &L = lds[wave];
+  FusedLds &L = reinterpret_cast<FusedLds *>(fsm + PL_DOUBLES)[wave];
   const int ix = lane & 7, iy = lane >> 3;
-  PinvFragments P;
-  P.load(Pinv, lane);
   const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
   const double beta = sc->beta;
   const bool restart = MODE == 0 && sc->restart_flag != 0;
@@ -94,7 +145,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__re
 #pragma unroll
   for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
 
-  // v of block `blk` at this lane's cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
+  // v at this lane's cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
   const auto form_v = [&](double a, double b, double c) -> double {
     if (MODE == 0) {
       if (restart) return c;
@@ -104,118 +155,183 @@ __global__ __launch_bounds__(WG, 2) void k_fused(FusedArgs A, const double *__re
     }
     return a + c1 * b;
   };
+  struct Raw {
+    double a[8], b[8], c[8];
+  };
 
+  // tiles of 16 blocks over the waves of the persistent grid, contiguous per XCD (workgroup w runs on XCD w % 8)
   const int ntiles = (count + TB - 1) / TB;
-  const TileRange tr = tile_range(ntiles);
-  for (int t = tr.begin; t < tr.end; t += tr.stride) {
-    const int b0 = t * TB;
-    const int nvalid = min(TB, count - b0);
-    // ---- classify the 64 (block, side) neighbour slots of the tile: lane = block * 4 + side ----
-    const int si = lane >> 2, ss = lane & 3;
-    const int nb = si < nvalid ? nbr[4 * (b0 + si) + ss] : CUP2D_WALL;
-    const bool is_ring = si < nvalid && nb >= 0 && (nb < b0 || nb >= b0 + nvalid);
-    const unsigned long long rmask = __ballot(is_ring);
-    int nring = __popcll(rmask);
-    if (is_ring) {
+  int t_begin, t_end, t_stride;
+  {
+    const int G = gridDim.x, w = blockIdx.x;
+    if (G >= 8 && (G % 8) == 0) {
+      const int xcd = w & 7, slot = w >> 3, per = G >> 3;
+      const long long lo = (long long)ntiles * xcd / 8, hi = (long long)ntiles * (xcd + 1) / 8;
+      t_begin = (int)lo + slot * FWAVES + wave;
+      t_end = (int)hi;
+      t_stride = per * FWAVES;
+    } else {
+      t_begin = w * FWAVES + wave;
+      t_end = ntiles;
+      t_stride = G * FWAVES;
+    }
+  }
+  const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
+  const auto load_nb = [&](int t) -> int {
+    const int b = t * TB + si;
+    return (t < t_end && b < count) ? nbr[4 * b + ss] : CUP2D_WALL;
+  };
+  // state of a tile: its blocks, this lane's neighbour slot, the ring list (in LDS) it was classified into
+  struct Tile {
+    int b0, nvalid, nb, nring, npass;
+    bool is_ring;
+  };
+  // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the list
+  // of the previous tile: call only when that one is dead)
+  const auto classify = [&](int t, int nb) -> Tile {
+    Tile T;
+    T.b0 = t * TB;
+    T.nvalid = min(TB, count - T.b0);
+    T.nb = nb;
+    T.is_ring = si < T.nvalid && nb >= 0 && (nb < T.b0 || nb >= T.b0 + T.nvalid);
+    const unsigned long long rmask = __ballot(T.is_ring);
+    T.nring = (dbg & 1) ? 0 : __popcll(rmask);  // dbg 1: timing experiment without the ring -- WRONG results
+    T.npass = (T.nring + TB - 1) / TB;
+    if (T.is_ring) {
       const int slot = __popcll(rmask & ((1ull << lane) - 1ull));
       L.ring_nb[slot] = nb;
       L.ring_dst[slot] = lane;
     }
-    if (dbg & 1) {  // timing experiment (CUP2D_FUSED_DBG): no ring at all -- WRONG results
-      nring = 0;
+    wave_lds_sync();
+    return T;
+  };
+  // blocks of the 8 entries of batch `half` of job j of tile T -- ring entries, or for the last job blocks of
+  // the tile -- branch-free (the ring list is read even when it is not used), so that the 8 x {3|2} loads
+  // issue back to back
+  const auto issue = [&](Raw &R, const Tile &T, int j, int half) {
+    const bool tile_job = j >= T.npass;
+    const int ne = max(1, min(TB, T.nring - j * TB));
+    int blk[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int idx = 8 * half + e;
+      const int rb = L.ring_nb[min(j * TB + min(idx, ne - 1), TB * 4 - 1)];
+      blk[e] = tile_job ? T.b0 + min(idx, T.nvalid - 1) : rb;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const size_t o = (size_t)uniform(blk[e]) * BC + lane;
+      if (NT_LOADS && tile_job) {  // streamed once by the tile's own job: keep L2 for the ring re-reads
+        R.a[e] = __builtin_nontemporal_load(A.in0 + o);
+        R.b[e] = __builtin_nontemporal_load(A.in1 + o);
+        if (MODE == 0) R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+      } else {
+        R.a[e] = A.in0[o];
+        R.b[e] = A.in1[o];
+        if (MODE == 0) R.c[e] = A.in2[o];
+      }
+    }
+  };
+
+  Raw Ra, Rb;
+  Tile T;
+  if (t_begin < t_end) {
+    T = classify(t_begin, load_nb(t_begin));
+    issue(Ra, T, 0, 0);
+  }
+  int nb_next = load_nb(t_begin + t_stride);
+  for (int t = t_begin; t < t_end; t += t_stride) {
+    // invariant: T describes tile t, its ring list is in LDS, the first batch of its first job is in flight in Ra
+    const int b0 = T.b0, nvalid = T.nvalid;
+    if (dbg & 1) {
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = 0.0;
     }
-    wave_lds_sync();
-    // ---- ring: z on the edges of the blocks around the tile, 16 entries per pass ----
-    for (int base = 0; base < nring; base += TB) {
-      const int ne = min(TB, nring - base);
-#pragma unroll
-      for (int h = 0; h < TB; h += 8) {
-        double ra[8], rb[8], rc[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const int blk = uniform(L.ring_nb[base + min(h + e, ne - 1)]);
-          const size_t o = (size_t)blk * BC + lane;
-          ra[e] = A.in0[o];
-          rb[e] = A.in1[o];
-          rc[e] = MODE == 0 ? A.in2[o] : 0.0;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; e++) L.S[(h + e) * XS + lane] = form_v(ra[e], rb[e], rc[e]);
-      }
-      wave_lds_sync();
-      if (!(dbg & 2)) tile_precond(L.S, P, lane);  // dbg 2: ring loads but no ring MFMA -- WRONG results
-      // entry e feeds slot dst = block*4 + side with the OPPOSITE edge of the neighbour block
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
-        if (e < ne) {
-          const int dst = L.ring_dst[base + e];
-          L.GE[dst * BS + q] = L.S[e * XS + edge_cell((dst & 3) ^ 1, q)];
-        }
-      }
-      wave_lds_sync();
-    }
-    // ---- the tile's own blocks ----
-#pragma unroll
-    for (int h = 0; h < TB; h += 8) {
-      double ra[8], rb[8], rc[8];
+    double W[TB];  // dot-product operand of the tile's cells: rhat (AB; r on a restart) or s itself (CD)
+    const auto stage = [&](const Raw &R, bool is_tile, int half) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        const size_t o = (size_t)(b0 + min(h + e, nvalid - 1)) * BC + lane;
-        ra[e] = A.in0[o];
-        rb[e] = A.in1[o];
-        rc[e] = MODE == 0 ? A.in2[o] : 0.0;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const double v = form_v(ra[e], rb[e], rc[e]);
-        L.S[(h + e) * XS + lane] = v;
-        if (h + e < nvalid) {
-          const size_t o = (size_t)(b0 + h + e) * BC + lane;
-          A.vout[o] = v;
-          if (MODE == 0 && restart) A.w[o] = rc[e];  // rhat = r
+        const int idx = 8 * half + e;
+        const double v = form_v(R.a[e], R.b[e], MODE == 0 ? R.c[e] : 0.0);
+        L.S[idx * XS + lane] = v;
+        if (is_tile) {
+          if (MODE == 1) W[idx] = v;
+          if (MODE == 0 && restart) W[idx] = R.c[e];
+          if (idx < nvalid) {
+            const size_t o = (size_t)(b0 + idx) * BC + lane;
+            if (NT_STORES) __builtin_nontemporal_store(v, A.vout + o);
+            else A.vout[o] = v;
+            if (MODE == 0 && restart) A.w[o] = R.c[e];  // rhat = r
+          }
         }
       }
+    };
+    Tile N = T;  // the next tile, once classified
+    for (int j = 0; j <= T.npass; j++) {
+      const bool is_tile = j == T.npass;
+      issue(Rb, T, j, 1);
+      stage(Ra, is_tile, 0);
+      if (!is_tile) {
+        issue(Ra, T, j + 1, 0);
+      } else if (MODE == 0 && !restart) {
+#pragma unroll
+        for (int i = 0; i < TB; i++) W[i] = A.w[(size_t)(b0 + min(i, nvalid - 1)) * BC + lane];
+      }
+      stage(Rb, is_tile, 1);
+      if (is_tile && t + t_stride < t_end) {
+        // this tile's ring list is dead: classify the NEXT tile into it and put its first batch in flight
+        // behind this tile's MFMA, edge fill and stencil
+        N = classify(t + t_stride, nb_next);
+        nb_next = load_nb(t + 2 * t_stride);
+        issue(Ra, N, 0, 0);
+      } else {
+        wave_lds_sync();
+      }
+      tile_precond(L.S, PL, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      if (!is_tile) {
+        // entry e feeds slot dst = block*4 + side with the OPPOSITE edge of the neighbour block
+        const int ne = min(TB, T.nring - j * TB);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
+          if (e < ne) {
+            const int dst = L.ring_dst[j * TB + e];
+            L.GE[dst * BS + q] = L.S[e * XS + edge_cell((dst & 3) ^ 1, q)];
+          }
+        }
+        wave_lds_sync();
+      }
     }
-    wave_lds_sync();
-    if (!(dbg & 4)) tile_precond(L.S, P, lane);  // dbg 4: no tile MFMA -- WRONG results
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
-    if (si < nvalid && !is_ring) {
-      const int sblk = nb < 0 ? si : nb - b0, sside = nb < 0 ? ss : ss ^ 1;
+    if (si < nvalid && !T.is_ring) {
+      const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = L.S[sblk * XS + edge_cell(sside, q)];
     }
     wave_lds_sync();
     // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products ----
-    const double *wsrc = MODE == 0 ? (restart ? A.in2 : A.w) : A.vout;
-    for (int i0 = 0; i0 < nvalid; i0 += 4) {  // four blocks per round: their w loads are in flight together
-      double wc[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) wc[u] = wsrc[(size_t)(b0 + min(i0 + u, nvalid - 1)) * BC + lane];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u;
-        if (i < nvalid) {
-          const double *zb = L.S + i * XS + lane;
-          const double *ge = L.GE + i * 4 * BS;
-          const double l0 = zb[0];
-          const double l1 = *(ix > 0 ? zb - 1 : ge + 0 * BS + iy);
-          const double l2 = *(ix < BS - 1 ? zb + 1 : ge + 1 * BS + iy);
-          const double l3 = *(iy > 0 ? zb - BS : ge + 2 * BS + ix);
-          const double l4 = *(iy < BS - 1 ? zb + BS : ge + 3 * BS + ix);
-          const double yv = l1 + l2 + l3 + l4 - 4 * l0;
-          A.yout[(size_t)(b0 + i) * BC + lane] = yv;
-          acc[0] = __builtin_fma(yv, wc[u], acc[0]);
-          if constexpr (NDOT == 2) acc[1] = __builtin_fma(yv, yv, acc[1]);
-        }
+    for (int i = 0; i < TB; i++) {
+      if (i < nvalid) {
+        const double *zb = L.S + i * XS + lane;
+        const double *ge = L.GE + i * 4 * BS;
+        const double l0 = zb[0];
+        const double l1 = *(ix > 0 ? zb - 1 : ge + 0 * BS + iy);
+        const double l2 = *(ix < BS - 1 ? zb + 1 : ge + 1 * BS + iy);
+        const double l3 = *(iy > 0 ? zb - BS : ge + 2 * BS + ix);
+        const double l4 = *(iy < BS - 1 ? zb + BS : ge + 3 * BS + ix);
+        const double yv = l1 + l2 + l3 + l4 - 4 * l0;
+        if (NT_STORES) __builtin_nontemporal_store(yv, A.yout + (size_t)(b0 + i) * BC + lane);
+        else A.yout[(size_t)(b0 + i) * BC + lane] = yv;
+        acc[0] = __builtin_fma(yv, W[i], acc[0]);
+        if constexpr (NDOT == 2) acc[1] = __builtin_fma(yv, yv, acc[1]);
       }
     }
-    wave_lds_sync();  // the next tile overwrites S, GE and the ring list
+    wave_lds_sync();  // the next tile overwrites S and GE
+    T = N;
   }
-  workgroup_reduce_store<NDOT, false, MERGE>(acc, partials, 0, 0);
+  fused_reduce_store<FWAVES, NDOT, MERGE>(acc, partials);
   if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, NDOT, 0, red, sc, MODE + 1, nullptr);
 }
 
@@ -291,13 +407,22 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const int G = grid_for(c, nb);
   int gridE = (int)((n / 2 + WG - 1) / WG);
   if (gridE > c->grid) gridE = c->grid;
-  // one wave per 16-block tile, 2 workgroups per CU (P_inv lives in 128 VGPRs of every wave)
+  // one wave per 16-block tile; 8 waves = ONE 512-thread workgroup per CU (P_inv fragments + 8 staging
+  // tiles are 134 KiB of its 160 KiB LDS)
   const int ntiles = (nb + TB - 1) / TB;
-  int gridF = (ntiles + WPG - 1) / WPG;
-  const int capF = 2 * (c->num_cus > 0 ? c->num_cus : 256);
+  int gridF = (ntiles + FWAVES - 1) / FWAVES;
+  const int capF = c->num_cus > 0 ? c->num_cus : 256;
   if (gridF > capF) gridF = capF;
   if (gridF >= 8) gridF -= gridF % 8;
   if (gridF < 1) gridF = 1;
+  static bool lds_set = false;
+  if (!lds_set) {  // > 64 KiB of LDS is an opt-in per kernel
+    const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, true>), reinterpret_cast<const void *>(&k_fused<0, false>),
+                        reinterpret_cast<const void *>(&k_fused<1, true>), reinterpret_cast<const void *>(&k_fused<1, false>)};
+    for (const void *k : ks)
+      CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
+    lds_set = true;
+  }
   const bool merge = c->finish_in_kernel && !c->allreduce;
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
@@ -330,10 +455,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
       if (merge)
-        hipLaunchKernelGGL((k_fused<0, true>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
+        hipLaunchKernelGGL((k_fused<0, true>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
                            c->d_partials, nb, c->d_red, c->d_ticket, dbg);
       else
-        hipLaunchKernelGGL((k_fused<0, false>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
+        hipLaunchKernelGGL((k_fused<0, false>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
                            c->d_partials, nb, c->d_red, c->d_ticket, dbg);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
@@ -342,10 +467,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
       if (merge)
-        hipLaunchKernelGGL((k_fused<1, true>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
+        hipLaunchKernelGGL((k_fused<1, true>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
                            c->d_partials, nb, c->d_red, c->d_ticket, dbg);
       else
-        hipLaunchKernelGGL((k_fused<1, false>), dim3(gridF), dim3(WG), 0, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
+        hipLaunchKernelGGL((k_fused<1, false>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
                            c->d_partials, nb, c->d_red, c->d_ticket, dbg);
     }
     CUP2D_HIP_CHECK(hipGetLastError());

@@ -48,7 +48,11 @@ for sub, ctr in (("pmc_fetch_%s" % tag, "FETCH_SIZE"), ("pmc_write_%s" % tag, "W
         if r["Counter_Name"] == ctr:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        traffic.setdefault(k, {})[ctr] = {"launches": len(v), "avg_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
+        # launches that return at once (speculative BiCGSTAB iterations enqueued behind a finished solve) move no
+        # data: they are not part of the per-launch average
+        full = [x for x in v if x >= 0.05 * max(v)] or v
+        traffic.setdefault(k, {})[ctr] = {"launches": len(full), "early_exits": len(v) - len(full),
+                                          "avg_KiB": sum(full) / len(full), "min_KiB": min(full), "max_KiB": max(full)}
 if traffic:
     outj = {"unit": "bytes per launch", "correction": "hbm_bytes = 2 * FETCH_SIZE_KiB * 1024 + WRITE_SIZE_KiB * 1024 (gfx950 FETCH_SIZE x2)",
             "kernels": {}}

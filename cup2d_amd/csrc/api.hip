@@ -433,9 +433,16 @@ int cup2d_poisson_solve(cup2d_ctx *c, double max_error, double max_rel_error, in
                         int *restarts, double *linf, double *linf_init) {
   CUP2D_CHECK_CTX(c);
   if (max_iter < 0) { set_error("poisson_solve: max_iter"); return CUP2D_ERR_ARG; }
-  if (c->solver == CUP2D_SOLVER_FUSED && fused_supported(c))
+  c->last_solver = (c->solver == CUP2D_SOLVER_FUSED && fused_supported(c)) ? CUP2D_SOLVER_FUSED : CUP2D_SOLVER_SWEEPS;
+  if (c->last_solver == CUP2D_SOLVER_FUSED)
     return solve_fused_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
   return solve_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
+}
+int cup2d_get_last_solver(cup2d_ctx *c, int *kind) {
+  CUP2D_CHECK_CTX(c);
+  if (!kind) return CUP2D_ERR_ARG;
+  *kind = c->last_solver;
+  return CUP2D_OK;
 }
 int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   CUP2D_CHECK_CTX(c);

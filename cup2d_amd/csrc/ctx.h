@@ -108,6 +108,7 @@ struct cup2d_ctx {
   // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
   double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
+  int last_solver = 0;       // what the last solve ran
   int finish_in_kernel = 1;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
   unsigned *d_ticket = nullptr;  // arrival counter of arrive_last, zero between launches
   double *d_partials = nullptr;  // [NSLOT][grid]

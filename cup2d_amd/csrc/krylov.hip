@@ -523,11 +523,23 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
   workgroup_reduce_store<1, true>(m, partials, 2, poff);
 }
 
-// r = rhat = b - A x over all owned blocks in one launch (no ghost blocks): the fused solver's entry
-int launch_init_residual(cup2d_ctx *c, const double *x, const double *b, int G) {
-  hipLaunchKernelGGL(k_init_residual, dim3(G), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr, c->d_partials, 0,
-                     c->nblocks, 0);
+// r = rhat = b - A x over all owned blocks on the neighbour table (the fused solver's entry): inner blocks
+// while the face strips of x are in flight, halo blocks after unpack (main.cpp:3035-3057).  *GP = number of
+// per-workgroup partials written.
+int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP) {
+  const int nb = c->nblocks;
+  const int n_in = overlapped(c) ? c->n_inner : nb, n_ha = nb - n_in;
+  const int G_in = n_in > 0 ? grid_for(c, n_in) : 0, G_ha = n_ha > 0 ? grid_for(c, n_ha) : 0;
+  CUP2D_TRY(exchange_begin(c, x, 1, 1));
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_init_residual, dim3(G_in), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                       c->d_partials, 0, n_in, 0);
+  CUP2D_TRY(exchange_end(c, x, 1, 1));
+  if (n_ha > 0)
+    hipLaunchKernelGGL(k_init_residual, dim3(G_ha), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                       c->d_partials, n_in, n_ha, G_in);
   CUP2D_HIP_CHECK(hipGetLastError());
+  *GP = G_in + G_ha;
   return CUP2D_OK;
 }
 

@@ -125,7 +125,11 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 template <int MODE, bool MERGE>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
-                                                  int count, double *red, unsigned *ticket, int dbg) {
+                                                  int first, int count, int poff, int nowned,
+                                                  const double *__restrict__ zg, double *red, unsigned *ticket,
+                                                  int dbg) {
+  // blocks [first, first + count) of the nowned owned blocks; neighbour ids >= nowned are ghost blocks whose z
+  // edges were computed by their owner rank (k_fused_edges) and unpacked into zg
   extern __shared__ double fsm[];
   if (sc->status != 0) return;
   double *PL = fsm;
@@ -177,9 +181,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
   }
   const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
+  const int last = first + count;
   const auto load_nb = [&](int t) -> int {
-    const int b = t * TB + si;
-    return (t < t_end && b < count) ? nbr[4 * b + ss] : CUP2D_WALL;
+    const int b = first + t * TB + si;
+    return (t < t_end && b < last) ? nbr[4 * b + ss] : CUP2D_WALL;
   };
   // state of a tile: its blocks, this lane's neighbour slot, the ring list (in LDS) it was classified into
   struct Tile {
@@ -190,10 +195,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   // of the previous tile: call only when that one is dead)
   const auto classify = [&](int t, int nb) -> Tile {
     Tile T;
-    T.b0 = t * TB;
-    T.nvalid = min(TB, count - T.b0);
+    T.b0 = first + t * TB;
+    T.nvalid = min(TB, last - T.b0);
     T.nb = nb;
-    T.is_ring = si < T.nvalid && nb >= 0 && (nb < T.b0 || nb >= T.b0 + T.nvalid);
+    T.is_ring = si < T.nvalid && nb >= 0 && nb < nowned && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (dbg & 1) ? 0 : __popcll(rmask);  // dbg 1: timing experiment without the ring -- WRONG results
     T.npass = (T.nring + TB - 1) / TB;
@@ -305,9 +310,15 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
     if (si < nvalid && !T.is_ring) {
-      const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
+      if (T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
+        const double *g = zg + (size_t)T.nb * BC;
 #pragma unroll
-      for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = L.S[sblk * XS + edge_cell(sside, q)];
+        for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = g[edge_cell(ss ^ 1, q)];
+      } else {
+        const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
+#pragma unroll
+        for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = L.S[sblk * XS + edge_cell(sside, q)];
+      }
     }
     wave_lds_sync();
     // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products ----
@@ -331,8 +342,67 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     wave_lds_sync();  // the next tile overwrites S and GE
     T = N;
   }
-  fused_reduce_store<FWAVES, NDOT, MERGE>(acc, partials);
+  fused_reduce_store<FWAVES, NDOT, MERGE>(acc, partials + poff);
   if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, NDOT, 0, red, sc, MODE + 1, nullptr);
+}
+
+// ---- z on the faces other ranks need (multi-GPU) ---------------------------------------------------
+// For every (block, face) strip of the halo plan's send list: v of that block (the sweep's own formula),
+// z = P_inv v on the matrix cores, written to the block's place in zg.  The regular pack / exchange / unpack
+// of a width-1 scalar halo then delivers the face cells into the ghost blocks of the neighbour rank's zg,
+// where its k_fused picks up the edge it needs.  16 list entries per wave.
+template <int MODE>
+__global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double *__restrict__ Pinv,
+                                                       const int32_t *__restrict__ blocks, int n,
+                                                       double *__restrict__ zg, const KrylovScalars *__restrict__ sc) {
+  __shared__ double Ss[WPG][TB * XS];
+  if (sc->status != 0) return;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double *S = Ss[wave];
+  PinvFragments P;
+  P.load(Pinv, lane);
+  const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;
+  const double beta = sc->beta;
+  const bool restart = MODE == 0 && sc->restart_flag != 0;
+  const int njobs = (n + TB - 1) / TB;
+  for (int job = blockIdx.x * WPG + wave; job < njobs; job += gridDim.x * WPG) {
+#pragma unroll
+    for (int e = 0; e < TB; e++) {
+      const size_t o = (size_t)uniform(blocks[min(job * TB + e, n - 1)]) * BC + lane;
+      const double a = A.in0[o], b = A.in1[o];
+      double v;
+      if (MODE == 0) {
+        const double c = A.in2[o];
+        if (restart) {
+          v = c;
+        } else {
+          v = a + c1 * b;
+          v = v * beta;
+          v = v + c;
+        }
+      } else {
+        v = a + c1 * b;
+      }
+      S[e * XS + lane] = v;
+    }
+    wave_lds_sync();
+    double xa[16];
+    const int ablk = lane & 15, akk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
+    v4f64 acc[4];
+    precond_tile(xa, P, acc);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int e = job * TB + akk + 4 * v;
+      if (e < n) {
+        double *dst = zg + (size_t)blocks[e] * BC;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) dst[16 * nt + ablk] = acc[nt][v];
+      }
+    }
+    wave_lds_sync();
+  }
 }
 
 // ---- sweep E in the preconditioned space ---------------------------------------------------------
@@ -372,7 +442,7 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *__restrict__ y, double
   if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, 2, 1, red, sc, 3, host_status);
 }
 
-bool fused_supported(const cup2d_ctx *c) { return !c->mat.active && c->nghost == 0 && !c->exchange; }
+bool fused_supported(const cup2d_ctx *c) { return !c->mat.active && (c->nghost == 0 || c->exchange != nullptr); }
 
 static int ensure_fused_buffers(cup2d_ctx *c) {
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
@@ -385,7 +455,54 @@ static int ensure_fused_buffers(cup2d_ctx *c) {
   return CUP2D_OK;
 }
 
-int launch_init_residual(cup2d_ctx *c, const double *x, const double *b, int G);  // krylov.hip
+int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP);  // krylov.hip
+
+// one wave per 16-block tile; 8 waves = ONE 512-thread workgroup per CU (P_inv fragments + 8 staging tiles
+// are 134 KiB of its 160 KiB LDS)
+static int fused_grid(const cup2d_ctx *c, int count) {
+  const int ntiles = (count + TB - 1) / TB;
+  int g = (ntiles + FWAVES - 1) / FWAVES;
+  const int cap = c->num_cus > 0 ? c->num_cus : 256;
+  if (g > cap) g = cap;
+  if (g >= 8) g -= g % 8;
+  return g < 1 ? 1 : g;
+}
+
+// One fused sweep (MODE 0: A+B, MODE 1: C+D) over all owned blocks.  With ghost blocks: z on the faces the
+// other ranks need first (k_fused_edges -> zg = the otherwise unused z vector), its width-1 halo exchange
+// overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
+// main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
+template <int MODE>
+static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, bool merge, int dbg, int *GP) {
+  const int nb = c->nblocks;
+  const bool ghosts = c->nghost > 0 && c->exchange;
+  const int n_in = ghosts ? c->n_inner : nb, n_ha = nb - n_in;
+  const int G_in = n_in > 0 ? fused_grid(c, n_in) : 0, G_ha = n_ha > 0 ? fused_grid(c, n_ha) : 0;
+  double *zg = c->d_z;
+  if (ghosts && c->plan.nsend > 0) {
+    const int njobs = (c->plan.nsend + TB - 1) / TB;
+    int g = (njobs + WPG - 1) / WPG;
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(k_fused_edges<MODE>, dim3(g), dim3(WG), 0, c->stream, a, c->d_Pinv, c->plan.d_send_block,
+                       c->plan.nsend, zg, c->d_sc);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  if (ghosts) CUP2D_TRY(exchange_begin(c, zg, 1, 1));
+  const auto launch = [&](int first, int count, int poff, int g) {
+    if (merge)
+      hipLaunchKernelGGL((k_fused<MODE, true>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+    else
+      hipLaunchKernelGGL((k_fused<MODE, false>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+  };
+  if (n_in > 0) launch(0, n_in, 0, G_in);
+  if (ghosts) CUP2D_TRY(exchange_end(c, zg, 1, 1));
+  if (n_ha > 0) launch(n_in, n_ha, G_in, G_ha);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  *GP = G_in + G_ha;
+  return CUP2D_OK;
+}
 
 // b = TMP, x0 = PRES, result -> PRES (same contract as solve_impl)
 int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
@@ -404,17 +521,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   init.max_restarts = max_restarts; init.max_iter = max_iter;
   *c->h_sc = init;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->h_sc, sizeof init, hipMemcpyHostToDevice, c->stream));
-  const int G = grid_for(c, nb);
   int gridE = (int)((n / 2 + WG - 1) / WG);
   if (gridE > c->grid) gridE = c->grid;
-  // one wave per 16-block tile; 8 waves = ONE 512-thread workgroup per CU (P_inv fragments + 8 staging
-  // tiles are 134 KiB of its 160 KiB LDS)
-  const int ntiles = (nb + TB - 1) / TB;
-  int gridF = (ntiles + FWAVES - 1) / FWAVES;
-  const int capF = c->num_cus > 0 ? c->num_cus : 256;
-  if (gridF > capF) gridF = capF;
-  if (gridF >= 8) gridF -= gridF % 8;
-  if (gridF < 1) gridF = 1;
   static bool lds_set = false;
   if (!lds_set) {  // > 64 KiB of LDS is an opt-in per kernel
     const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, true>), reinterpret_cast<const void *>(&k_fused<0, false>),
@@ -423,14 +531,16 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     lds_set = true;
   }
-  const bool merge = c->finish_in_kernel && !c->allreduce;
+  // in-kernel finish: one launch per sweep and no all-reduce between the partials and the scalar update
+  const bool merge = c->finish_in_kernel && !c->allreduce && !(c->nghost > 0 && c->exchange);
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
+  int GP = 0;
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
-    CUP2D_TRY(launch_init_residual(c, x, b, G));
+    CUP2D_TRY(launch_init_residual(c, x, b, &GP));
   }
-  CUP2D_TRY(finish(c, G, 1, 1, 0, false));
+  CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
   // p, nu start at zero (cuda.cu:436-437); so does the accumulated correction
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
@@ -454,27 +564,15 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
-      if (merge)
-        hipLaunchKernelGGL((k_fused<0, true>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
-      else
-        hipLaunchKernelGGL((k_fused<0, false>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
+      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP));
     }
-    CUP2D_HIP_CHECK(hipGetLastError());
-    if (!merge) CUP2D_TRY(finish(c, gridF, 1, 0, 1, true));
+    if (!merge) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
-      if (merge)
-        hipLaunchKernelGGL((k_fused<1, true>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
-      else
-        hipLaunchKernelGGL((k_fused<1, false>), dim3(gridF), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                           c->d_partials, nb, c->d_red, c->d_ticket, dbg);
+      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP));
     }
-    CUP2D_HIP_CHECK(hipGetLastError());
-    if (!merge) CUP2D_TRY(finish(c, gridF, 2, 0, 2, true));
+    if (!merge) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_E);
       if (merge)

@@ -156,6 +156,12 @@ class Simulation:
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)),
                  "set_solver")
 
+    def last_solver(self):
+        """'fused' or 'sweeps': what the last poisson_solve ran"""
+        k = ctypes.c_int()
+        _l.check(self.L.cup2d_get_last_solver(self._ctx, ctypes.byref(k)), "get_last_solver")
+        return "fused" if k.value == _l.SOLVER_FUSED else "sweeps"
+
     def set_matrix_coo(self, row, col, val, halo=0):
         """Assembled Poisson operator (what main.cpp:7034-7112 pushes into LocalSpMatDnVec), local
         int32 indices in device block order; poisson_solve / apply_A use it instead of the stencil."""

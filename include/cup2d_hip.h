@@ -166,6 +166,8 @@ int cup2d_set_precond(cup2d_ctx *ctx, int kind);
  * CUP2D_FINISH_IN_KERNEL (0|1) override them at cup2d_create. */
 typedef enum { CUP2D_SOLVER_SWEEPS = 0, CUP2D_SOLVER_FUSED = 1 } cup2d_solver_kind;
 int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
+/* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
+int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 
 /* ---------------------------------------------------------------- assembled operator ----- */
 /* The seam the reference itself crosses (cuda.h LocalSpMatDnVec): instead of the 5-point stencil on

@@ -54,6 +54,7 @@ def test_fused_solver_vs_oracle(gpu_lib, oracle, order, nbx, nby, finish):
     with cup2d_amd.Simulation(nbx, nby, grid=g, h=1.0 / g.nx) as s:
         s.set_solver(fused=True, finish_in_kernel=finish)
         x, info = solve(s, b, tol=1e-9, max_restarts=100)
+        assert s.last_solver() == "fused"
         assert info["err"] <= 1e-9
         assert abs(info["err_init"] - io["err_init"]) < 1e-12
         assert abs(info["iters"] - io["iters"]) <= max(5, io["iters"] // 4), (info, io)

@@ -210,6 +210,15 @@ class Simulation:
         self.step_count += 1
         return dict(dt=dt.value, iters=it.value, err=e.value)
 
+    # ---- output ----------------------------------------------------------------------------------
+    def dump(self, path, time=None, level=0):
+        """the reference's dump() (main.cpp:3367-3466, called at 6601 with "vel.%08d"): velocity in the
+        XDMF2 + raw float32 layout post.py reads.  level: refinement level the grid stands for (h0 = h * 2^level)."""
+        from . import dump as _d
+        slab = np.empty((self.grid.nblocks, 128))
+        _l.check(self.L.cup2d_download_slab(self._ctx, _l.VEL, slab.ctypes.data_as(ctypes.c_void_p)), "download_slab")
+        _d.dump(path, self.time if time is None else time, self.grid, slab, self.h * (1 << level), level)
+
     # ---- instrumentation -----------------------------------------------------------------------
     def set_timing(self, on=True):
         """False/0 off, True/1 every launch, 2 sampled (see include/cup2d_hip.h)"""

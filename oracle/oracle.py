@@ -264,6 +264,18 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
     return out
 
 
+def ref_dump(vel, time=0.0):
+    """The reference's dump() (main.cpp:3367-3466) on a velocity field: returns the bytes of the three
+    files it writes, {'xyz': ..., 'attr': ..., 'xdmf2': ...}."""
+    vel = _c(vel)
+    n = vel.shape[0]
+    with tempfile.TemporaryDirectory() as d:
+        vel.tofile(os.path.join(d, "vel.in"))
+        _run_ref("dump", n, d, dt=float(time))
+        return {k: open(os.path.join(d, "vel." + ext), "rb").read()
+                for k, ext in (("xyz", "xyz.raw"), ("attr", "attr.raw"), ("xdmf2", "xdmf2"))}
+
+
 def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, hip=False, env=None):
     """BiCGSTAB (CPU port of cuda.cu) on the matrix the reference assembles; also returns A*x0.
     hip=True: the solve goes through libcup2d_spmat.so on the GPU instead (A*x0 is then None)."""

@@ -512,6 +512,7 @@ static void usage() {
           "              matrix; write x.out, Ax.out\n"
           "   run      : inject vel.in as IC, run the reference time loop for steps=N steps\n"
           "   bench    : time computeA<VectorLab>(KernelAdvectDiffuse) etc. reps=R\n"
+          "   dump     : read <dir>/vel.in; write vel.{xyz.raw,attr.raw,xdmf2} with the reference's dump() (time = dt key)\n"
           "  keys: nu dt cfl steps reps tol reltol restarts maxiter\n");
 }
 
@@ -689,6 +690,17 @@ int main(int argc, char **argv) {
         var.vel->infos[i].block[j] += var.tmpV->infos[i].block[j] * ih2;
     }
     dump_grid(dir + "/projected_vel.out", var.vel, 2);
+    MPI_Finalize();
+    return 0;
+  }
+
+  if (mode == "dump") {
+    /* the reference's own output writer (dump(), main.cpp:3367-3466) on an injected velocity field:
+     * <dir>/vel.xyz.raw, vel.attr.raw, vel.xdmf2 -- the byte-level golden of cup2d_amd/dump.py */
+    auto vel = read_file(dir + "/vel.in", 2 * N);
+    scatter(var.vel, 2, vel);
+    std::string path = dir + "/vel";
+    ::dump(dt > 0 ? dt : 0.0, var.vel->infos.size(), var.vel->infos.data(), const_cast<char *>(path.c_str()));
     MPI_Finalize();
     return 0;
   }

@@ -51,6 +51,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "run_n32_3steps.npz"), n=32, nu=1e-3, cfl=0.5, vel0=vel0, vel=R["vel"],
                         pres=R["pres"], dts=np.array([s["dt"] for s in R["steps"]]),
                         vel_adv=np.stack([s["vel_adv"] for s in R["steps"]]), b=np.stack([s["b"] for s in R["steps"]]))
+    # the reference's output writer dump() (main.cpp:3367-3466) on a 32^2 velocity field: raw bytes of the three files
+    vd = O.taylor_green(32, noise=0.1, seed=5)
+    D = O.ref_dump(vd, time=0.375)
+    np.savez_compressed(os.path.join(HERE, "dump_n32.npz"), vel=vd, time=0.375, xyz=np.frombuffer(D["xyz"], dtype=np.uint8),
+                        attr=np.frombuffer(D["attr"], dtype=np.uint8), xdmf2=np.frombuffer(D["xdmf2"], dtype=np.uint8))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -60,6 +60,9 @@ def main():
                     help="organisation of a BiCGSTAB iteration (include/cup2d_hip.h cup2d_solver_kind)")
     ap.add_argument("--finish", default=DEFAULT_FINISH, choices=["launch", "kernel"],
                     help="reduction finish + scalar update: own launch, or by the last workgroup of the sweep")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the domain-decomposed code path (RCCL callbacks, comm stream) even with one rank: a smoke "
+                         "test of the N > 1 path on a single-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
@@ -79,9 +82,11 @@ def main():
     torch.cuda.set_device(local_rank)
     n = args.n
 
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         from cup2d_amd.distributed import DistributedSimulation, cartesian_dims
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # --force-dist outside torch.distributed.run
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         px, py = cartesian_dims(world)
         cx, cy = rank % px, rank // px

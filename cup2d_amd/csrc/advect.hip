@@ -180,14 +180,33 @@ __global__ __launch_bounds__(WG) void k_advect_diffuse(const double2 *__restrict
     wave_lds_sync();
     // ---- upwind differences (derivative(), main.cpp:202-208) ----
     // U > 0: plus(c) - plus(c-1)   else: minus(c+1) - minus(c)
-    const double nxu = up ? L.Fx[0][iy * FROW + ix] : L.Gx[0][iy * FROW + ix + 1];
-    const double nxv = up ? L.Fx[1][iy * FROW + ix] : L.Gx[1][iy * FROW + ix + 1];
-    const double nyu = vp ? L.Fy[0][iy * BS + ix] : L.Gy[0][(iy + 1) * BS + ix];
-    const double nyv = vp ? L.Fy[1][iy * BS + ix] : L.Gy[1][(iy + 1) * BS + ix];
-    const double dudx = up ? Pxu - nxu : nxu - Mxu;
-    const double dvdx = up ? Pxv - nxv : nxv - Mxv;
-    const double dudy = vp ? Pyu - nyu : nyu - Myu;
-    const double dvdy = vp ? Pyv - nyv : nyv - Myv;
+    // a block whose lanes all upwind to the same side (the common case) takes a wave-uniform branch: no
+    // per-lane selects; the values are the same either way
+    double dudx, dvdx, dudy, dvdy;
+    if (!nMx) {
+      dudx = Pxu - L.Fx[0][iy * FROW + ix];
+      dvdx = Pxv - L.Fx[1][iy * FROW + ix];
+    } else if (!nPx) {
+      dudx = L.Gx[0][iy * FROW + ix + 1] - Mxu;
+      dvdx = L.Gx[1][iy * FROW + ix + 1] - Mxv;
+    } else {
+      const double nxu = up ? L.Fx[0][iy * FROW + ix] : L.Gx[0][iy * FROW + ix + 1];
+      const double nxv = up ? L.Fx[1][iy * FROW + ix] : L.Gx[1][iy * FROW + ix + 1];
+      dudx = up ? Pxu - nxu : nxu - Mxu;
+      dvdx = up ? Pxv - nxv : nxv - Mxv;
+    }
+    if (!nMy) {
+      dudy = Pyu - L.Fy[0][iy * BS + ix];
+      dvdy = Pyv - L.Fy[1][iy * BS + ix];
+    } else if (!nPy) {
+      dudy = L.Gy[0][(iy + 1) * BS + ix] - Myu;
+      dvdy = L.Gy[1][(iy + 1) * BS + ix] - Myv;
+    } else {
+      const double nyu = vp ? L.Fy[0][iy * BS + ix] : L.Gy[0][(iy + 1) * BS + ix];
+      const double nyv = vp ? L.Fy[1][iy * BS + ix] : L.Gy[1][(iy + 1) * BS + ix];
+      dudy = vp ? Pyu - nyu : nyu - Myu;
+      dvdy = vp ? Pyv - nyv : nyv - Myv;
+    }
     // main.cpp:5497-5502, same operand order
     double2 r;
     r.x = afac * (u * dudx + v * dudy) + dfac * (xs[3].x + xs[1].x + ys[3].x + ys[1].x - 4 * u);

@@ -55,6 +55,7 @@ struct KrylovScalars {
   int status;        // 0 running, 1 converged, 2 restart limit, 3 iteration cap
   int restart_flag;  // next p-update must do rhat = r, p = r (cuda.cu:461-476)
   int x_is_best;     // the iterate held in x is the best so far (cuda.cu:535-538)
+  int ycur, ybest;   // fused solver: which of its three y buffers holds the current / the best iterate
   int pad;
 };
 

@@ -24,6 +24,12 @@ static __device__ void begin_iteration(KrylovScalars *sc) {
     sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
   }
 }
+// The fused solver keeps the accumulated correction y in THREE buffers and never copies the best iterate
+// (cuda.cu:535-538 copies x to x_opt): sweep E reads buffer ycur and writes the buffer that is neither ycur
+// nor ybest; stage 3 below then rotates.  (The five-sweep solver updates x in place and copies.)
+static __device__ __forceinline__ int y_out_buffer(int cur, int best) {
+  return (cur != 0 && best != 0) ? 0 : ((cur != 1 && best != 1) ? 1 : 2);
+}
 // STAGE 0: after k_init_residual  red = {r.r, -, max|r|}
 // STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
 // STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
@@ -33,6 +39,7 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
   case 0:
     sc->err = sc->err_init = sc->err_opt = red[2];
     sc->x_is_best = 1;
+    sc->ycur = sc->ybest = 0;
     sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
     begin_iteration(sc);
     break;
@@ -45,9 +52,11 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
   case 3:
     sc->iter++;
     sc->err = red[2];
+    sc->ycur = y_out_buffer(sc->ycur, sc->ybest);  // where sweep E put the new iterate
     if (sc->err < sc->err_opt) {
       sc->err_opt = sc->err;
       sc->x_is_best = 1;
+      sc->ybest = sc->ycur;
       if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
     } else {
       sc->x_is_best = 0;

@@ -406,27 +406,30 @@ __global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double
 }
 
 // ---- sweep E in the preconditioned space ---------------------------------------------------------
-// y += alpha p + omega s ; r = s - omega t ; partial(rhat.r, r.r), max|r|   (cuda.cu:498, 520-525, 440-442
-// with x = x0 + P_inv y); best-iterate copy deferred like k_sweepE's (cuda.cu:535-538)
+// y' = y + alpha p + omega s ; r = s - omega t ; partial(rhat.r, r.r), max|r|   (cuda.cu:498, 520-525, 440-442
+// with x = x0 + P_inv y).  y lives in three buffers: y' goes to the one that holds neither y nor the best
+// iterate so far, so the reference's copy of the best iterate (cuda.cu:535-538) is a change of index
+// (krylov_common.h y_out_buffer) and the sweep moves a flat 56 B/cell.
 template <bool MERGE>
-__global__ __launch_bounds__(WG) void k_sweepE_y(double2 *__restrict__ y, double2 *__restrict__ yopt,
-                                                 const double2 *__restrict__ p, double2 *__restrict__ r,
-                                                 const double2 *__restrict__ s, const double2 *__restrict__ t,
-                                                 const double2 *__restrict__ rhat, KrylovScalars *sc, double *partials,
-                                                 size_t n2, double *red, unsigned *ticket, int *host_status) {
+__global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, double2 *y2, const double2 *__restrict__ p,
+                                                 double2 *__restrict__ r, const double2 *__restrict__ s,
+                                                 const double2 *__restrict__ t, const double2 *__restrict__ rhat,
+                                                 KrylovScalars *sc, double *partials, size_t n2, double *red,
+                                                 unsigned *ticket, int *host_status) {
   if (sc->status != 0) return;
   const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega;
-  const int save = sc->x_is_best;
+  const int cur = sc->ycur, out = y_out_buffer(cur, sc->ybest);
+  const double2 *__restrict__ yin = cur == 0 ? y0 : (cur == 1 ? y1 : y2);
+  double2 *__restrict__ yout = out == 0 ? y0 : (out == 1 ? y1 : y2);
   double sm[2] = {0.0, 0.0}, m[1] = {0.0};
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
-    double2 yv = y[i];
-    if (save) yopt[i] = yv;
+    double2 yv = yin[i];
     const double2 pv = p[i], sv = s[i], tv = t[i], hv = rhat[i];
     yv.x = yv.x + alpha * pv.x;
     yv.y = yv.y + alpha * pv.y;
     yv.x = yv.x + omega * sv.x;
     yv.y = yv.y + omega * sv.y;
-    y[i] = yv;
+    yout[i] = yv;
     double2 rv;
     rv.x = sv.x + momega * tv.x;
     rv.y = sv.y + momega * tv.y;
@@ -577,12 +580,12 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       ProfScope prof(c, CUP2D_T_SWEEP_E);
       if (merge)
         hipLaunchKernelGGL(k_sweepE_y<true>, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
-                           (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
+                           (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
                            (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
                            &c->h_status[slot]);
       else
         hipLaunchKernelGGL(k_sweepE_y<false>, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
-                           (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
+                           (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
                            (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
                            &c->h_status[slot]);
     }
@@ -594,7 +597,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
-  const double *ybest = c->h_sc->x_is_best ? c->d_y : c->d_yopt;
+  const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
+  const double *ybest = ybuf[c->h_sc->ybest];
   CUP2D_TRY(launch_precond(c, ybest, c->d_s, 0, nb));
   CUP2D_TRY(launch_axpy_field(c, x, c->d_s, 1.0, n));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));

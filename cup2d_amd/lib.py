@@ -42,7 +42,8 @@ class Cup2dError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libcup2d_hip.so")
+    # CUP2D_LIB: another build of the same library (A/B timing of kernel variants on one box)
+    return os.environ.get("CUP2D_LIB") or os.path.join(_HERE, "libcup2d_hip.so")
 
 
 def load_library():

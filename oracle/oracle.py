@@ -264,6 +264,30 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
     return out
 
 
+def ref_run_amr(level_start, level_max, steps, rtol, ctol, nu=1e-3, cfl=0.5, max_iter=None, hip=False, env=None):
+    """The reference's time loop with refinement on (ref_harness 'amr': config 5 through the reference's own
+    adapt(), coarse-fine labs, flux correction and matrix assembly) from an analytic vortex pair.
+    Returns dict(blocks=(nb,3) int [level, i, j], vel=(nb,64,2), pres=(nb,64), steps=[...]) sorted by
+    (level, j, i).  hip=True: every linear solve goes through libcup2d_spmat.so on the GPU."""
+    with tempfile.TemporaryDirectory() as d:
+        kw = dict(levelmax=int(level_max), rtol=float(rtol), ctol=float(ctol), steps=int(steps), nu=float(nu), cfl=float(cfl))
+        if max_iter is not None:
+            kw["maxiter"] = int(max_iter)
+        cmd_n = 8 << int(level_start)
+        _run_ref("amr", cmd_n, d, _hip=hip, _env=env, **kw)
+        a = np.fromfile(os.path.join(d, "blocks.final")).reshape(-1, 3 + 128 + 64)
+        meta = open(os.path.join(d, "meta.txt")).read().strip().split("\n")
+    key = a[:, 0] * 1e12 + a[:, 2] * 1e6 + a[:, 1]
+    a = a[np.argsort(key)]
+    out = dict(blocks=a[:, :3].astype(np.int64), vel=a[:, 3:131].reshape(-1, 64, 2), pres=a[:, 131:], steps=[])
+    for line in meta:
+        t = line.split()
+        if t[0] == "step":
+            out["steps"].append(dict(blocks=int(t[3]), lmin=int(t[5]), lmax=int(t[6]), dt=float(t[8]), update=int(t[10]),
+                                     prev_iters=int(t[12])))
+    return out
+
+
 def ref_dump(vel, time=0.0):
     """The reference's dump() (main.cpp:3367-3466) on a velocity field: returns the bytes of the three
     files it writes, {'xyz': ..., 'attr': ..., 'xdmf2': ...}."""

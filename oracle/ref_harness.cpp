@@ -474,13 +474,13 @@ static void global_to_blockvec(const std::vector<double> &glob, std::vector<doub
 }
 
 static int run_reference_main(int levelStart, double nu, double cfl, double tend,
-                              double ptol, double ptolrel, int prestarts) {
+                              double ptol, double ptolrel, int prestarts, int levelMax = -1, int adaptSteps = 1000000) {
   /* uniform n x n recipe: one base block, all blocks at
    * levelStart, refinement and compression disabled */
   std::vector<std::string> a = {"ref_harness",
       "-bpdx", "1", "-bpdy", "1",
-      "-levelMax", std::to_string(levelStart + 1), "-levelStart", std::to_string(levelStart),
-      "-Rtol", "1e30", "-Ctol", "0", "-AdaptSteps", "1000000", "-extent", "1",
+      "-levelMax", std::to_string(levelMax > 0 ? levelMax : levelStart + 1), "-levelStart", std::to_string(levelStart),
+      "-Rtol", "1e30", "-Ctol", "0", "-AdaptSteps", std::to_string(adaptSteps), "-extent", "1",
       "-CFL", std::to_string(cfl), "-tend", std::to_string(tend), "-lambda", "1e7",
       "-nu", std::to_string(nu), "-poissonTol", std::to_string(ptol),
       "-poissonTolRel", std::to_string(ptolrel),
@@ -512,6 +512,8 @@ static void usage() {
           "              matrix; write x.out, Ax.out\n"
           "   run      : inject vel.in as IC, run the reference time loop for steps=N steps\n"
           "   bench    : time computeA<VectorLab>(KernelAdvectDiffuse) etc. reps=R\n"
+          "   amr      : the reference time loop with refinement on (levelmax= rtol= ctol= steps=), analytic vortex-pair IC;\n"
+          "              writes blocks.final (level, i, j, vel, pres per block) and meta.txt\n"
           "   dump     : read <dir>/vel.in; write vel.{xyz.raw,attr.raw,xdmf2} with the reference's dump() (time = dt key)\n"
           "  keys: nu dt cfl steps reps tol reltol restarts maxiter\n");
 }
@@ -522,7 +524,8 @@ int main(int argc, char **argv) {
   const int levelStart = atoi(argv[2]);
   const std::string dir = argv[3];
   double nu = 1e-3, dt = -1, cfl = 0.5, tol = 0, reltol = 0;
-  int steps = 1, reps = 10, restarts = 100, maxiter = -1, dump = 1;
+  int steps = 1, reps = 10, restarts = 100, maxiter = -1, dump = 1, levelmax = -1;
+  double rtol_amr = 1e30, ctol_amr = 0;
   for (int i = 4; i < argc; i++) {
     std::string kv = argv[i];
     auto eq = kv.find('=');
@@ -538,6 +541,9 @@ int main(int argc, char **argv) {
     else if (k == "restarts") restarts = atoi(v.c_str());
     else if (k == "maxiter") maxiter = atoi(v.c_str());
     else if (k == "dump") dump = atoi(v.c_str());
+    else if (k == "levelmax") levelmax = atoi(v.c_str());
+    else if (k == "rtol") rtol_amr = atof(v.c_str());
+    else if (k == "ctol") ctol_amr = atof(v.c_str());
     else { usage(); return 2; }
   }
   g_n = _BS_ << levelStart;
@@ -546,6 +552,63 @@ int main(int argc, char **argv) {
 #ifdef HARNESS_HIP_SPMAT
   if (maxiter >= 0) setenv("CUP2D_SPMAT_MAX_ITER", std::to_string(maxiter).c_str(), 1);
 #endif
+
+  if (mode == "amr") {
+    /* Config 5 through the reference's own machinery: the time loop of main.cpp with refinement ENABLED
+     * (adapt(), coarse-fine labs, flux correction, coarse-fine matrix rows: all the reference's code).  The
+     * grid starts uniform at levelStart; at the first solve an analytic vortex pair is injected and the
+     * refinement / compression thresholds are switched on, so the following steps regrid (one level per
+     * adapt() call, main.cpp:6603).  Output: blocks.final = per block (level, i, j, 64 x (u, v), 64 x p),
+     * meta.txt = per step (blocks, dt, previous iterations).  With ref_harness_hip every linear solve
+     * (solveWithUpdate after each regrid) runs in libcup2d_spmat.so on the GPU. */
+    FILE *meta = fopen((dir + "/meta.txt").c_str(), "w");
+    int solve_count = 0;
+    auto inject = [&]() {
+      for (auto &I : var.vel->infos)
+        for (int iy = 0; iy < _BS_; iy++)
+          for (int ix = 0; ix < _BS_; ix++) {
+            const double x = I.origin[0] + (ix + 0.5) * I.h, y = I.origin[1] + (iy + 0.5) * I.h;
+            double u = 0, v = 0;
+            const double cx[2] = {0.35, 0.65}, cy[2] = {0.5, 0.5}, gam[2] = {1.0, -1.0};
+            for (int k = 0; k < 2; k++) {
+              const double dx = x - cx[k], dy = y - cy[k], r2 = dx * dx + dy * dy;
+              const double f = gam[k] * std::exp(-r2 / (0.06 * 0.06)) / 0.06;
+              u += -dy * f;
+              v += dx * f;
+            }
+            I.block[2 * (iy * _BS_ + ix) + 0] = u;
+            I.block[2 * (iy * _BS_ + ix) + 1] = v;
+          }
+    };
+    hooks.on_solve = [&](LocalSpMatDnVec *, bool withUpdate, double, double, int) {
+      if (solve_count == 0) {
+        inject();
+        sim.Rtol = rtol_amr;
+        sim.Ctol = ctol_amr;
+      }
+      int lmin = 99, lmax = -1;
+      for (auto &I : var.vel->infos) { lmin = std::min(lmin, I.level); lmax = std::max(lmax, I.level); }
+      fprintf(meta, "step %d blocks %zu levels %d %d dt %.17g update %d prev_iters %d prev_err %.17g\n", solve_count,
+              var.vel->infos.size(), lmin, lmax, sim.dt, (int)withUpdate, hooks.last_iters, hooks.last_error);
+      if (solve_count == steps) sim.endTime = 1e-300;
+      solve_count++;
+    };
+    try {
+      run_reference_main(levelStart, nu, cfl, 1e300, tol, reltol, restarts, levelmax, 1);
+    } catch (EscapeFromMain &) {
+    }
+    fprintf(meta, "final iters %d err %.17g steps %d\n", hooks.last_iters, hooks.last_error, sim.step);
+    fclose(meta);
+    std::vector<double> out;
+    for (size_t i = 0; i < var.vel->infos.size(); i++) {
+      const Info &I = var.vel->infos[i];
+      out.push_back(I.level); out.push_back(I.index[0]); out.push_back(I.index[1]);
+      for (int j = 0; j < 2 * _BS_ * _BS_; j++) out.push_back(I.block[j]);
+      for (int j = 0; j < _BS_ * _BS_; j++) out.push_back(var.pres->infos[i].block[j]);
+    }
+    write_file(dir + "/blocks.final", out.data(), out.size());
+    return 0;
+  }
 
   if (mode == "run") {
     /* The reference's own time loop.  Step 0 runs on all-zero fields; the IC is

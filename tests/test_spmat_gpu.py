@@ -45,6 +45,24 @@ def test_reference_assembled_system_solved_by_hip_spmat(gpu_lib, oracle, force_m
     assert np.abs(x - G["x"]).max() < 1e-8
 
 
+def test_amr_time_loop_with_hip_spmat(gpu_lib, oracle):
+    """BASELINE.json configs[4] (block-AMR) through seam B1: the reference's own time loop with refinement ON --
+    adapt(), coarse-fine labs, flux correction and the coarse-fine matrix rows are the reference's code -- with
+    every linear solve (solveWithUpdate after each regrid: 16 -> 40 -> 76 blocks on levels 2..4) served by
+    libcup2d_spmat.so's general sliced-ELL operator on the GPU, against the same run with the CPU restatement
+    of cuda.cu behind the seam.  Same regrid history, same fields to the solve tolerance."""
+    assert oracle.have_reference_hip(), "oracle/_ref/ref_harness_hip was not shipped"
+    kw = dict(level_start=2, level_max=5, steps=8, rtol=2.0, ctol=0.5, nu=1e-3, max_iter=200)
+    C = oracle.ref_run_amr(**kw)
+    G = oracle.ref_run_amr(hip=True, **kw)
+    assert [s["blocks"] for s in G["steps"]] == [s["blocks"] for s in C["steps"]]
+    assert max(s["lmax"] for s in C["steps"]) - min(s["lmin"] for s in C["steps"]) >= 2  # three levels
+    assert np.array_equal(G["blocks"], C["blocks"])
+    assert np.allclose([s["dt"] for s in G["steps"]], [s["dt"] for s in C["steps"]], rtol=1e-9, atol=0)
+    assert np.abs(G["vel"] - C["vel"]).max() < 1e-8 * max(1.0, np.abs(C["vel"]).max())
+    assert np.abs(G["pres"] - C["pres"]).max() < 1e-7 * max(1.0, np.abs(C["pres"]).max())
+
+
 @pytest.mark.parametrize("order,nbx,nby", [("hilbert", 8, 8), ("rowmajor", 5, 3)])
 def test_assembled_operator_equals_stencil(gpu_lib, oracle, order, nbx, nby):
     import cup2d_amd

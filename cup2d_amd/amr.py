@@ -1,0 +1,125 @@
+"""Block-AMR grids on the host (BASELINE.json configs[4]): which leaf blocks exist on which level and what lies
+across every side of each -- the tables of cup2d_set_amr (include/cup2d_hip.h).  Replaces, for this purpose, the
+reference's tree / Info::Znei / Zchild / Zparent lookups (main.cpp:672-738, 2197-2198) with dense arrays built once
+per regrid.  Fields of an adapted grid are per-block arrays [nblocks][64 * dim] in the order of `blocks`."""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+
+BS = 8
+
+
+class AmrBlockGrid:
+    """blocks: (nb, 3) int array of leaf blocks (level, i, j) of a bpdx x bpdy base grid (level-0 blocks), 2:1
+    balanced (the reference's adapt() guarantees it, main.cpp:4734-4861).  h0 = extent / max(bpdx, bpdy) / 8
+    (main.cpp:6338)."""
+
+    def __init__(self, blocks, bpdx=1, bpdy=1, extent=1.0):
+        self.blocks = np.ascontiguousarray(blocks, dtype=np.int64).reshape(-1, 3)
+        self.nblocks = len(self.blocks)
+        self.bpdx, self.bpdy = int(bpdx), int(bpdy)
+        self.h0 = float(extent) / max(self.bpdx, self.bpdy) / BS
+        index = {tuple(int(v) for v in b): k for k, b in enumerate(self.blocks)}
+        nb = self.nblocks
+        self.level = np.ascontiguousarray(self.blocks[:, 0], dtype=np.int32)
+        self.kind = np.zeros((nb, 4), dtype=np.int32)
+        self.nbr2 = -np.ones((nb, 4, 2), dtype=np.int32)
+        self.half = np.zeros((nb, 4), dtype=np.int32)
+        for b, (l, i, j) in enumerate(self.blocks):
+            l, i, j = int(l), int(i), int(j)
+            for s, (di, dj) in enumerate(((-1, 0), (1, 0), (0, -1), (0, 1))):
+                ni, nj = i + di, j + dj
+                if ni < 0 or nj < 0 or ni >= self.bpdx << l or nj >= self.bpdy << l:
+                    self.kind[b, s] = _l.AMR_WALL
+                elif (l, ni, nj) in index:
+                    self.kind[b, s] = _l.AMR_SAME
+                    self.nbr2[b, s, 0] = index[(l, ni, nj)]
+                elif l > 0 and (l - 1, ni // 2, nj // 2) in index:
+                    self.kind[b, s] = _l.AMR_COARSER
+                    self.nbr2[b, s, 0] = index[(l - 1, ni // 2, nj // 2)]
+                    self.half[b, s] = (j % 2) if s < 2 else (i % 2)
+                else:
+                    # the two children of (l, ni, nj) that touch this side, ordered along the face
+                    kids = [(l + 1, 2 * ni + (1 if s == 0 else 0 if s == 1 else a), 2 * nj + (a if s < 2 else 1 if s == 2 else 0))
+                            for a in (0, 1)]
+                    if any(k not in index for k in kids):
+                        raise ValueError("block %s side %d: neither a leaf, a coarser leaf nor two finer leaves across "
+                                         "(grid not 2:1 balanced?)" % ((l, i, j), s))
+                    self.kind[b, s] = _l.AMR_FINER
+                    self.nbr2[b, s] = [index[k] for k in kids]
+        # same-level neighbour table for cup2d_create (sides that are not same-level: wall)
+        self.nbr = np.where(self.kind == _l.AMR_SAME, self.nbr2[:, :, 0], -1).astype(np.int32)
+        self.nghost, self.n_inner = 0, nb
+
+    def h(self, level):
+        return self.h0 / (1 << int(level))
+
+    def cell_centres(self):
+        """x, y of every cell, (nb, 64) each, as the reference places them (origin main.cpp:695-696)"""
+        l = self.blocks[:, 0]
+        h = self.h0 / (1 << l)
+        ox = self.blocks[:, 1] * BS * self.h0 / (1 << l)
+        oy = self.blocks[:, 2] * BS * self.h0 / (1 << l)
+        ix = np.tile(np.arange(BS), BS)
+        iy = np.repeat(np.arange(BS), BS)
+        return ox[:, None] + (ix[None, :] + 0.5) * h[:, None], oy[:, None] + (iy[None, :] + 0.5) * h[:, None]
+
+
+class AmrSimulation:
+    """Device-resident fields on an adapted grid + the halo-1 block operators in their AMR form.  Fields are set and
+    read as per-block arrays (nb, 64) / (nb, 64, 2)."""
+
+    def __init__(self, grid, nu=1e-3, cfl=0.5, device=0):
+        self.L = _l.load_library()
+        self.grid, self.nu, self.cfl = grid, float(nu), float(cfl)
+        self._ctx = ctypes.c_void_p()
+        vp = ctypes.c_void_p
+        _l.check(self.L.cup2d_create(ctypes.byref(self._ctx), grid.nblocks, 0, grid.nblocks,
+                                     np.ascontiguousarray(grid.nbr).ctypes.data_as(vp), grid.h0, int(device)), "cup2d_create")
+        self._tables = [np.ascontiguousarray(a, dtype=np.int32) for a in (grid.level, grid.kind, grid.nbr2, grid.half)]
+        _l.check(self.L.cup2d_set_amr(self._ctx, grid.h0, *[a.ctypes.data_as(vp) for a in self._tables]), "cup2d_set_amr")
+
+    def close(self):
+        if self._ctx:
+            self.L.cup2d_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_field(self, field, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(self.grid.nblocks, 64 * _l.FIELD_DIM[field])
+        _l.check(self.L.cup2d_upload_slab(self._ctx, field, a.ctypes.data_as(ctypes.c_void_p)), "upload_slab")
+
+    def get_field(self, field):
+        dim = _l.FIELD_DIM[field]
+        a = np.empty((self.grid.nblocks, 64 * dim))
+        _l.check(self.L.cup2d_download_slab(self._ctx, field, a.ctypes.data_as(ctypes.c_void_p)), "download_slab")
+        return a.reshape(self.grid.nblocks, 64, 2) if dim == 2 else a
+
+    def laplacian_sub(self):
+        """prepare0 / computeA<ScalarLab>(pressure_rhs1(), var.pold, 1) / fillcases (main.cpp:7022-7027)"""
+        _l.check(self.L.cup2d_laplacian_sub(self._ctx, _l.BLOCKS_ALL), "laplacian_sub")
+
+    def vorticity(self):
+        _l.check(self.L.cup2d_vorticity(self._ctx, _l.BLOCKS_ALL), "vorticity")
+
+    def pressure_rhs(self, dt):
+        """computeB<pressure_rhs,..> + fillcases (main.cpp:7007-7013): tmp from vel, tmpV (= udef), chi"""
+        _l.check(self.L.cup2d_pressure_rhs(self._ctx, float(dt), 1, _l.BLOCKS_ALL), "pressure_rhs")
+
+    def pressure_correction(self, dt):
+        _l.check(self.L.cup2d_pressure_correction(self._ctx, float(dt), _l.BLOCKS_ALL), "pressure_correction")
+
+    def apply_A(self, dst, src):
+        _l.check(self.L.cup2d_apply_A(self._ctx, dst, src), "apply_A")
+
+    def compute_dt(self):
+        v = ctypes.c_double()
+        _l.check(self.L.cup2d_compute_dt(self._ctx, self.nu, self.cfl, ctypes.byref(v)), "compute_dt")
+        return v.value

@@ -1,0 +1,282 @@
+// amr.hip -- the halo-1 block operators on a block-AMR grid (BASELINE.json configs[4]; SURVEY.md rows a5, a9,
+// a10, a11, a19 with a20's flux correction): ghost cells across coarse-fine faces and the conservative
+// correction of the coarse side.
+//
+// Reference: BlockLab::load / post_load (main.cpp:2270-2687, 2689-2933) for Stencil{-1,-1,2,2, tensorial =
+// false} (use_averages is false for it, main.cpp:2265-2267), LI (2203-2210), the wall conditions 3131-3255, the
+// face tails of the functors (6140-6206, 6231-6285) and prepare0 / fillcases / fillcase0 / fillcase1
+// (1564-1849).  What lies across a block's side is one of
+//   wall     ghost = edge cell (vector: wall-normal component negated)
+//   same     the neighbour's edge cell
+//   finer    mean of the 2x2 fine cells under the ghost cell -- INCLUDING the reference's unrolled W/E branch
+//            (main.cpp:2476-2534), whose first row pairs fine rows y and y+2: parity is with the reference as it is
+//   coarser  quadratic interpolation ALONG the face through the coarse column (centred, one-sided at the ends of
+//            the block's span, main.cpp:2797-2846), then LI() ACROSS the face with the two fine interior cells
+// and a functor records, on every side that is not wall/same, the flux it saw; fillcases then gives the edge
+// cell of a COARSE block  + (its own flux) + (sum of the two fine fluxes) per fine pair, W/E faces before S/N.
+// Every expression keeps the reference's operand order (the translation unit is built with -ffp-contract=off):
+// results are bit-identical to the reference's CPU functors (tests/test_amr_gpu.py).
+//
+// One wave per block as everywhere else; the 32 ghost cells of the cross are computed by lanes 0..31.  The
+// irregular sides gather from other blocks through global memory -- this is the first, parity-first version of
+// the AMR path; its tuning follows the uniform path's.
+#include "block.h"
+
+namespace cup2d {
+
+enum { AMR_WALL = 0, AMR_SAME = 1, AMR_COARSE = 2, AMR_FINE = 3 };
+
+// main.cpp:2203-2210
+static __device__ __forceinline__ double amr_LI(double a, double b, double c) {
+  const double kappa = ((4.0 / 15.0) * a + (6.0 / 15.0) * c) + (-10.0 / 15.0) * b;
+  const double lambda = (b - c) - kappa;
+  return (4.0 * kappa + 2.0 * lambda) + c;
+}
+
+// ghost value at position q of side s of a block; get(block, cell) reads one component of the field,
+// e1 / e2 = the block's own edge cell and the next cell inwards at that position
+template <class Get>
+static __device__ __forceinline__ double amr_ghost(Get get, int kind, int n0, int n1, int half, int s, int q, double e1,
+                                                   double e2, double wall_sign) {
+  if (kind == AMR_WALL) return wall_sign * e1;
+  if (kind == AMR_SAME) {
+    const int cell = s == 0 ? q * BS + 7 : s == 1 ? q * BS : s == 2 ? 7 * BS + q : q;
+    return get(n0, cell);
+  }
+  if (kind == AMR_FINE) {
+    const int a = q >> 2, ee = q & 3;
+    const int fb = a ? n1 : n0;
+    if (s >= 2) {  // rows y, y+1 of the fine block, columns 2ee, 2ee+1 (main.cpp:2548-2564)
+      const int r0 = s == 2 ? 6 : 0;
+      return (get(fb, r0 * BS + 2 * ee) + get(fb, (r0 + 1) * BS + 2 * ee) + get(fb, r0 * BS + 2 * ee + 1) +
+              get(fb, (r0 + 1) * BS + 2 * ee + 1)) / 4;
+    }
+    const int x = s == 0 ? 6 : 0;
+    const int y0 = 2 * ee, y1 = ee == 0 ? 2 : 2 * ee + 1;  // ee == 0: rows 0 and 2 (main.cpp:2528-2529)
+    return (get(fb, y0 * BS + x) + get(fb, y1 * BS + x) + get(fb, y0 * BS + x + 1) + get(fb, y1 * BS + x + 1)) / 4;
+  }
+  // coarser neighbour: its four cells along the face that span this block
+  double cc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int j = 4 * half + k;
+    cc[k] = get(n0, s == 0 ? j * BS + 7 : s == 1 ? j * BS : s == 2 ? 7 * BS + j : j);
+  }
+  const int qq = q >> 1;
+  const double c1 = cc[qq];
+  double d1, d2;
+  if (qq == 0) {
+    d1 = (-0.5 * cc[2] - 1.5 * cc[0]) + 2.0 * cc[1];
+    d2 = (cc[2] + cc[0]) - 2.0 * cc[1];
+  } else if (qq == 3) {
+    d1 = (0.5 * cc[1] + 1.5 * cc[3]) - 2.0 * cc[2];
+    d2 = (cc[1] + cc[3]) - 2.0 * cc[2];
+  } else {
+    d1 = 0.5 * (cc[qq + 1] - cc[qq - 1]);
+    d2 = (cc[qq + 1] + cc[qq - 1]) - 2.0 * cc[qq];
+  }
+  const double dy = -0.25;
+  const double t = (q & 1) ? c1 - dy * d1 + (0.5 * dy * dy) * d2 : c1 + dy * d1 + (0.5 * dy * dy) * d2;
+  return amr_LI(t, e1, e2);
+}
+
+struct AmrDev {
+  const int32_t *kind, *nbr2, *half, *level;
+  double *faces;
+  double h0;
+};
+
+// lab index of ghost (side, q), of the edge cell and of the next cell inwards
+static __device__ __forceinline__ void amr_slot(int s, int q, int &gi, int &e1, int &e2) {
+  if (s == 0) { gi = (q + 1) * LAB1; e1 = gi + 1; e2 = gi + 2; }
+  else if (s == 1) { gi = (q + 1) * LAB1 + 9; e1 = gi - 1; e2 = gi - 2; }
+  else if (s == 2) { gi = q + 1; e1 = gi + LAB1; e2 = gi + 2 * LAB1; }
+  else { gi = 9 * LAB1 + q + 1; e1 = gi - LAB1; e2 = gi - 2 * LAB1; }
+}
+
+// OP 0: y -= Lap5(x)      pressure_rhs1, faces = ghost - edge                         (main.cpp:6209-6285)
+// OP 1: y  = Lap5(x)      the operator alone (no face arrays)
+// OP 2: tmpV = pFac grad x  pressureCorrectionKernel; its face arrays are never consumed by the reference's
+//                           fillcases (main.cpp:7174-7179 passes tmp's buffers), so none are written (6021-6043)
+template <int OP>
+__global__ __launch_bounds__(WG) void k_amr_scalar(const double *__restrict__ x, double *__restrict__ y, AmrDev T,
+                                                   int nblocks, double dt) {
+  __shared__ double labs[WPG][LAB1 * LAB1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *lab = labs[wave];
+  const int ix = lane & 7, iy = lane >> 3;
+  const int c0 = (iy + 1) * LAB1 + ix + 1;
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    lab[c0] = x[(size_t)b * BC + lane];
+    wave_lds_sync();
+    int s = lane >> 3, q = lane & 7, gi = 0, e1 = 0, e2 = 0, kind = AMR_WALL;
+    double g = 0.0;
+    if (lane < 32) {
+      amr_slot(s, q, gi, e1, e2);
+      kind = T.kind[4 * b + s];
+      const auto get = [&](int blk, int cell) { return x[(size_t)blk * BC + cell]; };
+      g = amr_ghost(get, kind, T.nbr2[(4 * b + s) * 2], T.nbr2[(4 * b + s) * 2 + 1], T.half[4 * b + s], s, q, lab[e1],
+                    lab[e2], 1.0);
+    }
+    wave_lds_sync();
+    if (lane < 32) lab[gi] = g;
+    wave_lds_sync();
+    const double l0 = lab[c0], l1 = lab[c0 - 1], l2 = lab[c0 + 1], l3 = lab[c0 - LAB1], l4 = lab[c0 + LAB1];
+    const size_t o = (size_t)b * BC + lane;
+    if (OP == 0) y[o] -= l1 + l2 + l3 + l4 - 4 * l0;
+    if (OP == 1) y[o] = l1 + l2 + l3 + l4 - 4 * l0;
+    if (OP == 2) {
+      const double h = T.h0 / (double)(1 << T.level[b]);
+      const double pFac = -0.5 * dt * h;
+      double2 *tv = (double2 *)y;
+      double2 r;
+      r.x = pFac * (l2 - l1);
+      r.y = pFac * (l4 - l3);
+      tv[o] = r;
+    }
+    if (OP == 0 && lane < 32 && kind >= AMR_COARSE) T.faces[(size_t)(4 * b + s) * BS + q] = g - lab[e1];
+    wave_lds_sync();
+  }
+}
+
+// OP 0: tmp = (1/2h)(u_S - u_N + v_E - v_W)                                  KernelVorticity main.cpp:3343-3366
+// OP 1: tmp = facDiv (div vel) - facDiv chi (div udef), faces as main.cpp:6140-6206       pressure_rhs 6105-6206
+template <int OP>
+__global__ __launch_bounds__(WG) void k_amr_vector(const double2 *__restrict__ vel, const double2 *__restrict__ udef,
+                                                   const double *__restrict__ chi, double *__restrict__ out, AmrDev T,
+                                                   int nblocks, double dt) {
+  __shared__ double2 vlabs[WPG][LAB1 * LAB1];
+  __shared__ double2 ulabs[WPG][LAB1 * LAB1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double2 *vlab = vlabs[wave], *ulab = ulabs[wave];
+  const int ix = lane & 7, iy = lane >> 3;
+  const int c0 = (iy + 1) * LAB1 + ix + 1;
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    vlab[c0] = vel[(size_t)b * BC + lane];
+    if (OP == 1) ulab[c0] = udef[(size_t)b * BC + lane];
+    wave_lds_sync();
+    int s = lane >> 3, q = lane & 7, gi = 0, e1 = 0, e2 = 0, kind = AMR_WALL;
+    double2 gv = {0.0, 0.0}, gu = {0.0, 0.0};
+    if (lane < 32) {
+      amr_slot(s, q, gi, e1, e2);
+      kind = T.kind[4 * b + s];
+      const int n0 = T.nbr2[(4 * b + s) * 2], n1 = T.nbr2[(4 * b + s) * 2 + 1], half = T.half[4 * b + s];
+      // VectorLab::applyBCface (main.cpp:3131-3204): the wall-normal component changes sign
+      const double sx = s < 2 ? -1.0 : 1.0, sy = s < 2 ? 1.0 : -1.0;
+      const auto vx = [&](int blk, int cell) { return vel[(size_t)blk * BC + cell].x; };
+      const auto vy = [&](int blk, int cell) { return vel[(size_t)blk * BC + cell].y; };
+      gv.x = amr_ghost(vx, kind, n0, n1, half, s, q, vlab[e1].x, vlab[e2].x, sx);
+      gv.y = amr_ghost(vy, kind, n0, n1, half, s, q, vlab[e1].y, vlab[e2].y, sy);
+      if (OP == 1) {
+        const auto ux = [&](int blk, int cell) { return udef[(size_t)blk * BC + cell].x; };
+        const auto uy = [&](int blk, int cell) { return udef[(size_t)blk * BC + cell].y; };
+        gu.x = amr_ghost(ux, kind, n0, n1, half, s, q, ulab[e1].x, ulab[e2].x, sx);
+        gu.y = amr_ghost(uy, kind, n0, n1, half, s, q, ulab[e1].y, ulab[e2].y, sy);
+      }
+    }
+    wave_lds_sync();
+    if (lane < 32) {
+      vlab[gi] = gv;
+      if (OP == 1) ulab[gi] = gu;
+    }
+    wave_lds_sync();
+    const double h = T.h0 / (double)(1 << T.level[b]);
+    const size_t o = (size_t)b * BC + lane;
+    if (OP == 0) {
+      const double i2h = 0.5 / h;
+      out[o] = i2h * (vlab[c0 - LAB1].x - vlab[c0 + LAB1].x + vlab[c0 + 1].y - vlab[c0 - 1].y);
+    } else {
+      const double facDiv = 0.5 * h / dt;
+      const double ch = chi[o];
+      out[o] = facDiv * (vlab[c0 + 1].x - vlab[c0 - 1].x + vlab[c0 + LAB1].y - vlab[c0 - LAB1].y) -
+               facDiv * ch * (ulab[c0 + 1].x - ulab[c0 - 1].x + ulab[c0 + LAB1].y - ulab[c0 - LAB1].y);
+      if (lane < 32 && kind >= AMR_COARSE) {
+        // main.cpp:6140-6206: the face-normal component at the ghost and at the edge cell; chi of the edge cell
+        const int ecell = s == 0 ? q * BS : s == 1 ? q * BS + 7 : s == 2 ? q : 7 * BS + q;
+        const double che = chi[(size_t)b * BC + ecell];
+        const double v1 = s < 2 ? gv.x : gv.y, v0 = s < 2 ? vlab[e1].x : vlab[e1].y;
+        const double u1 = s < 2 ? gu.x : gu.y, u0 = s < 2 ? ulab[e1].x : ulab[e1].y;
+        double f;
+        if ((s & 1) == 0) f = facDiv * (v1 + v0) - (facDiv * che) * (u1 + u0);
+        else f = -facDiv * (v1 + v0) + (facDiv * che) * (u1 + u0);
+        T.faces[(size_t)(4 * b + s) * BS + q] = f;
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// fillcases (main.cpp:1767-1849) for a scalar field: on every side of a block whose neighbours are FINER the edge
+// cells get  own flux + (fine flux 2q + fine flux 2q+1)  (fillcase0 then fillcase1), W/E faces before S/N
+__global__ __launch_bounds__(WG) void k_amr_fillcases(double *__restrict__ y, AmrDev T, int nblocks) {
+  __shared__ double blk[WPG][BC];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *B = blk[wave];
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    const int k0 = T.kind[4 * b + 0], k1 = T.kind[4 * b + 1], k2 = T.kind[4 * b + 2], k3 = T.kind[4 * b + 3];
+    if (k0 != AMR_FINE && k1 != AMR_FINE && k2 != AMR_FINE && k3 != AMR_FINE) continue;  // wave-uniform
+    B[lane] = y[(size_t)b * BC + lane];
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane < 16) {
+        const int s = 2 * pass + (lane >> 3), q = lane & 7;
+        if (T.kind[4 * b + s] == AMR_FINE) {
+          const int fb = T.nbr2[(4 * b + s) * 2 + (q >> 2)], qq = q & 3;
+          const double *ff = T.faces + (size_t)(4 * fb + (s ^ 1)) * BS;
+          double cf = T.faces[(size_t)(4 * b + s) * BS + q];
+          cf += ff[2 * qq] + ff[2 * qq + 1];
+          const int cell = s == 0 ? q * BS : s == 1 ? q * BS + 7 : s == 2 ? q : 7 * BS + q;
+          B[cell] += cf;
+        }
+      }
+      wave_lds_sync();
+    }
+    y[(size_t)b * BC + lane] = B[lane];
+    wave_lds_sync();
+  }
+}
+
+static AmrDev amr_dev(const cup2d_ctx *c) {
+  AmrDev T;
+  T.kind = c->amr.d_kind; T.nbr2 = c->amr.d_nbr2; T.half = c->amr.d_half; T.level = c->amr.d_level;
+  T.faces = c->amr.d_faces; T.h0 = c->amr.h0;
+  return T;
+}
+static int amr_grid(const cup2d_ctx *c) {
+  int g = (c->nblocks + WPG - 1) / WPG;
+  return g > c->grid ? c->grid : (g < 1 ? 1 : g);
+}
+
+int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract) {
+  const AmrDev T = amr_dev(c);
+  if (subtract) {
+    hipLaunchKernelGGL(k_amr_scalar<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
+    hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, y, T, c->nblocks);
+  } else {
+    hipLaunchKernelGGL(k_amr_scalar<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
+  }
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt) {
+  hipLaunchKernelGGL(k_amr_scalar<2>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, pres, tmpV, amr_dev(c), c->nblocks, dt);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+int amr_vorticity(cup2d_ctx *c, const double *vel, double *out) {
+  hipLaunchKernelGGL(k_amr_vector<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, nullptr, nullptr, out,
+                     amr_dev(c), c->nblocks, 0.0);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt) {
+  const AmrDev T = amr_dev(c);
+  hipLaunchKernelGGL(k_amr_vector<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (const double2 *)udef,
+                     chi, out, T, c->nblocks, dt);
+  hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, out, T, c->nblocks);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
+}  // namespace cup2d

@@ -212,6 +212,8 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipHostFree(c->h_status);
   for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
+  (void)hipFree(c->amr.d_level); (void)hipFree(c->amr.d_kind); (void)hipFree(c->amr.d_nbr2); (void)hipFree(c->amr.d_half);
+  (void)hipFree(c->amr.d_faces);
   (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
   (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -317,15 +319,68 @@ int cup2d_copy_field(cup2d_ctx *c, int dst, int src) {
   return CUP2D_OK;
 }
 
+// ---- block-AMR topology -------------------------------------------------------------------------
+int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
+                  const int32_t *half) {
+  CUP2D_CHECK_CTX(c);
+  if (!(h0 > 0) || !level || !kind || !nbr2 || !half) { set_error("set_amr: bad argument"); return CUP2D_ERR_ARG; }
+  if (c->nghost != 0) { set_error("set_amr: ghost blocks (multi-GPU) are not supported on adapted grids yet"); return CUP2D_ERR_UNSUPPORTED; }
+  const int nb = c->nblocks;
+  for (int b = 0; b < nb; b++) {
+    if (level[b] < 0 || level[b] > 30) { set_error("set_amr: level[%d] = %d", b, level[b]); return CUP2D_ERR_ARG; }
+    for (int s = 0; s < 4; s++) {
+      const int k = kind[4 * b + s], n0 = nbr2[(4 * b + s) * 2], n1 = nbr2[(4 * b + s) * 2 + 1];
+      bool ok = k >= CUP2D_AMR_WALL && k <= CUP2D_AMR_FINER;
+      if (ok && k != CUP2D_AMR_WALL) ok = n0 >= 0 && n0 < nb;
+      if (ok && k == CUP2D_AMR_SAME) ok = level[n0] == level[b];
+      if (ok && k == CUP2D_AMR_COARSER) ok = level[n0] == level[b] - 1 && (half[4 * b + s] == 0 || half[4 * b + s] == 1);
+      if (ok && k == CUP2D_AMR_FINER) ok = n1 >= 0 && n1 < nb && level[n0] == level[b] + 1 && level[n1] == level[b] + 1;
+      if (!ok) { set_error("set_amr: block %d side %d: kind %d neighbours %d %d", b, s, k, n0, n1); return CUP2D_ERR_ARG; }
+    }
+  }
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  cup2d::AmrTopo &A = c->amr;
+  (void)hipFree(A.d_level); (void)hipFree(A.d_kind); (void)hipFree(A.d_nbr2); (void)hipFree(A.d_half); (void)hipFree(A.d_faces);
+  A = cup2d::AmrTopo();
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_level, sizeof(int32_t) * nb));
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_kind, sizeof(int32_t) * nb * 4));
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_nbr2, sizeof(int32_t) * nb * 8));
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_half, sizeof(int32_t) * nb * 4));
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_faces, sizeof(double) * nb * 4 * BS));
+  CUP2D_HIP_CHECK(hipMemcpy(A.d_level, level, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMemcpy(A.d_kind, kind, sizeof(int32_t) * nb * 4, hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMemcpy(A.d_nbr2, nbr2, sizeof(int32_t) * nb * 8, hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMemcpy(A.d_half, half, sizeof(int32_t) * nb * 4, hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMemset(A.d_faces, 0, sizeof(double) * nb * 4 * BS));
+  A.h0 = h0;
+  int lmax = 0;
+  for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;
+  A.h_min = h0 / (double)(1 << lmax);
+  A.active = true;
+  return CUP2D_OK;
+}
+#define AMR_UNSUPPORTED(c)                                                                      \
+  if ((c)->amr.active) {                                                                        \
+    set_error("%s: not built for adapted grids yet (cup2d_set_amr is active)", __func__);       \
+    return CUP2D_ERR_UNSUPPORTED;                                                               \
+  }
+#define AMR_ALL_BLOCKS(c, phase)                                                                \
+  if ((c)->amr.active && (phase) != CUP2D_BLOCKS_ALL) {                                         \
+    set_error("%s: adapted grids take CUP2D_BLOCKS_ALL", __func__);                             \
+    return CUP2D_ERR_ARG;                                                                       \
+  }
+
 // ---- block operators --------------------------------------------------------------------------
 int cup2d_advect_diffuse_rhs(cup2d_ctx *c, double nu, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   return launch_advect(c, c->d_field[CUP2D_VEL], nullptr, c->d_field[CUP2D_TMPV], 0, nu, dt, 0.0, first, count);
 }
 int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, int phase) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   const double ih2 = 1.0 / (c->h * c->h);
@@ -339,6 +394,7 @@ int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, in
 }
 int cup2d_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   for (int stage = 1; stage <= 2; stage++) {
     double *src = stage == 1 ? c->d_field[CUP2D_VEL] : c->d_vscratch;
     if (overlapped(c)) {  // inner blocks while the face strips are in flight (main.cpp:3035-3057)
@@ -357,6 +413,8 @@ int cup2d_vorticity(cup2d_ctx *c, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
+  AMR_ALL_BLOCKS(c, phase);
+  if (c->amr.active) return amr_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP]);
   return launch_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP], first, count);
 }
 int cup2d_pressure_rhs(cup2d_ctx *c, double dt, int use_bodies, int phase) {
@@ -364,6 +422,9 @@ int cup2d_pressure_rhs(cup2d_ctx *c, double dt, int use_bodies, int phase) {
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   if (!(dt > 0)) { set_error("pressure_rhs: dt"); return CUP2D_ERR_ARG; }
+  AMR_ALL_BLOCKS(c, phase);
+  if (c->amr.active)  // the chi / udef terms are always evaluated (chi = 0 without bodies), as the reference does
+    return amr_pressure_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], c->d_field[CUP2D_CHI], c->d_field[CUP2D_TMP], dt);
   return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
                              use_bodies ? c->d_field[CUP2D_CHI] : nullptr, nullptr, c->d_field[CUP2D_TMP], dt, first, count);
 }
@@ -371,10 +432,13 @@ int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
+  AMR_ALL_BLOCKS(c, phase);
+  if (c->amr.active) return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1);
   return launch_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1, first, count);
 }
 int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
   // pold = pres; pres = 0 (main.cpp:7016-7021) as a pointer swap + memset
   double *tmp = c->d_field[CUP2D_POLD];
@@ -392,6 +456,8 @@ int cup2d_pressure_correction(cup2d_ctx *c, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
+  AMR_ALL_BLOCKS(c, phase);
+  if (c->amr.active) return amr_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], dt);
   return launch_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], nullptr, dt, 0, first, count);
 }
 int cup2d_add_correction(cup2d_ctx *c) {
@@ -401,6 +467,7 @@ int cup2d_add_correction(cup2d_ctx *c) {
 }
 int cup2d_project(cup2d_ctx *c, double dt) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   ProfScope t(c, CUP2D_T_PROJECT);
   return project_impl(c, dt);
 }
@@ -421,7 +488,7 @@ int cup2d_compute_dt(cup2d_ctx *c, double nu, double cfl, double *dt) {
   if (!dt) return CUP2D_ERR_ARG;
   double umax = 0;
   CUP2D_TRY(cup2d_max_abs_vel(c, &umax));
-  const double h = c->h;  // uniform level: min h == h (main.cpp:6580-6583)
+  const double h = c->amr.active ? c->amr.h_min : c->h;  // the finest cell size (main.cpp:6580-6583)
   const double dtDiffusion = 0.25 * h * h / (nu + 0.25 * h * umax);
   const double dtAdvection = h / (umax + 1e-8);
   *dt = fmin(dtDiffusion, cfl * dtAdvection);
@@ -433,6 +500,10 @@ int cup2d_poisson_solve(cup2d_ctx *c, double max_error, double max_rel_error, in
                         int *restarts, double *linf, double *linf_init) {
   CUP2D_CHECK_CTX(c);
   if (max_iter < 0) { set_error("poisson_solve: max_iter"); return CUP2D_ERR_ARG; }
+  if (c->amr.active && !c->mat.active) {
+    set_error("poisson_solve: on an adapted grid install the assembled operator (cup2d_set_matrix_coo)");
+    return CUP2D_ERR_UNSUPPORTED;
+  }
   c->last_solver = (c->solver == CUP2D_SOLVER_FUSED && fused_supported(c)) ? CUP2D_SOLVER_FUSED : CUP2D_SOLVER_SWEEPS;
   if (c->last_solver == CUP2D_SOLVER_FUSED)
     return solve_fused_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
@@ -456,6 +527,7 @@ int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {
   CUP2D_CHECK_CTX(c);
   if (!scalar_field(dst) || !scalar_field(src) || dst == src) { set_error("apply_A: fields"); return CUP2D_ERR_ARG; }
   if (c->mat.active) return launch_matvec(c, c->d_field[src], c->d_field[dst]);
+  if (c->amr.active) return amr_laplacian(c, c->d_field[src], c->d_field[dst], 0);
   CUP2D_TRY(exchange_halo(c, c->d_field[src], 1, 1));
   return launch_laplacian(c, c->d_field[src], c->d_field[dst], 0, 0, c->nblocks);
 }
@@ -581,6 +653,7 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
 int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
                int max_iter, double *dt_out, int *iters, double *linf) {
   CUP2D_CHECK_CTX(c);
+  AMR_UNSUPPORTED(c);
   double dt = 0;
   CUP2D_TRY(cup2d_compute_dt(c, nu, cfl, &dt));
   if (!(dt > 2e-16)) {  // main.cpp:6596

@@ -84,6 +84,18 @@ struct SellMatrix {
 
 enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
 
+// Block-AMR topology (amr.hip): per block its level and, per side W,E,S,N, what lies across it
+struct AmrTopo {
+  bool active = false;
+  double h0 = 0;                 // cell size of level 0 (main.cpp:6338)
+  double h_min = 0;              // cell size of the finest level present (dt, main.cpp:6580-6583)
+  int32_t *d_level = nullptr;    // [nblocks]
+  int32_t *d_kind = nullptr;     // [nblocks][4]  0 wall, 1 same level, 2 coarser, 3 finer
+  int32_t *d_nbr2 = nullptr;     // [nblocks][4][2] neighbour block(s): one, or the two finer ones along the face
+  int32_t *d_half = nullptr;     // [nblocks][4]  coarser neighbour: which half of its face this block touches
+  double *d_faces = nullptr;     // [nblocks][4][8] fluxes recorded by the functors (BlockCase::d, main.cpp:513-517)
+};
+
 }  // namespace cup2d
 
 struct cup2d_ctx {
@@ -122,6 +134,7 @@ struct cup2d_ctx {
   double *h_red = nullptr;               // pinned [8]
   cup2d::HaloPlan plan;
   cup2d::SellMatrix mat;
+  cup2d::AmrTopo amr;
   int precond = cup2d::PRECOND_FD;  // block-Jacobi implementation (krylov.hip); FD needs the built-in P_inv
   bool custom_Pinv = false;         // cup2d_set_P_inv installed something else than -(A_loc)^-1
   // communication callbacks
@@ -220,6 +233,11 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                      int *iters, int *restarts, double *linf, double *linf_init);
 // reduction finish + scalar update of `stage` as its own launch(es) (+ all-reduce callback with N GPUs)
 int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr);
+// halo-1 block operators on a block-AMR grid (amr.hip)
+int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract);
+int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt);
+int amr_vorticity(cup2d_ctx *c, const double *vel, double *out);
+int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);
 // ghost-strip exchange of a device vector through the comm callbacks (no-ops without ghosts):

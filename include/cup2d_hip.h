@@ -188,6 +188,23 @@ int cup2d_clear_matrix(cup2d_ctx *ctx);
  * strip_doubles = 1 and device_recv = &vec[64*nblocks].  Call after cup2d_set_matrix_coo. */
 int cup2d_set_gather(cup2d_ctx *ctx, int nsend, const int32_t *idx);
 
+/* ---------------------------------------------------------------- block-AMR --------------- */
+/* Adapted grids (BASELINE.json configs[4]; the reference's Info::level / tree, main.cpp:504-517, 2197-2198).
+ * level[b] = refinement level of block b (cell size h0 / 2^level, main.cpp:693); for every side W,E,S,N of b:
+ *   kind[b][s]   CUP2D_AMR_WALL, _SAME (neighbour nbr2[b][s][0] on the same level), _COARSER (nbr2[b][s][0] is one
+ *                level coarser; half[b][s] = 0|1 = which half of its face b touches, in increasing y for W/E and
+ *                increasing x for S/N), _FINER (the two blocks nbr2[b][s][0..1] one level finer, ordered along the face)
+ * 2:1 balance is the caller's invariant (the reference's adapt() enforces it, main.cpp:4734-4861).
+ * Once set, the halo-1 block operators run their AMR form -- ghost cells across coarse-fine faces as
+ * BlockLab::load/post_load builds them (main.cpp:2270-2933) and the flux correction of prepare0/fillcases
+ * (main.cpp:1564-1849): cup2d_laplacian_sub, cup2d_apply_A, cup2d_pressure_rhs, cup2d_pressure_correction,
+ * cup2d_vorticity (phase must be CUP2D_BLOCKS_ALL; the nbr table of cup2d_create is ignored by them).  Entry points
+ * whose AMR form is not built yet (WENO5 advect-diffuse: halo-3 interpolation; the matrix-free solve and the
+ * projection: use cup2d_set_matrix_coo with the caller's coarse-fine rows) return CUP2D_ERR_UNSUPPORTED. */
+typedef enum { CUP2D_AMR_WALL = 0, CUP2D_AMR_SAME = 1, CUP2D_AMR_COARSER = 2, CUP2D_AMR_FINER = 3 } cup2d_amr_kind;
+int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
+                  const int32_t *half);
+
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:
  * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL. */

@@ -590,6 +590,75 @@ int main(int argc, char **argv) {
       for (auto &I : var.vel->infos) { lmin = std::min(lmin, I.level); lmax = std::max(lmax, I.level); }
       fprintf(meta, "step %d blocks %zu levels %d %d dt %.17g update %d prev_iters %d prev_err %.17g\n", solve_count,
               var.vel->infos.size(), lmin, lmax, sim.dt, (int)withUpdate, hooks.last_iters, hooks.last_error);
+      if (solve_count == steps && reps == -1) {
+        /* functors=1: leave the time loop here and evaluate block functors on the adapted grid with ANALYTIC
+         * fields (cell-centre samples), exactly through the reference's own call sequences:
+         *   lap : prepare0 / computeA<ScalarLab>(pressure_rhs1(), var.pold, 1) / fillcases  (main.cpp:7022-7027)
+         *   vort: computeA<VectorLab>(KernelVorticity(), var.vel, 2)                          (main.cpp:4659)
+         * blocks.functors = per block (level, i, j, 64 pold, 64 tmp_in, 64 tmp_out, 128 vel, 64 vorticity) */
+        auto fs = [](double x, double y) { return std::sin(5.0 * x + 0.3) * std::cos(3.0 * y - 0.2) + 0.25 * x * y; };
+        auto gs = [](double x, double y) { return 0.1 * std::cos(2.0 * x) - 0.2 * std::sin(4.0 * y + 1.0); };
+        const size_t nb = var.vel->infos.size();
+        /* + chi (64), udef (128), pressure_rhs out (64), pres (64), pressureCorrectionKernel out (128) */
+        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128;
+        std::vector<double> out(nb * stride);
+        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64;
+        sim.dt = dt > 0 ? dt : 0.01;
+        for (size_t i = 0; i < nb; i++) {
+          Info &I = var.pold->infos[i];
+          double *o = &out[i * stride];
+          o[0] = I.level; o[1] = I.index[0]; o[2] = I.index[1];
+          for (int iy = 0; iy < _BS_; iy++)
+            for (int ix = 0; ix < _BS_; ix++) {
+              const double x = I.origin[0] + (ix + 0.5) * I.h, y = I.origin[1] + (iy + 0.5) * I.h;
+              const int k = iy * _BS_ + ix;
+              I.block[k] = fs(x, y);
+              var.tmp->infos[i].block[k] = gs(x, y);
+              var.vel->infos[i].block[2 * k] = fs(y, x);
+              var.vel->infos[i].block[2 * k + 1] = gs(x + 0.1, y) + fs(x, y);
+              o[3 + k] = I.block[k];
+              o[3 + 64 + k] = var.tmp->infos[i].block[k];
+              o[3 + 192 + 2 * k] = var.vel->infos[i].block[2 * k];
+              o[3 + 192 + 2 * k + 1] = var.vel->infos[i].block[2 * k + 1];
+              var.chi->infos[i].block[k] = 0.5 + 0.4 * std::sin(3.0 * x) * std::cos(2.0 * y);
+              var.tmpV->infos[i].block[2 * k] = 0.3 * fs(x + 0.2, y - 0.1);
+              var.tmpV->infos[i].block[2 * k + 1] = -0.2 * gs(y, x);
+              var.pres->infos[i].block[k] = gs(x - 0.3, y + 0.2) + fs(y, x + 0.1);
+              o[o_chi + k] = var.chi->infos[i].block[k];
+              o[o_udef + 2 * k] = var.tmpV->infos[i].block[2 * k];
+              o[o_udef + 2 * k + 1] = var.tmpV->infos[i].block[2 * k + 1];
+              o[o_pres + k] = var.pres->infos[i].block[k];
+            }
+        }
+        if (var.tmp->UpdateFluxCorrection) {
+          prepare0(var.buf1, &var.tmp->infos, &var.tmp->all, &var.tmp->tree, 1);
+          var.tmp->UpdateFluxCorrection = false;
+        }
+        computeA<ScalarLab>(pressure_rhs1(), var.pold, 1);
+        fillcases(var.buf1, &var.tmp->tree, 1);
+        for (size_t i = 0; i < nb; i++)
+          for (int k = 0; k < 64; k++) out[i * stride + 3 + 128 + k] = var.tmp->infos[i].block[k];
+        computeA<VectorLab>(KernelVorticity(), var.vel, 2);
+        for (size_t i = 0; i < nb; i++)
+          for (int k = 0; k < 64; k++) out[i * stride + 3 + 192 + 128 + k] = var.tmp->infos[i].block[k];
+        /* pressure_rhs with its flux correction (main.cpp:7007-7013); vel, tmpV = udef, chi as set above */
+        computeB<pressure_rhs, VectorLab, VectorLab>(pressure_rhs(), var.vel, 2, var.tmpV, 2);
+        fillcases(var.buf1, &var.tmp->tree, 1);
+        for (size_t i = 0; i < nb; i++)
+          for (int k = 0; k < 64; k++) out[i * stride + o_prhs + k] = var.tmp->infos[i].block[k];
+        /* pressureCorrectionKernel (main.cpp:7178): tmpV = -0.5 dt h grad(pres) */
+        computeA<ScalarLab>(pressureCorrectionKernel(), var.pres, 1);
+        for (size_t i = 0; i < nb; i++)
+          for (int k = 0; k < 128; k++) out[i * stride + o_pc + k] = var.tmpV->infos[i].block[k];
+        {
+          double sc[2] = {sim.dt, sim.h0};
+          write_file(dir + "/functors_scalars", sc, 2);
+        }
+        write_file(dir + "/blocks.functors", out.data(), out.size());
+        fclose(meta);
+        MPI_Finalize();
+        exit(0);
+      }
       if (solve_count == steps) sim.endTime = 1e-300;
       solve_count++;
     };

@@ -56,6 +56,9 @@ def main():
     D = O.ref_dump(vd, time=0.375)
     np.savez_compressed(os.path.join(HERE, "dump_n32.npz"), vel=vd, time=0.375, xyz=np.frombuffer(D["xyz"], dtype=np.uint8),
                         attr=np.frombuffer(D["attr"], dtype=np.uint8), xdmf2=np.frombuffer(D["xdmf2"], dtype=np.uint8))
+    # block functors of the reference on an ADAPTED grid (three levels, 76 blocks): the grid its own adapt() builds around
+    # an analytic vortex pair, halo-1 functors with their flux correction on analytic fields (ref_harness 'amr' reps=-1)
+    np.savez_compressed(os.path.join(HERE, "amr_functors.npz"), **O.ref_amr_functors(2, 5, 4, 2.0, 0.5))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

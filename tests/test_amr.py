@@ -1,0 +1,107 @@
+"""Block-AMR (BASELINE.json configs[4]), halo-1 block operators: ghost cells across coarse-fine faces and the flux
+correction of the coarse side.  Three layers, all BIT FOR BIT:
+  golden  tests/golden/amr_functors.npz -- written by the reference itself (oracle/_ref/ref_harness 'amr': its own
+          adapt() builds a 3-level, 76-block grid around a vortex pair; pressure_rhs1, pressure_rhs (both with
+          prepare0/fillcases), pressureCorrectionKernel and KernelVorticity run on analytic fields)
+  oracle  oracle/amr.py, the numpy restatement of BlockLab::load/post_load + fillcases for halo-1 stencils
+  HIP     csrc/amr.hip through the C ABI (cup2d_set_amr + the usual entry points)      [-m gpu]"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def _grid_cases(oracle):
+    yield "golden", golden("amr_functors.npz")
+    if oracle.have_reference():
+        yield "live-118", oracle.ref_amr_functors(1, 5, 6, 1.0, 0.2)
+        yield "live-232", oracle.ref_amr_functors(2, 6, 7, 3.0, 1.0)
+
+
+def test_amr_oracle_bit_exact_vs_reference(oracle):
+    from oracle import amr as A
+    seen = set()
+    for name, F in _grid_cases(oracle):
+        g = A.AmrGrid(F["blocks"])
+        seen |= {(s, g.neighbour(b, s)[0]) for b in range(len(g.blocks)) for s in range(4)}
+        assert np.array_equal(A.laplacian_sub_amr(g, F["pold"], F["tmp_in"]), F["tmp_out"]), name
+        assert np.array_equal(A.vorticity_amr(g, F["vel"]), F["vort"]), name
+        assert np.array_equal(A.pressure_rhs_amr(g, F["vel"], F["udef"], F["chi"], float(F["dt"])), F["prhs"]), name
+        assert np.array_equal(A.pressure_correction_amr(g, F["pres"], float(F["dt"])), F["pcorr"]), name
+    # every side meets every kind of neighbour in the fixtures
+    assert seen == {(s, k) for s in range(4) for k in ("wall", "same", "coarse", "fine")}
+
+
+def test_amr_topology_tables(oracle):
+    """cup2d_amd.amr.AmrBlockGrid (product) against the oracle's neighbour logic; level jumps are 2:1"""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid
+    from oracle import amr as A
+    F = golden("amr_functors.npz")
+    g, o = AmrBlockGrid(F["blocks"]), A.AmrGrid(F["blocks"])
+    name = {L.AMR_WALL: "wall", L.AMR_SAME: "same", L.AMR_COARSER: "coarse", L.AMR_FINER: "fine"}
+    for b in range(g.nblocks):
+        for s in range(4):
+            t = o.neighbour(b, s)
+            assert name[int(g.kind[b, s])] == t[0]
+            if t[0] in ("same", "coarse"):
+                assert g.nbr2[b, s, 0] == t[1]
+            if t[0] == "fine":
+                assert tuple(g.nbr2[b, s]) == tuple(t[1:])
+            if t[0] == "coarse":
+                assert g.half[b, s] == (F["blocks"][b][2] % 2 if s < 2 else F["blocks"][b][1] % 2)
+    x, y = g.cell_centres()
+    assert x.min() > 0 and x.max() < 1 and y.min() > 0 and y.max() < 1
+    with pytest.raises(ValueError):
+        AmrBlockGrid([(0, 0, 0), (2, 0, 0)])  # not a tiling
+
+
+@pytest.mark.gpu
+def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    for name, F in _grid_cases(oracle):
+        dt = float(F["dt"])
+        with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
+            # tmp -= Lap5(pold) with the flux correction (main.cpp:7022-7027)
+            s.set_field(L.POLD, F["pold"])
+            s.set_field(L.TMP, F["tmp_in"])
+            s.laplacian_sub()
+            assert np.array_equal(s.get_field(L.TMP), F["tmp_out"]), name
+            # the operator alone: y = A x without the correction equals tmp_in - tmp_out away from coarse blocks' edges
+            s.set_field(L.PRES, F["pold"])
+            s.apply_A(L.TMP, L.PRES)
+            fine_side = np.asarray(s.grid.kind == L.AMR_FINER).any(axis=1)
+            assert np.array_equal(s.get_field(L.TMP)[~fine_side], (F["tmp_in"] - F["tmp_out"])[~fine_side]) or \
+                np.abs(s.get_field(L.TMP)[~fine_side] - (F["tmp_in"] - F["tmp_out"])[~fine_side]).max() < 1e-13
+            # KernelVorticity
+            s.set_field(L.VEL, F["vel"])
+            s.vorticity()
+            assert np.array_equal(s.get_field(L.TMP), F["vort"]), name
+            # pressure_rhs with chi / udef and its flux correction (main.cpp:7007-7013)
+            s.set_field(L.TMPV, F["udef"])
+            s.set_field(L.CHI, F["chi"])
+            s.pressure_rhs(dt)
+            assert np.array_equal(s.get_field(L.TMP), F["prhs"]), name
+            # pressureCorrectionKernel (main.cpp:7178)
+            s.set_field(L.PRES, F["pres"])
+            s.pressure_correction(dt)
+            assert np.array_equal(s.get_field(L.TMPV), F["pcorr"]), name
+            # dt uses the finest cell size (main.cpp:6580-6595)
+            umax = np.abs(F["vel"]).max()
+            hmin = s.grid.h(F["blocks"][:, 0].max())
+            assert s.compute_dt() == oracle.compute_dt(hmin, 1e-3, 0.5, umax)
+
+
+@pytest.mark.gpu
+def test_amr_unsupported_entry_points_say_so(gpu_lib):
+    import ctypes
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
+        assert s.L.cup2d_advect_diffuse_rk2(s._ctx, 1e-3, 1e-3) == -4  # CUP2D_ERR_UNSUPPORTED
+        assert b"adapted" in s.L.cup2d_last_error()
+        it = ctypes.c_int()
+        assert s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 10, 10, ctypes.byref(it), None, None, None) == -4
+        assert s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER) == -1  # CUP2D_ERR_ARG: adapted grids take all blocks

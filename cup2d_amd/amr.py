@@ -56,6 +56,108 @@ class AmrBlockGrid:
     def h(self, level):
         return self.h0 / (1 << int(level))
 
+    # ---- Poisson matrix of main.cpp:7034-7112 on this adapted grid -------------------------------
+    def poisson_coo(self):
+        """COO triplets (row, col, val) of the matrix the reference assembles (rows/columns numbered 64 * block + 8 * iy
+        + ix in the order of `blocks`): 5-point rows inside a block (main.cpp:7075-7087); on block-edge cells, per side:
+        nothing at a domain wall, +1/-1 towards a same-level neighbour, and across coarse-fine faces the reference's
+        interpolated fluxes (Solver::makeFlux / interpolate / D1 / D2, main.cpp:5915-5997): weights 2/3, -1/5, 8/15 on
+        the two fine cells and the coarse cell plus the Taylor corrections along the face.  Duplicate columns of a row
+        are summed as SpRowInfo::mapColVal does (cuda.h:1-24).  Host-side, regrid-time code."""
+        rows = {}
+
+        def add(r, c, v):
+            d = rows.setdefault(r, {})
+            d[c] = d.get(c, 0.0) + v
+
+        def cell(b, ix, iy):
+            return 64 * b + 8 * iy + ix
+
+        def d1(b, s, ix, iy):
+            t = iy if s < 2 else ix  # coordinate along the face
+            nei = (lambda d: cell(b, ix, iy + d)) if s < 2 else (lambda d: cell(b, ix + d, iy))
+            if t in (7, 3):
+                return [(nei(-2), 1. / 8.), (nei(-1), -1. / 2.), (cell(b, ix, iy), 3. / 8.)]
+            if t in (0, 4):
+                return [(nei(2), -1. / 8.), (nei(1), 1. / 2.), (cell(b, ix, iy), -3. / 8.)]
+            return [(nei(-1), -1. / 8.), (nei(1), 1. / 8.), (cell(b, ix, iy), 0.)]
+
+        def d2(b, s, ix, iy):
+            t = iy if s < 2 else ix
+            nei = (lambda d: cell(b, ix, iy + d)) if s < 2 else (lambda d: cell(b, ix + d, iy))
+            if t in (7, 3):
+                return [(nei(-2), 1. / 32.), (nei(-1), -1. / 16.), (cell(b, ix, iy), 1. / 32.)]
+            if t in (0, 4):
+                return [(nei(2), 1. / 32.), (nei(1), -1. / 16.), (cell(b, ix, iy), 1. / 32.)]
+            return [(nei(-1), 1. / 32.), (nei(1), 1. / 32.), (cell(b, ix, iy), -1. / 16.)]
+
+        def interpolate(r, bc, s, ixc, iyc, fine_close, fine_far, sign_int, sign_taylor):
+            add(r, fine_close, sign_int * 2. / 3.)
+            add(r, fine_far, -sign_int * 1. / 5.)
+            tf = sign_int * 8. / 15.
+            add(r, cell(bc, ixc, iyc), tf)
+            for c, w in d1(bc, s, ixc, iyc):
+                add(r, c, sign_taylor * tf * w)
+            for c, w in d2(bc, s, ixc, iyc):
+                add(r, c, tf * w)
+
+        for b, (l, bi, bj) in enumerate(self.blocks):
+            bi, bj = int(bi), int(bj)
+            for iy in range(BS):
+                for ix in range(BS):
+                    r = cell(b, ix, iy)
+                    if 0 < ix < BS - 1 and 0 < iy < BS - 1:
+                        for c, v in ((cell(b, ix, iy - 1), 1.), (cell(b, ix - 1, iy), 1.), (r, -4.), (cell(b, ix + 1, iy), 1.),
+                                     (cell(b, ix, iy + 1), 1.)):
+                            add(r, c, v)
+                        continue
+                    inblock = (ix > 0, ix < BS - 1, iy > 0, iy < BS - 1)
+                    inner = (cell(b, ix - 1, iy) if ix > 0 else -1, cell(b, ix + 1, iy) if ix < BS - 1 else -1,
+                             cell(b, ix, iy - 1) if iy > 0 else -1, cell(b, ix, iy + 1) if iy < BS - 1 else -1)
+                    for s in range(4):
+                        if inblock[s]:
+                            add(r, inner[s], 1.)
+                            add(r, r, -1.)
+                            continue
+                        k = int(self.kind[b, s])
+                        if k == _l.AMR_WALL:
+                            continue
+                        n0, n1 = int(self.nbr2[b, s, 0]), int(self.nbr2[b, s, 1])
+                        if k == _l.AMR_SAME:
+                            c = cell(n0, 7, iy) if s == 0 else cell(n0, 0, iy) if s == 1 else cell(n0, ix, 7) if s == 2 else cell(n0, ix, 0)
+                            add(r, c, 1.)
+                            add(r, r, -1.)
+                        elif k == _l.AMR_COARSER:
+                            ixc = 7 if s == 0 else 0 if s == 1 else (ix // 2 if bi % 2 == 0 else ix // 2 + 4)
+                            iyc = 7 if s == 2 else 0 if s == 3 else (iy // 2 if bj % 2 == 0 else iy // 2 + 4)
+                            inward = cell(b, ix + 1, iy) if s == 0 else cell(b, ix - 1, iy) if s == 1 else cell(b, ix, iy + 1) if s == 2 \
+                                else cell(b, ix, iy - 1)
+                            t = iy if s < 2 else ix
+                            interpolate(r, n0, s, ixc, iyc, r, inward, 1., -1. if t % 2 == 0 else 1.)
+                            add(r, r, -1.)
+                        else:  # two finer cells across the face, in the child block that covers this cell
+                            t = iy if s < 2 else ix
+                            fb = n1 if t >= 4 else n0
+                            f = (t % 4) * 2
+                            for j, st in ((0, -1.), (1, 1.)):
+                                if s == 0:
+                                    close, far = cell(fb, 7, f + j), cell(fb, 6, f + j)
+                                elif s == 1:
+                                    close, far = cell(fb, 0, f + j), cell(fb, 1, f + j)
+                                elif s == 2:
+                                    close, far = cell(fb, f + j, 7), cell(fb, f + j, 6)
+                                else:
+                                    close, far = cell(fb, f + j, 0), cell(fb, f + j, 1)
+                                add(r, close, 1.)
+                                interpolate(r, b, s, ix, iy, close, far, -1., st)
+        rr, cc, vv = [], [], []
+        for r in sorted(rows):
+            for c in sorted(rows[r]):
+                rr.append(r)
+                cc.append(c)
+                vv.append(rows[r][c])
+        return np.asarray(rr, dtype=np.int32), np.asarray(cc, dtype=np.int32), np.asarray(vv, dtype=np.float64)
+
     def cell_centres(self):
         """x, y of every cell, (nb, 64) each, as the reference places them (origin main.cpp:695-696)"""
         l = self.blocks[:, 0]

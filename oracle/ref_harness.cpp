@@ -580,7 +580,9 @@ int main(int argc, char **argv) {
             I.block[2 * (iy * _BS_ + ix) + 1] = v;
           }
     };
-    hooks.on_solve = [&](LocalSpMatDnVec *, bool withUpdate, double, double, int) {
+    bool in_matvec = false;
+    hooks.on_solve = [&](LocalSpMatDnVec *M, bool withUpdate, double, double, int) {
+      if (in_matvec) return; /* the matvec below re-enters solveNoUpdate */
       if (solve_count == 0) {
         inject();
         sim.Rtol = rtol_amr;
@@ -600,9 +602,9 @@ int main(int argc, char **argv) {
         auto gs = [](double x, double y) { return 0.1 * std::cos(2.0 * x) - 0.2 * std::sin(4.0 * y + 1.0); };
         const size_t nb = var.vel->infos.size();
         /* + chi (64), udef (128), pressure_rhs out (64), pres (64), pressureCorrectionKernel out (128) */
-        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128;
+        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64; /* ... + A x (64) */
         std::vector<double> out(nb * stride);
-        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64;
+        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64, o_ax = o_pc + 128;
         sim.dt = dt > 0 ? dt : 0.01;
         for (size_t i = 0; i < nb; i++) {
           Info &I = var.pold->infos[i];
@@ -654,6 +656,22 @@ int main(int argc, char **argv) {
           double sc[2] = {sim.dt, sim.h0};
           write_file(dir + "/functors_scalars", sc, 2);
         }
+#ifndef HARNESS_HIP_SPMAT
+        /* the Poisson matrix the reference assembled for this grid (main.cpp:7034-7113, coarse-fine rows by
+         * Solver::makeFlux; still current when this step did not regrid) applied to the analytic pres field */
+        {
+          std::vector<double> &xv = M->get_x();
+          for (size_t i = 0; i < nb; i++)
+            for (int k = 0; k < 64; k++) xv[i * 64 + k] = var.pres->infos[i].block[k];
+          hooks.matvec_only = true;
+          in_matvec = true;
+          M->solveNoUpdate(0, 0, 0);
+          in_matvec = false;
+          hooks.matvec_only = false;
+          for (size_t i = 0; i < nb; i++)
+            for (int k = 0; k < 64; k++) out[i * stride + o_ax + k] = M->get_x()[i * 64 + k];
+        }
+#endif
         write_file(dir + "/blocks.functors", out.data(), out.size());
         fclose(meta);
         MPI_Finalize();

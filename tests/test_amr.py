@@ -56,6 +56,55 @@ def test_amr_topology_tables(oracle):
         AmrBlockGrid([(0, 0, 0), (2, 0, 0)])  # not a tiling
 
 
+def test_amr_poisson_matrix_vs_reference(oracle):
+    """the coarse-fine rows of the Poisson matrix (Solver::makeFlux / interpolate, main.cpp:5915-5997) assembled by
+    cup2d_amd.amr.AmrBlockGrid.poisson_coo, against the matrix the REFERENCE assembled for the same grid, through
+    its action on a field (the harness applies the reference's own triplets)"""
+    import scipy.sparse as sp
+    from cup2d_amd.amr import AmrBlockGrid
+    for name, F in _grid_cases(oracle):
+        g = AmrBlockGrid(F["blocks"])
+        r, c, v = g.poisson_coo()
+        n = 64 * g.nblocks
+        A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
+        assert np.abs(A @ F["pres"].ravel() - F["Ax"].ravel()).max() < 1e-14, name
+        assert np.abs(A @ np.ones(n)).max() < 1e-14  # constants are in the null space (homogeneous Neumann walls)
+        assert A.getnnz(axis=1).max() <= 13 and (A.getnnz(axis=1) >= 3).all()
+
+
+@pytest.mark.gpu
+def test_amr_poisson_solve_gpu(gpu_lib, oracle):
+    """config 5 through the C ABI: the assembled coarse-fine operator installed with cup2d_set_matrix_coo, applied and
+    solved on the GPU (sliced-ELL sweeps, block-Jacobi BiCGSTAB of cuda.cu:403-548)"""
+    import ctypes
+    import scipy.sparse as sp
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    g = AmrBlockGrid(F["blocks"])
+    r, c, v = g.poisson_coo()
+    n = 64 * g.nblocks
+    A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
+    vp = ctypes.c_void_p
+    with AmrSimulation(g) as s:
+        L.check(s.L.cup2d_set_matrix_coo(s._ctx, 0, len(v), r.ctypes.data_as(vp), c.ctypes.data_as(vp), v.ctypes.data_as(vp)), "coo")
+        s.set_field(L.PRES, F["pres"])
+        s.apply_A(L.TMP, L.PRES)
+        assert np.abs(s.get_field(L.TMP) - F["Ax"]).max() < 1e-13
+        b = F["Ax"].copy()  # in the range of the singular operator
+        s.set_field(L.TMP, b)
+        s.set_field(L.PRES, np.zeros_like(b))
+        it, rs = ctypes.c_int(), ctypes.c_int()
+        e, e0 = ctypes.c_double(), ctypes.c_double()
+        L.check(s.L.cup2d_poisson_solve(s._ctx, 1e-9, 0.0, 100, 1000, ctypes.byref(it), ctypes.byref(rs), ctypes.byref(e),
+                                        ctypes.byref(e0)), "solve")
+        x = s.get_field(L.PRES)
+        assert e.value <= 1e-9 and 0 < it.value < 1000
+        assert np.abs(b.ravel() - A @ x.ravel()).max() <= 1.05e-9
+        d = x - F["pres"]
+        assert np.abs(d - d.mean()).max() < 1e-6  # the solution up to the constant
+
+
 @pytest.mark.gpu
 def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
     from cup2d_amd import lib as L

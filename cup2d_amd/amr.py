@@ -204,6 +204,13 @@ class AmrSimulation:
         _l.check(self.L.cup2d_download_slab(self._ctx, field, a.ctypes.data_as(ctypes.c_void_p)), "download_slab")
         return a.reshape(self.grid.nblocks, 64, 2) if dim == 2 else a
 
+    def set_math(self, strict):
+        _l.check(self.L.cup2d_set_math(self._ctx, _l.MATH_STRICT if strict else _l.MATH_FAST), "set_math")
+
+    def advect_diffuse_rhs(self, dt):
+        """prepare0 / computeA<VectorLab>(KernelAdvectDiffuse(), var.vel, 2) / fillcases (main.cpp:6611-6617): tmpV"""
+        _l.check(self.L.cup2d_advect_diffuse_rhs(self._ctx, self.nu, float(dt), _l.BLOCKS_ALL), "advect_diffuse_rhs")
+
     def laplacian_sub(self):
         """prepare0 / computeA<ScalarLab>(pressure_rhs1(), var.pold, 1) / fillcases (main.cpp:7022-7027)"""
         _l.check(self.L.cup2d_laplacian_sub(self._ctx, _l.BLOCKS_ALL), "laplacian_sub")

@@ -20,6 +20,7 @@
 // One wave per block as everywhere else; the 32 ghost cells of the cross are computed by lanes 0..31.  The
 // irregular sides gather from other blocks through global memory -- this is the first, parity-first version of
 // the AMR path; its tuning follows the uniform path's.
+#include "advect_tile.h"
 #include "block.h"
 
 namespace cup2d {
@@ -237,6 +238,235 @@ __global__ __launch_bounds__(WG) void k_amr_fillcases(double *__restrict__ y, Am
   }
 }
 
+// ---- halo 3: the tile of KernelAdvectDiffuse (Stencil{-3,-3,4,4,true}, main.cpp:5442) -----------------------------
+// Closed forms of the CROSS ghosts of BlockLab::load/post_load for this stencil (use_averages = true), derived from
+// and pinned against a literal transcription of the reference (oracle/amr_lab.py, oracle/amr.py lab3_cross):
+//   wall / same / finer as for halo 1, three layers; on W/E faces the first of every four rows of a finer neighbour
+//   pairs fine rows 0 and 2 (main.cpp:2528-2531)
+//   coarser, layers 1-2: the halo-1 tangential quadratic, then LI (layer 1) / LE (layer 2) with the two interior cells
+//   coarser, layer 3   : TestInterp (main.cpp:2219-2230) on the 3x3 coarse cells around the ghost cell -- read from
+//                        COMPONENT 0 for both components (main.cpp:2753-2763 passes `Test` without the component
+//                        offset; parity is with the reference as it is).  The coarse cell one step beyond the outer end
+//                        of the block's span lies across the coarse neighbour's tangential side: a wall (mirrored;
+//                        x-walls negate component 0), a block of the coarse level (its cell) or of this level (2x2 mean).
+static __device__ __forceinline__ double amr_LE(double a, double b, double c) {  // main.cpp:2211-2218
+  const double kappa = ((4.0 / 15.0) * a + (6.0 / 15.0) * c) + (-10.0 / 15.0) * b;
+  const double lambda = (b - c) - kappa;
+  return (9.0 * kappa + 3.0 * lambda) + c;
+}
+
+// tangential quadratic through the four coarse cells cc[] of the span at fine position q (main.cpp:2797-2846)
+static __device__ __forceinline__ double amr_tangential(const double (&cc)[4], int q) {
+  const int qq = q >> 1;
+  const double c1 = cc[qq];
+  double d1, d2;
+  if (qq == 0) {
+    d1 = (-0.5 * cc[2] - 1.5 * cc[0]) + 2.0 * cc[1];
+    d2 = (cc[2] + cc[0]) - 2.0 * cc[1];
+  } else if (qq == 3) {
+    d1 = (0.5 * cc[1] + 1.5 * cc[3]) - 2.0 * cc[2];
+    d2 = (cc[1] + cc[3]) - 2.0 * cc[2];
+  } else {
+    d1 = 0.5 * (cc[qq + 1] - cc[qq - 1]);
+    d2 = (cc[qq + 1] + cc[qq - 1]) - 2.0 * cc[qq];
+  }
+  const double dy = -0.25;
+  return (q & 1) ? c1 - dy * d1 + (0.5 * dy * dy) * d2 : c1 + dy * d1 + (0.5 * dy * dy) * d2;
+}
+
+// ghost (side s, layer k = 0 nearest, position q) of block b of the vector field f
+static __device__ double2 amr_ghost3(const double2 *__restrict__ f, const AmrDev &T, int b, int s, int k, int q,
+                                     double2 e1, double2 e2) {
+  const int kind = T.kind[4 * b + s];
+  const int n0 = T.nbr2[(4 * b + s) * 2], n1 = T.nbr2[(4 * b + s) * 2 + 1];
+  double2 r;
+  if (kind == AMR_WALL) {  // VectorLab::applyBCface main.cpp:3131-3204
+    r.x = s < 2 ? -e1.x : e1.x;
+    r.y = s < 2 ? e1.y : -e1.y;
+    return r;
+  }
+  if (kind == AMR_SAME) {
+    const int cell = s == 0 ? q * BS + 7 - k : s == 1 ? q * BS + k : s == 2 ? (7 - k) * BS + q : k * BS + q;
+    return f[(size_t)n0 * BC + cell];
+  }
+  if (kind == AMR_FINE) {
+    const int a = q >> 2, t = q & 3;
+    const double2 *fb = f + (size_t)(a ? n1 : n0) * BC;
+    double2 q00, q10, q01, q11;
+    if (s < 2) {
+      const int c0 = s == 1 ? 2 * k : 6 - 2 * k;
+      const int y0 = 2 * t, y1 = t == 0 ? 2 : 2 * t + 1;
+      q00 = fb[y0 * BS + c0]; q10 = fb[y1 * BS + c0]; q01 = fb[y0 * BS + c0 + 1]; q11 = fb[y1 * BS + c0 + 1];
+    } else {
+      const int y = s == 3 ? 2 * k : 6 - 2 * k;
+      q00 = fb[y * BS + 2 * t]; q10 = fb[(y + 1) * BS + 2 * t]; q01 = fb[y * BS + 2 * t + 1]; q11 = fb[(y + 1) * BS + 2 * t + 1];
+    }
+    r.x = (q00.x + q10.x + q01.x + q11.x) / 4;
+    r.y = (q00.y + q10.y + q01.y + q11.y) / 4;
+    return r;
+  }
+  // ---- coarser neighbour ----
+  const int half = T.half[4 * b + s];
+  const double2 *cb = f + (size_t)n0 * BC;
+  if (k < 2) {
+    double ccx[4], ccy[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int jj = 4 * half + j;
+      const double2 v = cb[s == 0 ? jj * BS + 7 : s == 1 ? jj * BS : s == 2 ? 7 * BS + jj : jj];
+      ccx[j] = v.x;
+      ccy[j] = v.y;
+    }
+    const double tx = amr_tangential(ccx, q), ty = amr_tangential(ccy, q);
+    if (k == 0) { r.x = amr_LI(tx, e1.x, e2.x); r.y = amr_LI(ty, e1.y, e2.y); }
+    else { r.x = amr_LE(tx, e1.x, e2.x); r.y = amr_LE(ty, e1.y, e2.y); }
+    return r;
+  }
+  // layer 3: 3x3 coarse cells (component 0) around (Xc, Yc) in the coarse neighbour's cell coordinates
+  const int tside = s < 2 ? (half == 0 ? 2 : 3) : (half == 0 ? 0 : 1);  // the outer end of the span
+  const int ekind = T.kind[4 * n0 + tside];
+  const int en0 = T.nbr2[(4 * n0 + tside) * 2], en1 = T.nbr2[(4 * n0 + tside) * 2 + 1];
+  const auto coarse0 = [&](int X, int Y) -> double {
+    if (X >= 0 && X < BS && Y >= 0 && Y < BS) return cb[Y * BS + X].x;
+    if (ekind == AMR_WALL) {
+      if (s < 2) return cb[min(max(Y, 0), 7) * BS + X].x;  // y-wall: component 0 copied
+      return -cb[Y * BS + min(max(X, 0), 7)].x;            // x-wall: component 0 negated
+    }
+    if (ekind == AMR_SAME) return f[(size_t)en0 * BC + ((Y + BS) % BS) * BS + ((X + BS) % BS)].x;
+    if (ekind == AMR_FINE) {  // blocks of this block's level: FillCoarseVersion's 2x2 mean (main.cpp:2958-2996)
+      if (s < 2) {
+        const double2 *eb = f + (size_t)(s == 0 ? en1 : en0) * BC;
+        const int Xc = X - (s == 0 ? 4 : 0), y0 = Y < 0 ? 6 : 0;
+        return (eb[y0 * BS + 2 * Xc].x + eb[(y0 + 1) * BS + 2 * Xc].x + eb[y0 * BS + 2 * Xc + 1].x + eb[(y0 + 1) * BS + 2 * Xc + 1].x) / 4;
+      }
+      const double2 *eb = f + (size_t)(s == 2 ? en1 : en0) * BC;
+      const int Yc = Y - (s == 2 ? 4 : 0), x0 = X < 0 ? 6 : 0;
+      return (eb[2 * Yc * BS + x0].x + eb[(2 * Yc + 1) * BS + x0].x + eb[2 * Yc * BS + x0 + 1].x + eb[(2 * Yc + 1) * BS + x0 + 1].x) / 4;
+    }
+    return 0.0;  // two levels coarser across the corner: the reference reads an unset cell there
+  };
+  int Xc, Yc;
+  double dx, dy;
+  if (s < 2) {
+    Xc = s == 1 ? 1 : 6;
+    Yc = 4 * half + (q >> 1);
+    dx = s == 1 ? -0.25 : 0.25;
+    dy = 0.25 * (2 * (q & 1) - 1);
+  } else {
+    Yc = s == 3 ? 1 : 6;
+    Xc = 4 * half + (q >> 1);
+    dy = s == 3 ? -0.25 : 0.25;
+    dx = 0.25 * (2 * (q & 1) - 1);
+  }
+  double C[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i][j] = coarse0(Xc - 1 + i, Yc - 1 + j);
+  const double dudx = 0.5 * (C[2][1] - C[0][1]);
+  const double dudy = 0.5 * (C[1][2] - C[1][0]);
+  const double dudxdy = 0.25 * ((C[0][0] + C[2][2]) - (C[2][0] + C[0][2]));
+  const double dudx2 = (C[0][1] + C[2][1]) - 2.0 * C[1][1];
+  const double dudy2 = (C[1][0] + C[1][2]) - 2.0 * C[1][1];
+  r.x = (C[1][1] + (dx * dudx + dy * dudy)) + (((0.5 * dx * dx) * dudx2 + (0.5 * dy * dy) * dudy2) + (dx * dy) * dudxdy);
+  r.y = r.x;
+  return r;
+}
+
+// tmpV = KernelAdvectDiffuse(vel) on every block of the adapted grid + its face arrays dfac (edge - ghost) on the
+// coarse-fine faces (main.cpp:5504-5570); faces2: [nblocks][4][8][2]
+template <class W>
+__global__ __launch_bounds__(WG) void k_amr_advect(const double2 *__restrict__ vel, double2 *__restrict__ out, AmrDev T,
+                                                   double *__restrict__ faces2, int nblocks, double nu, double dt) {
+  __shared__ AdvectLds lds[WPG];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  AdvectLds &L = lds[wave];
+  RimSlot rim;
+  rim.init(L, lane);
+  const int ix = lane & 7, iy = lane >> 3;
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    L.lab[(iy + 3) * LABS + ix + 3] = vel[(size_t)b * BC + lane];
+    wave_lds_sync();
+    double2 g[4];
+    if (lane < 24) {
+      const int k = lane >> 3, q = lane & 7;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        // the block's edge cell and the next one inwards at position q of side s
+        const int e1 = s == 0 ? (q + 3) * LABS + 3 : s == 1 ? (q + 3) * LABS + 10 : s == 2 ? 3 * LABS + q + 3 : 10 * LABS + q + 3;
+        const int e2 = s == 0 ? e1 + 1 : s == 1 ? e1 - 1 : s == 2 ? e1 + LABS : e1 - LABS;
+        g[s] = amr_ghost3(vel, T, b, s, k, q, L.lab[e1], L.lab[e2]);
+      }
+    }
+    wave_lds_sync();
+    if (lane < 24) {
+      const int k = lane >> 3, q = lane & 7;
+      L.lab[(q + 3) * LABS + 2 - k] = g[0];
+      L.lab[(q + 3) * LABS + 11 + k] = g[1];
+      L.lab[(2 - k) * LABS + q + 3] = g[2];
+      L.lab[(11 + k) * LABS + q + 3] = g[3];
+    }
+    wave_lds_sync();
+    const double h = T.h0 / (double)(1 << T.level[b]);
+    const double dfac = nu * dt, afac = -dt * h;  // main.cpp:5446-5447
+    // face arrays before the tile's scratch is reused: nearest ghost layer and edge cell, both components
+    if (lane < 32) {
+      const int s = lane >> 3, q = lane & 7;
+      if (T.kind[4 * b + s] >= AMR_COARSE) {
+        const int e1 = s == 0 ? (q + 3) * LABS + 3 : s == 1 ? (q + 3) * LABS + 10 : s == 2 ? 3 * LABS + q + 3 : 10 * LABS + q + 3;
+        const int gi = s == 0 ? e1 - 1 : s == 1 ? e1 + 1 : s == 2 ? e1 - LABS : e1 + LABS;
+        const double2 ed = L.lab[e1], gh = L.lab[gi];
+        double *fa = faces2 + ((size_t)(4 * b + s) * BS + q) * 2;
+        fa[0] = dfac * (ed.x - gh.x);
+        fa[1] = dfac * (ed.y - gh.y);
+      }
+    }
+    const double2 r = advect_cell<W>(L, rim, lane, afac, dfac);
+    out[(size_t)b * BC + lane] = r;
+    wave_lds_sync();
+  }
+}
+
+// fillcases with dim = 2 (main.cpp:1767-1849): as k_amr_fillcases, plus the reference's own arithmetic slip -- fillcase1
+// runs once per received face (two per coarse face) and its memset (main.cpp:1660, 1668) clears entries 0..8 of the 16
+// only, so entries 9..15 (position 4 component 1, positions 5..7) are added a SECOND time.
+__global__ __launch_bounds__(WG) void k_amr_fillcases2(double2 *__restrict__ y, AmrDev T, const double *__restrict__ faces2,
+                                                       int nblocks) {
+  __shared__ double2 blk[WPG][BC];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double2 *B = blk[wave];
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    const int k0 = T.kind[4 * b + 0], k1 = T.kind[4 * b + 1], k2 = T.kind[4 * b + 2], k3 = T.kind[4 * b + 3];
+    if (k0 != AMR_FINE && k1 != AMR_FINE && k2 != AMR_FINE && k3 != AMR_FINE) continue;  // wave-uniform
+    B[lane] = y[(size_t)b * BC + lane];
+    wave_lds_sync();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      if (lane < 16) {
+        const int s = 2 * pass + (lane >> 3), q = lane & 7;
+        if (T.kind[4 * b + s] == AMR_FINE) {
+          const int fb = T.nbr2[(4 * b + s) * 2 + (q >> 2)], qq = q & 3;
+          const double *ff = faces2 + (size_t)(4 * fb + (s ^ 1)) * BS * 2;
+          const double *cf = faces2 + ((size_t)(4 * b + s) * BS + q) * 2;
+          double cx = cf[0], cy = cf[1];
+          cx += ff[2 * (2 * qq)] + ff[2 * (2 * qq + 1)];
+          cy += ff[2 * (2 * qq) + 1] + ff[2 * (2 * qq + 1) + 1];
+          const int cell = s == 0 ? q * BS : s == 1 ? q * BS + 7 : s == 2 ? q : 7 * BS + q;
+          double2 v = B[cell];
+          v.x += cx;
+          v.y += cy;
+          if (2 * q >= 9) v.x += cx;      // entries 9..15 once more
+          if (2 * q + 1 >= 9) v.y += cy;
+          B[cell] = v;
+        }
+      }
+      wave_lds_sync();
+    }
+    y[(size_t)b * BC + lane] = B[lane];
+    wave_lds_sync();
+  }
+}
+
 static AmrDev amr_dev(const cup2d_ctx *c) {
   AmrDev T;
   T.kind = c->amr.d_kind; T.nbr2 = c->amr.d_nbr2; T.half = c->amr.d_half; T.level = c->amr.d_level;
@@ -279,4 +509,20 @@ int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const 
   return CUP2D_OK;
 }
 
+}  // namespace cup2d
+
+namespace cup2d {
+// tmpV = KernelAdvectDiffuse(vel) with the flux correction (main.cpp:6611-6617 / 6627-6633)
+int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt) {
+  const AmrDev T = amr_dev(c);
+  if (c->math == CUP2D_MATH_STRICT)
+    hipLaunchKernelGGL(k_amr_advect<WenoStrict>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV,
+                       T, c->amr.d_faces2, c->nblocks, nu, dt);
+  else
+    hipLaunchKernelGGL(k_amr_advect<WenoFast>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV, T,
+                       c->amr.d_faces2, c->nblocks, nu, dt);
+  hipLaunchKernelGGL(k_amr_fillcases2, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)tmpV, T, c->amr.d_faces2, c->nblocks);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
 }  // namespace cup2d

@@ -213,7 +213,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
   (void)hipFree(c->amr.d_level); (void)hipFree(c->amr.d_kind); (void)hipFree(c->amr.d_nbr2); (void)hipFree(c->amr.d_half);
-  (void)hipFree(c->amr.d_faces);
+  (void)hipFree(c->amr.d_faces); (void)hipFree(c->amr.d_faces2);
   (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
   (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -340,7 +340,7 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   cup2d::AmrTopo &A = c->amr;
-  (void)hipFree(A.d_level); (void)hipFree(A.d_kind); (void)hipFree(A.d_nbr2); (void)hipFree(A.d_half); (void)hipFree(A.d_faces);
+  (void)hipFree(A.d_level); (void)hipFree(A.d_kind); (void)hipFree(A.d_nbr2); (void)hipFree(A.d_half); (void)hipFree(A.d_faces); (void)hipFree(A.d_faces2);
   A = cup2d::AmrTopo();
   CUP2D_HIP_CHECK(hipMalloc(&A.d_level, sizeof(int32_t) * nb));
   CUP2D_HIP_CHECK(hipMalloc(&A.d_kind, sizeof(int32_t) * nb * 4));
@@ -352,6 +352,8 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   CUP2D_HIP_CHECK(hipMemcpy(A.d_nbr2, nbr2, sizeof(int32_t) * nb * 8, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(A.d_half, half, sizeof(int32_t) * nb * 4, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemset(A.d_faces, 0, sizeof(double) * nb * 4 * BS));
+  CUP2D_HIP_CHECK(hipMalloc(&A.d_faces2, sizeof(double) * nb * 4 * BS * 2));
+  CUP2D_HIP_CHECK(hipMemset(A.d_faces2, 0, sizeof(double) * nb * 4 * BS * 2));
   A.h0 = h0;
   int lmax = 0;
   for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;
@@ -373,7 +375,8 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
 // ---- block operators --------------------------------------------------------------------------
 int cup2d_advect_diffuse_rhs(cup2d_ctx *c, double nu, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
+  AMR_ALL_BLOCKS(c, phase);
+  if (c->amr.active) return amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   return launch_advect(c, c->d_field[CUP2D_VEL], nullptr, c->d_field[CUP2D_TMPV], 0, nu, dt, 0.0, first, count);

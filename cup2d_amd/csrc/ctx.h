@@ -94,6 +94,7 @@ struct AmrTopo {
   int32_t *d_nbr2 = nullptr;     // [nblocks][4][2] neighbour block(s): one, or the two finer ones along the face
   int32_t *d_half = nullptr;     // [nblocks][4]  coarser neighbour: which half of its face this block touches
   double *d_faces = nullptr;     // [nblocks][4][8] fluxes recorded by the functors (BlockCase::d, main.cpp:513-517)
+  double *d_faces2 = nullptr;    // [nblocks][4][8][2] the same for vector functors (KernelAdvectDiffuse)
 };
 
 }  // namespace cup2d
@@ -237,6 +238,7 @@ int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded,
 int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract);
 int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt);
 int amr_vorticity(cup2d_ctx *c, const double *vel, double *out);
+int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt);
 int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);

@@ -268,3 +268,181 @@ def pressure_correction_amr(grid, pres, dt):
         out[b, ..., 0] = pFac * (m[1:-1, 2:] - m[1:-1, :-2])
         out[b, ..., 1] = pFac * (m[2:, 1:-1] - m[:-2, 1:-1])
     return out.reshape(nb, BS * BS, 2)
+
+
+# ---- halo-3 vector lab (KernelAdvectDiffuse, Stencil{-3,-3,4,4,true}): closed forms of the cross ghosts -------------
+def LE(a, b, c):
+    """main.cpp:2211-2218"""
+    kappa = ((4.0 / 15.0) * a + (6.0 / 15.0) * c) + (-10.0 / 15.0) * b
+    lam = (b - c) - kappa
+    return (9.0 * kappa + 3.0 * lam) + c
+
+
+def _test_interp(C, dx, dy):
+    """TestInterp main.cpp:2219-2230 on a 3x3 stencil C[i][j] (i along x)"""
+    dudx = 0.5 * (C[2][1] - C[0][1])
+    dudy = 0.5 * (C[1][2] - C[1][0])
+    dudxdy = 0.25 * ((C[0][0] + C[2][2]) - (C[2][0] + C[0][2]))
+    dudx2 = (C[0][1] + C[2][1]) - 2.0 * C[1][1]
+    dudy2 = (C[1][0] + C[1][2]) - 2.0 * C[1][1]
+    return (C[1][1] + (dx * dudx + dy * dudy)) + (((0.5 * dx * dx) * dudx2 + (0.5 * dy * dy) * dudy2) + (dx * dy) * dudxdy)
+
+
+def lab3_cross(grid, vel, b):
+    """The 14x14x2 tile of block b with the CROSS ghosts (3 layers per side) as BlockLab::load/post_load leaves them
+    (corners are not read by KernelAdvectDiffuse and stay NaN here).  Closed forms derived from the literal
+    transcription oracle/amr_lab.py, pinned against the reference's own tiles (tests/test_amr.py):
+      wall    edge cell, wall-normal component negated                                    (main.cpp:3131-3204)
+      same    the neighbour's cells
+      finer   2x2 means; on W/E faces the first of every four rows pairs fine rows 0 and 2 (main.cpp:2528-2531)
+      coarser layers 1, 2: quadratic ALONG the face through the coarse cells of the block's span, then LI / LE
+              ACROSS it with the two interior cells; layer 3: TestInterp on the 3x3 coarse cells around it -- taken
+              from component 0 for BOTH components (main.cpp:2753-2763 passes Test without the component offset)
+    The coarse cell one step beyond the span's outer end comes from the block across the coarse neighbour's
+    tangential side: wall (mirrored, x-walls negate component 0), one level coarser (its cell), or this level (2x2 mean)."""
+    own = vel[b].reshape(BS, BS, 2)
+    m = np.full((BS + 6, BS + 6, 2), np.nan)
+    m[3:11, 3:11] = own
+    l, bi, bj = (int(v) for v in grid.blocks[b])
+
+    def setg(side, k, q, val):  # layer k = 0 nearest
+        if side == W:
+            m[3 + q, 2 - k] = val
+        elif side == E:
+            m[3 + q, 11 + k] = val
+        elif side == S:
+            m[2 - k, 3 + q] = val
+        else:
+            m[11 + k, 3 + q] = val
+
+    for side in (W, E, S, N):
+        nb = grid.neighbour(b, side)
+        for q in range(8):
+            e1 = own[q, 0] if side == W else own[q, 7] if side == E else own[0, q] if side == S else own[7, q]
+            e2 = own[q, 1] if side == W else own[q, 6] if side == E else own[1, q] if side == S else own[6, q]
+            if nb[0] == "wall":
+                v = e1 * (np.array([-1.0, 1.0]) if side < 2 else np.array([1.0, -1.0]))
+                for k in range(3):
+                    setg(side, k, q, v)
+            elif nb[0] == "same":
+                o = vel[nb[1]].reshape(BS, BS, 2)
+                for k in range(3):
+                    setg(side, k, q, o[q, 7 - k] if side == W else o[q, k] if side == E else o[7 - k, q] if side == S else o[k, q])
+            elif nb[0] == "fine":
+                a, t = q >> 2, q & 3
+                f = vel[nb[1 + a]].reshape(BS, BS, 2)
+                for k in range(3):
+                    if side < 2:
+                        c0 = 2 * k if side == E else 6 - 2 * k
+                        y0, y1 = (0, 2) if t == 0 else (2 * t, 2 * t + 1)
+                        v = (f[y0, c0] + f[y1, c0] + f[y0, c0 + 1] + f[y1, c0 + 1]) / 4
+                    else:
+                        y = 2 * k if side == N else 6 - 2 * k
+                        v = (f[y, 2 * t] + f[y + 1, 2 * t] + f[y, 2 * t + 1] + f[y + 1, 2 * t + 1]) / 4
+                    setg(side, k, q, v)
+            else:
+                cb = vel[nb[1]].reshape(BS, BS, 2)
+                half = (bj % 2) if side < 2 else (bi % 2)
+                # layers 1, 2
+                if side < 2:
+                    col = 7 if side == W else 0
+                    cc = cb[4 * half:4 * half + 4, col]
+                else:
+                    row = 7 if side == S else 0
+                    cc = cb[row, 4 * half:4 * half + 4]
+                tq = np.array([_tangential(cc[:, d])[q] for d in (0, 1)])
+                setg(side, 0, q, np.array([LI(tq[d], e1[d], e2[d]) for d in (0, 1)]))
+                setg(side, 1, q, np.array([LE(tq[d], e1[d], e2[d]) for d in (0, 1)]))
+                # layer 3: 3x3 coarse stencil, component 0
+                tside = (S if half == 0 else N) if side < 2 else (W if half == 0 else E)  # outer end of the span
+                ext = grid.neighbour(nb[1], tside)
+
+                def coarse0(X, Y):
+                    """component 0 of the coarse cell at (X, Y) in the coarse neighbour's own cell coordinates"""
+                    if 0 <= X < BS and 0 <= Y < BS:
+                        return cb[Y, X, 0]
+                    if ext[0] == "wall":
+                        if side < 2:
+                            return cb[min(max(Y, 0), 7), X, 0]       # y-wall: component 0 copied
+                        return -cb[Y, min(max(X, 0), 7), 0]          # x-wall: component 0 negated
+                    if ext[0] == "same":                              # same level as the coarse neighbour
+                        eb = vel[ext[1]].reshape(BS, BS, 2)
+                        return eb[Y % BS, X % BS, 0]
+                    if ext[0] == "fine":                              # this block's level: 2x2 mean
+                        if side < 2:
+                            eb = vel[ext[1 + (1 if side == W else 0)]].reshape(BS, BS, 2)
+                            Xc = X - (4 if side == W else 0)
+                            y0 = 6 if Y < 0 else 0
+                            return (eb[y0, 2 * Xc, 0] + eb[y0 + 1, 2 * Xc, 0] + eb[y0, 2 * Xc + 1, 0] + eb[y0 + 1, 2 * Xc + 1, 0]) / 4
+                        eb = vel[ext[1 + (1 if side == S else 0)]].reshape(BS, BS, 2)
+                        Yc = Y - (4 if side == S else 0)
+                        x0 = 6 if X < 0 else 0
+                        return (eb[2 * Yc, x0, 0] + eb[2 * Yc + 1, x0, 0] + eb[2 * Yc, x0 + 1, 0] + eb[2 * Yc + 1, x0 + 1, 0]) / 4
+                    return np.nan
+
+                if side < 2:
+                    Xc = 1 if side == E else 6
+                    Yc = 4 * half + (q >> 1)
+                    dx = -0.25 if side == E else 0.25
+                    dy = 0.25 * (2 * (q & 1) - 1)
+                else:
+                    Yc = 1 if side == N else 6
+                    Xc = 4 * half + (q >> 1)
+                    dy = -0.25 if side == N else 0.25
+                    dx = 0.25 * (2 * (q & 1) - 1)
+                C = [[coarse0(Xc - 1 + i, Yc - 1 + j) for j in range(3)] for i in range(3)]
+                v3 = _test_interp(C, dx, dy)
+                setg(side, 2, q, np.array([v3, v3]))
+    return m
+
+
+def advect_diffuse_amr(grid, vel, nu, dt):
+    """KernelAdvectDiffuse (main.cpp:5441-5572) on the adapted grid with its flux correction (prepare0 / fillcases with
+    dim = 2, main.cpp:6611-6617): per block the functor on the interpolated tile, face arrays dfac (edge - ghost) on
+    every coarse-fine face, then the coarse side's edge cells += own face + the two fine faces."""
+    import ctypes
+    from . import oracle as O
+    lib = O.lib()
+    nb = len(grid.blocks)
+    out = np.empty((nb, BS, BS, 2))
+    faces = {}
+    dfac = nu * dt
+    dp = ctypes.POINTER(ctypes.c_double)
+    for b in range(nb):
+        m = np.ascontiguousarray(np.nan_to_num(lab3_cross(grid, vel, b), nan=0.0))  # corners are never read
+        o = np.empty((BS, BS, 2))
+        lib.oracle_advect_diffuse_lab(m.ctypes.data_as(dp), ctypes.c_double(grid.h(int(grid.blocks[b][0]))), ctypes.c_double(nu),
+                                      ctypes.c_double(dt), o.ctypes.data_as(dp))
+        out[b] = o
+        for side in (W, E, S, N):
+            if grid.neighbour(b, side)[0] in ("coarse", "fine"):
+                if side == W:
+                    ed, gh = m[3:11, 3], m[3:11, 2]
+                elif side == E:
+                    ed, gh = m[3:11, 10], m[3:11, 11]
+                elif side == S:
+                    ed, gh = m[3, 3:11], m[2, 3:11]
+                else:
+                    ed, gh = m[10, 3:11], m[11, 3:11]
+                faces[(b, side)] = dfac * (ed - gh)  # (8, 2)
+    for (b, side), fl in list(faces.items()):
+        nbh = grid.neighbour(b, side)
+        if nbh[0] != "coarse":
+            continue
+        l, bi, bj = (int(v) for v in grid.blocks[b])
+        half = (bj % 2) if side < 2 else (bi % 2)
+        cf = faces[(nbh[1], side ^ 1)]
+        for q in range(4):
+            cf[4 * half + q] += fl[2 * q] + fl[2 * q + 1]
+    # fillcase1 runs once per RECEIVED face, i.e. twice per coarse face (one per fine child), and for dim = 2 its
+    # memset(&CoarseFace[i2], 0, dim * sizeof(Real)) (main.cpp:1660, 1668) clears entries 0..8 only: the second run adds
+    # entries 9..15 (position 4 component 1 and positions 5..7) AGAIN.  Parity is with the reference as it is.
+    again = (2 * np.arange(8)[:, None] + np.arange(2)[None, :]) >= 9
+    for pass_sides in ((W, E), (S, N)):
+        for (b, side), fl in faces.items():
+            if side not in pass_sides or grid.neighbour(b, side)[0] != "fine":
+                continue
+            edge = out[b][:, 0] if side == W else out[b][:, 7] if side == E else out[b][0, :] if side == S else out[b][7, :]
+            edge += fl
+            edge[again] += fl[again]
+    return out.reshape(nb, BS * BS, 2)

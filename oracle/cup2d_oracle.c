@@ -124,6 +124,30 @@ void oracle_advect_diffuse_rhs(int nx, int ny, double h, double nu, double dt, c
     }
 }
 
+/* the same functor on ONE ghosted tile (14 x 14 x 2, cross cells only are read): the form KernelAdvectDiffuse has in
+ * the reference, used for adapted grids where the tile comes from BlockLab's coarse-fine interpolation (oracle/amr.py) */
+void oracle_advect_diffuse_lab(const double *lab, double h, double nu, double dt, double *out) {
+  const double dfac = nu * dt, afac = -dt * h;
+  const int nm = 14;
+  for (int iy = 0; iy < 8; iy++)
+    for (int ix = 0; ix < 8; ix++) {
+      double sx[2][7], sy[2][7];
+      for (int c = 0; c < 2; c++)
+        for (int k = -3; k <= 3; k++) {
+          sx[c][k + 3] = lab[2 * (nm * (iy + 3) + ix + 3 + k) + c];
+          sy[c][k + 3] = lab[2 * (nm * (iy + 3 + k) + ix + 3) + c];
+        }
+      const double u = sx[0][3], v = sx[1][3];
+      double dudx = derivative(u, sx[0][0], sx[0][1], sx[0][2], u, sx[0][4], sx[0][5], sx[0][6]);
+      double dudy = derivative(v, sy[0][0], sy[0][1], sy[0][2], u, sy[0][4], sy[0][5], sy[0][6]);
+      double dvdx = derivative(u, sx[1][0], sx[1][1], sx[1][2], v, sx[1][4], sx[1][5], sx[1][6]);
+      double dvdy = derivative(v, sy[1][0], sy[1][1], sy[1][2], v, sy[1][4], sy[1][5], sy[1][6]);
+      size_t o = 2 * ((size_t)iy * 8 + ix);
+      out[o] = afac * (u * dudx + v * dudy) + dfac * (sx[0][4] + sx[0][2] + sy[0][4] + sy[0][2] - 4 * u);
+      out[o + 1] = afac * (u * dvdx + v * dvdy) + dfac * (sx[1][4] + sx[1][2] + sy[1][4] + sy[1][2] - 4 * v);
+    }
+}
+
 /* ---- a4: RK2 glue (main.cpp:6607-6642): vold = vel; V = Vold + 0.5*tmpV/h^2; V = Vold + tmpV/h^2.
  * stage1 (optional) receives the mid-point velocity. ---- */
 void oracle_rk2_advect_diffuse(int nx, int ny, double h, double nu, double dt, double *vel, double *stage1) {

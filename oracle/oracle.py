@@ -294,18 +294,20 @@ def ref_amr_functors(level_start, level_max, steps, rtol, ctol, nu=1e-3, max_ite
     (prepare0 / computeA / fillcases, main.cpp:7022-7027) and KernelVorticity.  Per block, sorted by (level, j, i):
     blocks (nb,3), pold, tmp_in, tmp_out (nb,64), vel (nb,64,2), vort (nb,64); chi, udef, prhs = pressure_rhs with its
     flux correction (main.cpp:7007-7013); pres, pcorr = pressureCorrectionKernel's tmpV (7178); Ax = the reference-assembled
-    Poisson matrix (main.cpp:7034-7113) applied to pres; dt, h0."""
+    Poisson matrix (main.cpp:7034-7113) applied to pres; lab3 = the 14x14x2 ghosted tile of vel that
+    KernelAdvectDiffuse sees, advdiff = its output with the flux correction (main.cpp:6611-6617); nu, dt, h0."""
     with tempfile.TemporaryDirectory() as d:
         _run_ref("amr", 8 << int(level_start), d, levelmax=int(level_max), rtol=float(rtol), ctol=float(ctol), steps=int(steps),
                  nu=float(nu), maxiter=int(max_iter), reps=-1)
-        a = np.fromfile(os.path.join(d, "blocks.functors")).reshape(-1, 3 + 192 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64)
+        a = np.fromfile(os.path.join(d, "blocks.functors")).reshape(-1, 3 + 192 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128)
         dt, h0 = np.fromfile(os.path.join(d, "functors_scalars"))
     a = a[np.argsort(a[:, 0] * 1e12 + a[:, 2] * 1e6 + a[:, 1])]
     o = 387
     return dict(blocks=a[:, :3].astype(np.int64), pold=a[:, 3:67], tmp_in=a[:, 67:131], tmp_out=a[:, 131:195],
                 vel=a[:, 195:323].reshape(-1, 64, 2), vort=a[:, 323:387], chi=a[:, o:o + 64],
                 udef=a[:, o + 64:o + 192].reshape(-1, 64, 2), prhs=a[:, o + 192:o + 256], pres=a[:, o + 256:o + 320],
-                pcorr=a[:, o + 320:o + 448].reshape(-1, 64, 2), Ax=a[:, o + 448:o + 512], dt=float(dt), h0=float(h0))
+                pcorr=a[:, o + 320:o + 448].reshape(-1, 64, 2), Ax=a[:, o + 448:o + 512], lab3=a[:, o + 512:o + 904].reshape(-1, 14, 14, 2),
+                advdiff=a[:, o + 904:o + 1032].reshape(-1, 64, 2), nu=float(nu), dt=float(dt), h0=float(h0))
 
 
 def ref_dump(vel, time=0.0):

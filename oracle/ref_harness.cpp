@@ -502,6 +502,19 @@ static int run_reference_main(int levelStart, double nu, double cfl, double tend
 }
 
 
+/* writes the ghosted tile BlockLab::load/post_load hands to KernelAdvectDiffuse (Stencil{-3,-3,4,4,true},
+ * main.cpp:5442) -- 14 x 14 x 2 doubles per block -- and then runs that functor: the stage-by-stage oracle of the
+ * halo-3 interpolation across coarse-fine faces */
+struct DumpLab3 {
+  Stencil stencil{-3, -3, 4, 4, true};
+  std::vector<double> *out;
+  std::vector<double> *outc = nullptr; /* the coarse array c (10 x 10 x 2), debugging aid */
+  void operator()(VectorLab *lab, Info *info) {
+    memcpy(out->data() + (size_t)info->id * 392, lab->m, 392 * sizeof(double));
+    if (outc) memcpy(outc->data() + (size_t)info->id * 200, lab->c, 200 * sizeof(double));
+  }
+};
+
 static void usage() {
   fprintf(stderr,
           "usage: ref_harness <mode> <levelStart> <dir> [key=value ...]\n"
@@ -602,9 +615,10 @@ int main(int argc, char **argv) {
         auto gs = [](double x, double y) { return 0.1 * std::cos(2.0 * x) - 0.2 * std::sin(4.0 * y + 1.0); };
         const size_t nb = var.vel->infos.size();
         /* + chi (64), udef (128), pressure_rhs out (64), pres (64), pressureCorrectionKernel out (128) */
-        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64; /* ... + A x (64) */
+        /* ... + A x (64) + lab3 of vel (392) + KernelAdvectDiffuse out with flux correction (128) */
+        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128;
         std::vector<double> out(nb * stride);
-        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64, o_ax = o_pc + 128;
+        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64, o_ax = o_pc + 128, o_lab = o_ax + 64, o_adv = o_lab + 392;
         sim.dt = dt > 0 ? dt : 0.01;
         for (size_t i = 0; i < nb; i++) {
           Info &I = var.pold->infos[i];
@@ -672,6 +686,26 @@ int main(int argc, char **argv) {
             for (int k = 0; k < 64; k++) out[i * stride + o_ax + k] = M->get_x()[i * 64 + k];
         }
 #endif
+        /* halo-3 vector lab of vel, then KernelAdvectDiffuse with its flux correction (main.cpp:6611-6617) */
+        {
+          std::vector<double> labs(nb * 392);
+          DumpLab3 dl;
+          dl.out = &labs;
+          std::vector<double> cs(nb * 200);
+          dl.outc = &cs;
+          computeA<VectorLab>(dl, var.vel, 2);
+          write_file(dir + "/blocks.labc", cs.data(), cs.size());
+          for (size_t i = 0; i < nb; i++)
+            memcpy(&out[i * stride + o_lab], &labs[i * 392], 392 * sizeof(double));
+          if (var.tmpV->UpdateFluxCorrection) {
+            prepare0(var.buf2, &var.tmpV->infos, &var.tmpV->all, &var.tmpV->tree, 2);
+            var.tmpV->UpdateFluxCorrection = false;
+          }
+          computeA<VectorLab>(KernelAdvectDiffuse(), var.vel, 2);
+          fillcases(var.buf2, &var.tmpV->tree, 2);
+          for (size_t i = 0; i < nb; i++)
+            for (int k = 0; k < 128; k++) out[i * stride + o_adv + k] = var.tmpV->infos[i].block[k];
+        }
         write_file(dir + "/blocks.functors", out.data(), out.size());
         fclose(meta);
         MPI_Finalize();

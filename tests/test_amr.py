@@ -32,6 +32,27 @@ def test_amr_oracle_bit_exact_vs_reference(oracle):
     assert seen == {(s, k) for s in range(4) for k in ("wall", "same", "coarse", "fine")}
 
 
+def test_amr_halo3_tile_and_advect_diffuse_vs_reference(oracle):
+    """KernelAdvectDiffuse's ghosted tile (Stencil{-3,-3,4,4,true}): the literal transcription of BlockLab
+    (oracle/amr_lab.py) reproduces the reference's 14x14x2 tiles completely, the closed forms (oracle/amr.py lab3_cross,
+    what csrc/amr.hip implements) on the cross the functor reads; then the functor with its dim-2 flux correction."""
+    from oracle import amr as A
+    from oracle import amr_lab as AL
+    cross = np.zeros((14, 14), bool)
+    cross[3:11, :] = True
+    cross[:, 3:11] = True
+    for name, F in _grid_cases(oracle):
+        g = A.AmrGrid(F["blocks"])
+        t = AL.Tree(F["blocks"])
+        lab = AL.BlockLab(2, (-3, -3, 4, 4, True), True)
+        flat = F["vel"].reshape(len(F["blocks"]), -1)
+        for b in range(len(g.blocks)):
+            assert np.array_equal(lab.load(t, flat, b), F["lab3"][b]), (name, b)
+            m = A.lab3_cross(g, F["vel"], b)
+            assert np.array_equal(m[cross], F["lab3"][b][cross]), (name, b)
+        assert np.array_equal(A.advect_diffuse_amr(g, F["vel"], float(F["nu"]), float(F["dt"])), F["advdiff"]), name
+
+
 def test_amr_topology_tables(oracle):
     """cup2d_amd.amr.AmrBlockGrid (product) against the oracle's neighbour logic; level jumps are 2:1"""
     from cup2d_amd import lib as L
@@ -136,6 +157,16 @@ def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
             s.set_field(L.PRES, F["pres"])
             s.pressure_correction(dt)
             assert np.array_equal(s.get_field(L.TMPV), F["pcorr"]), name
+            # KernelAdvectDiffuse on the interpolated halo-3 tile + its dim-2 flux correction (main.cpp:6611-6617)
+            s.nu = float(F["nu"])
+            s.set_field(L.VEL, F["vel"])
+            s.set_math(True)
+            s.advect_diffuse_rhs(dt)
+            assert np.array_equal(s.get_field(L.TMPV), F["advdiff"]), name
+            s.set_math(False)
+            s.advect_diffuse_rhs(dt)
+            fast = s.get_field(L.TMPV)
+            assert np.abs(fast - F["advdiff"]).max() <= 2e-13 * np.abs(F["advdiff"]).max() + 1e-18, name
             # dt uses the finest cell size (main.cpp:6580-6595)
             umax = np.abs(F["vel"]).max()
             hmin = s.grid.h(F["blocks"][:, 0].max())
@@ -149,7 +180,7 @@ def test_amr_unsupported_entry_points_say_so(gpu_lib):
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
     F = golden("amr_functors.npz")
     with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
-        assert s.L.cup2d_advect_diffuse_rk2(s._ctx, 1e-3, 1e-3) == -4  # CUP2D_ERR_UNSUPPORTED
+        assert s.L.cup2d_advect_diffuse_rk2(s._ctx, 1e-3, 1e-3) == -4  # CUP2D_ERR_UNSUPPORTED (the fused RK2 stages)
         assert b"adapted" in s.L.cup2d_last_error()
         it = ctypes.c_int()
         assert s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 10, 10, ctypes.byref(it), None, None, None) == -4

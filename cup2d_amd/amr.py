@@ -228,6 +228,23 @@ class AmrSimulation:
     def apply_A(self, dst, src):
         _l.check(self.L.cup2d_apply_A(self._ctx, dst, src), "apply_A")
 
+    def install_poisson_matrix(self):
+        """assemble the coarse-fine Poisson rows on the host (AmrBlockGrid.poisson_coo) and hand them to the library:
+        what the reference does after every regrid (main.cpp:7034-7113)"""
+        r, c, v = self.grid.poisson_coo()
+        vp = ctypes.c_void_p
+        _l.check(self.L.cup2d_set_matrix_coo(self._ctx, 0, len(v), r.ctypes.data_as(vp), c.ctypes.data_as(vp), v.ctypes.data_as(vp)),
+                 "set_matrix_coo")
+
+    def step(self, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000):
+        """one pass of the time-loop body on the (fixed) adapted grid: dt, RK2 WENO5 advect-diffuse with flux correction,
+        Poisson rhs, BiCGSTAB on the assembled operator, volume-weighted mean removal + projection (main.cpp:6576-7187
+        without adapt())"""
+        dt, it, e = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol), int(max_restarts), int(max_iter),
+                                   ctypes.byref(dt), ctypes.byref(it), ctypes.byref(e)), "step")
+        return dict(dt=dt.value, iters=it.value, err=e.value)
+
     def compute_dt(self):
         v = ctypes.c_double()
         _l.check(self.L.cup2d_compute_dt(self._ctx, self.nu, self.cfl, ctypes.byref(v)), "compute_dt")

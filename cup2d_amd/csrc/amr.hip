@@ -512,6 +512,117 @@ int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const 
 }  // namespace cup2d
 
 namespace cup2d {
+// ---- glue of the time step on an adapted grid: every block carries its own h ------------------------------------
+// MODE 0: y = x0 + t * (coef / (h * h))     RK stages, main.cpp:6618-6626 (coef 0.5), 6634-6642 (coef 1.0)
+// MODE 1: y += t * (1.0 / h / h)            projection, main.cpp:7180-7187
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_amr_axpy(double2 *__restrict__ y, const double2 *__restrict__ x0,
+                                                 const double2 *__restrict__ t, AmrDev T, int nblocks, double coef) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    const double h = T.h0 / (double)(1 << T.level[b]);
+    const double ih2 = MODE == 0 ? coef / (h * h) : 1.0 / h / h;
+    const size_t o = (size_t)b * BC + lane;
+    const double2 tv = t[o];
+    double2 v = MODE == 0 ? x0[o] : y[o];
+    if (MODE == 0) {
+      v.x = v.x + tv.x * ih2;
+      v.y = v.y + tv.y * ih2;
+    } else {
+      v.x += tv.x * ih2;
+      v.y += tv.y * ih2;
+    }
+    y[o] = v;
+  }
+}
+// partial sums of p * h^2 and of h^2 over the cells (main.cpp:7126-7135): slots 0 and 1 of the partials
+__global__ __launch_bounds__(WG) void k_amr_wsum(const double *__restrict__ p, AmrDev T, int nblocks,
+                                                 double *__restrict__ partials) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double acc[2] = {0.0, 0.0};
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    const double h = T.h0 / (double)(1 << T.level[b]);
+    const double vv = h * h;
+    acc[0] += p[(size_t)b * BC + lane] * vv;
+    acc[1] += vv;
+  }
+  workgroup_reduce_store<2, false>(acc, partials, 0);
+}
+__global__ __launch_bounds__(WG) void k_amr_wsum_final(const double *__restrict__ partials, int n, double *__restrict__ red) {
+  __shared__ double sm[2][WG];
+  double a = 0.0, w = 0.0;
+  for (int i = threadIdx.x; i < n; i += WG) {
+    a += partials[i];
+    w += partials[PSTRIDE + i];
+  }
+  sm[0][threadIdx.x] = a;
+  sm[1][threadIdx.x] = w;
+  __syncthreads();
+  for (int s = WG / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) red[0] = sm[0][0] / sm[1][0];  // avg = avg / avg1, main.cpp:7142
+}
+// MODE 0: p += -avg (main.cpp:7143-7148)   MODE 1: p += pold - avg (main.cpp:7166-7172)
+template <int MODE>
+__global__ __launch_bounds__(WG) void k_amr_shift(double *__restrict__ p, const double *__restrict__ pold,
+                                                  const double *__restrict__ red, size_t n) {
+  const double avg = red[0];
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    if (MODE == 0) p[i] += -avg;
+    else p[i] += pold[i] - avg;
+  }
+}
+
+// main.cpp:6607-6642 on an adapted grid: vold = vel; two stages of [KernelAdvectDiffuse + flux correction; V = Vold +
+// c tmpV / h^2] (the reference's own un-fused sequence: the face arrays need tmpV)
+int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
+  const AmrDev T = amr_dev(c);
+  const size_t bytes = (size_t)c->nblocks * BC * 2 * sizeof(double);
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_VOLD], c->d_field[CUP2D_VEL], bytes, hipMemcpyDeviceToDevice, c->stream));
+  for (int stage = 0; stage < 2; stage++) {
+    CUP2D_TRY(amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt));
+    hipLaunchKernelGGL(k_amr_axpy<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)c->d_field[CUP2D_VEL],
+                       (const double2 *)c->d_field[CUP2D_VOLD], (const double2 *)c->d_field[CUP2D_TMPV], T, c->nblocks,
+                       stage == 0 ? 0.5 : 1.0);
+  }
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+// main.cpp:7007-7027: tmp = pressure_rhs (+ flux correction); pold = pres; pres = 0; tmp -= Lap(pold) (+ flux correction)
+int amr_poisson_rhs(cup2d_ctx *c, double dt) {
+  CUP2D_TRY(amr_pressure_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], c->d_field[CUP2D_CHI], c->d_field[CUP2D_TMP], dt));
+  double *tmp = c->d_field[CUP2D_POLD];
+  c->d_field[CUP2D_POLD] = c->d_field[CUP2D_PRES];
+  c->d_field[CUP2D_PRES] = tmp;
+  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_field[CUP2D_PRES], 0, (size_t)c->ntotal * BC * sizeof(double), c->stream));
+  return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1);
+}
+// main.cpp:7120-7187 on an adapted grid: volume-weighted means, pressure gradient, V += tmpV / h / h
+int amr_project(cup2d_ctx *c, double dt) {
+  const AmrDev T = amr_dev(c);
+  const size_t n = (size_t)c->nblocks * BC;
+  int gs = (int)((n + WG - 1) / WG);
+  if (gs > c->grid) gs = c->grid;
+  double *pres = c->d_field[CUP2D_PRES], *pold = c->d_field[CUP2D_POLD];
+  for (int pass = 0; pass < 2; pass++) {
+    const int g = amr_grid(c);
+    hipLaunchKernelGGL(k_amr_wsum, dim3(g), dim3(WG), 0, c->stream, pres, T, c->nblocks, c->d_partials);
+    hipLaunchKernelGGL(k_amr_wsum_final, dim3(1), dim3(WG), 0, c->stream, c->d_partials, g, c->d_red);
+    if (pass == 0) hipLaunchKernelGGL(k_amr_shift<0>, dim3(gs), dim3(WG), 0, c->stream, pres, pold, c->d_red, n);
+    else hipLaunchKernelGGL(k_amr_shift<1>, dim3(gs), dim3(WG), 0, c->stream, pres, pold, c->d_red, n);
+  }
+  CUP2D_TRY(amr_pressure_correction(c, pres, c->d_field[CUP2D_TMPV], dt));
+  hipLaunchKernelGGL(k_amr_axpy<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)c->d_field[CUP2D_VEL], nullptr,
+                     (const double2 *)c->d_field[CUP2D_TMPV], T, c->nblocks, 1.0);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // tmpV = KernelAdvectDiffuse(vel) with the flux correction (main.cpp:6611-6617 / 6627-6633)
 int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt) {
   const AmrDev T = amr_dev(c);

@@ -397,7 +397,7 @@ int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, in
 }
 int cup2d_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
+  if (c->amr.active) return amr_advect_diffuse_rk2(c, nu, dt);
   for (int stage = 1; stage <= 2; stage++) {
     double *src = stage == 1 ? c->d_field[CUP2D_VEL] : c->d_vscratch;
     if (overlapped(c)) {  // inner blocks while the face strips are in flight (main.cpp:3035-3057)
@@ -441,7 +441,10 @@ int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
 }
 int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
+  if (c->amr.active) {
+    if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
+    return amr_poisson_rhs(c, dt);
+  }
   if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
   // pold = pres; pres = 0 (main.cpp:7016-7021) as a pointer swap + memset
   double *tmp = c->d_field[CUP2D_POLD];
@@ -470,7 +473,7 @@ int cup2d_add_correction(cup2d_ctx *c) {
 }
 int cup2d_project(cup2d_ctx *c, double dt) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
+  if (c->amr.active) return amr_project(c, dt);
   ProfScope t(c, CUP2D_T_PROJECT);
   return project_impl(c, dt);
 }
@@ -656,7 +659,10 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
 int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
                int max_iter, double *dt_out, int *iters, double *linf) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
+  if (c->amr.active && !c->mat.active) {
+    set_error("step: on an adapted grid install the assembled Poisson operator first (cup2d_set_matrix_coo)");
+    return CUP2D_ERR_UNSUPPORTED;
+  }
   double dt = 0;
   CUP2D_TRY(cup2d_compute_dt(c, nu, cfl, &dt));
   if (!(dt > 2e-16)) {  // main.cpp:6596

@@ -239,6 +239,9 @@ int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract);
 int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt);
 int amr_vorticity(cup2d_ctx *c, const double *vel, double *out);
 int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt);
+int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt);
+int amr_poisson_rhs(cup2d_ctx *c, double dt);
+int amr_project(cup2d_ctx *c, double dt);
 int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);

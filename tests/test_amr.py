@@ -174,14 +174,40 @@ def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_amr_time_step_vs_reference_gpu(gpu_lib, oracle):
+    """One whole time step on the adapted grid through the C ABI (cup2d_step: dt, RK2 WENO5 with coarse-fine tiles and
+    flux correction, Poisson rhs, BiCGSTAB on the assembled coarse-fine operator, volume-weighted projection) against the
+    REFERENCE's own time loop: its state after step 5 goes in, its state after step 6 must come out (the grid is settled
+    at 76 blocks on three levels by then, so adapt() changes nothing in the reference's step 6)."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/ref_harness for the before/after states")
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    kw = dict(level_start=2, level_max=5, rtol=2.0, ctol=0.5, nu=1e-3, max_iter=200)
+    A = oracle.ref_run_amr(steps=5, **kw)
+    B = oracle.ref_run_amr(steps=6, **kw)
+    assert np.array_equal(A["blocks"], B["blocks"]) and B["steps"][-1]["blocks"] == len(A["blocks"])
+    with AmrSimulation(AmrBlockGrid(A["blocks"]), nu=1e-3, cfl=0.5) as s:
+        s.install_poisson_matrix()
+        s.set_math(True)
+        s.set_field(L.VEL, A["vel"])
+        s.set_field(L.PRES, A["pres"])
+        r = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=200)
+        assert abs(r["dt"] - B["steps"][-1]["dt"]) <= 1e-12 * r["dt"]
+        assert np.abs(s.get_field(L.VEL) - B["vel"]).max() < 1e-9 * max(1.0, np.abs(B["vel"]).max())
+        assert np.abs(s.get_field(L.PRES) - B["pres"]).max() < 1e-8 * max(1.0, np.abs(B["pres"]).max())
+
+
+@pytest.mark.gpu
 def test_amr_unsupported_entry_points_say_so(gpu_lib):
     import ctypes
     from cup2d_amd import lib as L
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
     F = golden("amr_functors.npz")
     with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
-        assert s.L.cup2d_advect_diffuse_rk2(s._ctx, 1e-3, 1e-3) == -4  # CUP2D_ERR_UNSUPPORTED (the fused RK2 stages)
+        assert s.L.cup2d_step(s._ctx, 1e-3, 0.5, 0.0, 0.0, 10, 10, None, None, None) == -4  # no assembled operator yet
         assert b"adapted" in s.L.cup2d_last_error()
+        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 1, L.BLOCKS_ALL) == -4  # the fused RK stage kernels
         it = ctypes.c_int()
         assert s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 10, 10, ctypes.byref(it), None, None, None) == -4
         assert s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER) == -1  # CUP2D_ERR_ARG: adapted grids take all blocks

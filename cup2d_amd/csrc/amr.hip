@@ -15,7 +15,7 @@
 // and a functor records, on every side that is not wall/same, the flux it saw; fillcases then gives the edge
 // cell of a COARSE block  + (its own flux) + (sum of the two fine fluxes) per fine pair, W/E faces before S/N.
 // Every expression keeps the reference's operand order (the translation unit is built with -ffp-contract=off):
-// results are bit-identical to the reference's CPU functors (tests/test_amr_gpu.py).
+// results are bit-identical to the reference's CPU functors (tests/test_amr.py).
 //
 // One wave per block as everywhere else; the 32 ghost cells of the cross are computed by lanes 0..31.  The
 // irregular sides gather from other blocks through global memory -- this is the first, parity-first version of

@@ -195,12 +195,14 @@ int cup2d_set_gather(cup2d_ctx *ctx, int nsend, const int32_t *idx);
  *                level coarser; half[b][s] = 0|1 = which half of its face b touches, in increasing y for W/E and
  *                increasing x for S/N), _FINER (the two blocks nbr2[b][s][0..1] one level finer, ordered along the face)
  * 2:1 balance is the caller's invariant (the reference's adapt() enforces it, main.cpp:4734-4861).
- * Once set, the halo-1 block operators run their AMR form -- ghost cells across coarse-fine faces as
- * BlockLab::load/post_load builds them (main.cpp:2270-2933) and the flux correction of prepare0/fillcases
- * (main.cpp:1564-1849): cup2d_laplacian_sub, cup2d_apply_A, cup2d_pressure_rhs, cup2d_pressure_correction,
- * cup2d_vorticity (phase must be CUP2D_BLOCKS_ALL; the nbr table of cup2d_create is ignored by them).  Entry points
- * whose AMR form is not built yet (WENO5 advect-diffuse: halo-3 interpolation; the matrix-free solve and the
- * projection: use cup2d_set_matrix_coo with the caller's coarse-fine rows) return CUP2D_ERR_UNSUPPORTED. */
+ * Once set, the block operators run their AMR form -- ghost cells across coarse-fine faces as BlockLab::load /
+ * post_load builds them (main.cpp:2270-2933) and the flux correction of prepare0/fillcases (main.cpp:1564-1849):
+ * cup2d_advect_diffuse_rhs, cup2d_advect_diffuse_rk2 (the reference's un-fused stage sequence, per-block h),
+ * cup2d_laplacian_sub, cup2d_apply_A, cup2d_pressure_rhs, cup2d_poisson_rhs, cup2d_pressure_correction,
+ * cup2d_project (volume-weighted means), cup2d_vorticity, cup2d_compute_dt (finest h), and cup2d_poisson_solve /
+ * cup2d_step once the caller's coarse-fine matrix rows are installed with cup2d_set_matrix_coo (main.cpp:7034-7113).
+ * phase must be CUP2D_BLOCKS_ALL; the nbr table of cup2d_create is ignored.  Not built for adapted grids yet (they
+ * return CUP2D_ERR_UNSUPPORTED): the fused RK-stage kernels (cup2d_advect_diffuse_stage), the matrix-free solve. */
 typedef enum { CUP2D_AMR_WALL = 0, CUP2D_AMR_SAME = 1, CUP2D_AMR_COARSER = 2, CUP2D_AMR_FINER = 3 } cup2d_amr_kind;
 int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
                   const int32_t *half);

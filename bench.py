@@ -252,6 +252,12 @@ def main():
                        "cores": r["threads"], "kind": "reference",
                        "sample": "reference main.cpp time loop (OpenMP functors; Poisson = CPU port of cuda.cu, %d iters) "
                                  "at %d^2, median of %d steps" % (args.iters, args.cpu_n, r["timed_steps"])}
+                # the reference's own functors alone (computeA over all blocks, OpenMP), median of reps
+                fb = O.ref_bench(args.cpu_n, reps=5, threads=thr)
+                cpu["functors_mcells_per_s"] = {"advect_diffuse": round(fb["advect_diffuse_mcells"], 2),
+                                                "pressure_rhs1": round(fb["pressure_rhs1_mcells"], 2),
+                                                "sample": "computeA<..>(KernelAdvectDiffuse / pressure_rhs1) at %d^2, median of 5"
+                                                          % args.cpu_n}
             else:
                 t1 = time.perf_counter()
                 v0 = O.taylor_green(512)

@@ -392,7 +392,5 @@ def ref_bench(n, reps=10, vel=None, dt=1e-4, threads=None):
         vel = taylor_green(n)
     with tempfile.TemporaryDirectory() as d:
         _c(vel).tofile(os.path.join(d, "vel.in"))
-        if threads:
-            os.environ["OMP_NUM_THREADS"] = str(threads)
-        txt = _run_ref("bench", n, d, reps=int(reps), dt=float(dt))
+        txt = _run_ref("bench", n, d, _threads=threads, reps=int(reps), dt=float(dt))
     return json.loads(txt.strip().split("\n")[-1])

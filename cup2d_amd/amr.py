@@ -236,16 +236,218 @@ class AmrSimulation:
         _l.check(self.L.cup2d_set_matrix_coo(self._ctx, 0, len(v), r.ctypes.data_as(vp), c.ctypes.data_as(vp), v.ctypes.data_as(vp)),
                  "set_matrix_coo")
 
-    def step(self, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000):
+    def step(self, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1000, dt=None):
         """one pass of the time-loop body on the (fixed) adapted grid: dt, RK2 WENO5 advect-diffuse with flux correction,
         Poisson rhs, BiCGSTAB on the assembled operator, volume-weighted mean removal + projection (main.cpp:6576-7187
-        without adapt())"""
-        dt, it, e = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-        _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol), int(max_restarts), int(max_iter),
-                                   ctypes.byref(dt), ctypes.byref(it), ctypes.byref(e)), "step")
-        return dict(dt=dt.value, iters=it.value, err=e.value)
+        without adapt()).  dt: the reference computes dt BEFORE it regrids (main.cpp:6579-6603); a caller that adapts
+        between the two passes the value compute_dt() gave on the old grid."""
+        it, e = ctypes.c_int(), ctypes.c_double()
+        if dt is None:
+            d = ctypes.c_double()
+            _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol), int(max_restarts), int(max_iter),
+                                       ctypes.byref(d), ctypes.byref(it), ctypes.byref(e)), "step")
+            return dict(dt=d.value, iters=it.value, err=e.value)
+        dt = float(dt)
+        _l.check(self.L.cup2d_advect_diffuse_rk2(self._ctx, self.nu, dt), "advect_diffuse_rk2")
+        _l.check(self.L.cup2d_poisson_rhs(self._ctx, dt, 0), "poisson_rhs")
+        _l.check(self.L.cup2d_poisson_solve(self._ctx, float(tol), float(rel_tol), int(max_restarts), int(max_iter), ctypes.byref(it),
+                                            None, ctypes.byref(e), None), "poisson_solve")
+        _l.check(self.L.cup2d_project(self._ctx, dt), "project")
+        return dict(dt=dt, iters=it.value, err=e.value)
+
+    def adapt(self, rtol, ctol, level_max):
+        """The reference's adapt() (main.cpp:4657-5440) for this simulation: tag by max|vorticity| per block (GPU),
+        validate the states, prolong / restrict every field on the host (regrid-time work, as in the reference), then
+        rebuild the device context on the new grid and re-assemble the Poisson operator.  Returns True if the grid
+        changed."""
+        self.vorticity()
+        linf = np.abs(self.get_field(_l.TMP)).max(axis=1)
+        st = validate_states(self.grid.blocks, tag_states(linf, self.grid.level, rtol, ctol, level_max), level_max,
+                             self.grid.bpdx, self.grid.bpdy)
+        if not (st != LEAVE).any():
+            return False
+        nbk = self.grid.nblocks
+        names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
+        fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
+        blocks, data = regrid(self.grid.blocks, st, fields, level_max)
+        device = 0
+        self.close()
+        self.__init__(AmrBlockGrid(blocks, self.grid.bpdx, self.grid.bpdy, self.grid.h0 * max(self.grid.bpdx, self.grid.bpdy) * BS),
+                      nu=self.nu, cfl=self.cfl, device=device)
+        for k, f in names.items():
+            self.set_field(f, data[k])
+        self.install_poisson_matrix()
+        return True
 
     def compute_dt(self):
         v = ctypes.c_double()
         _l.check(self.L.cup2d_compute_dt(self._ctx, self.nu, self.cfl, ctypes.byref(v)), "compute_dt")
         return v.value
+
+
+# ---- regridding: the reference's adapt() (main.cpp:4657-5440) for one rank ---------------------------------------------
+LEAVE, REFINE, COMPRESS = 0, 1, 2
+
+
+def tag_states(linf, level, rtol, ctol, level_max):
+    """main.cpp:4678-4690: Refine where max|vorticity| of the block exceeds Rtol, Compress where it is below Ctol;
+    the finest level cannot refine, level 0 cannot compress"""
+    linf = np.asarray(linf, dtype=np.float64)
+    level = np.asarray(level)
+    st = np.where(linf > rtol, REFINE, np.where(linf < ctol, COMPRESS, LEAVE)).astype(np.int32)
+    st[(st == REFINE) & (level == level_max - 1)] = LEAVE
+    st[(st == COMPRESS) & (level == 0)] = LEAVE
+    return st
+
+
+def validate_states(blocks, states, level_max, bpdx=1, bpdy=1):
+    """The reference's state validation (main.cpp:4718-4861), which keeps the grid 2:1 balanced across faces AND
+    corners: from the finest level down, a block next to finer blocks may not compress and refines if one of those is
+    refining; a compressing block next to a same-level refining block stays; four siblings compress together or not
+    at all.  Returns the final states."""
+    blocks = np.asarray(blocks, dtype=np.int64)
+    st = np.array(states, dtype=np.int32)
+    if not (st != LEAVE).any():
+        return st
+    index = {tuple(int(v) for v in b): k for k, b in enumerate(blocks)}
+
+    def tree(l, i, j):
+        if (l, i, j) in index:
+            return 0
+        if l > 0 and (l - 1, i // 2, j // 2) in index:
+            return -2
+        return -1
+
+    for k, (l, i, j) in enumerate(blocks):
+        if (st[k] == REFINE and l == level_max - 1) or (st[k] == COMPRESS and l == 0):
+            st[k] = LEAVE
+    for m in range(level_max - 1, -1, -1):
+        for k, (l, i, j) in enumerate(blocks):
+            l, i, j = int(l), int(i), int(j)
+            if l != m or st[k] == REFINE or l == level_max - 1:
+                continue
+            nx, ny = bpdx << l, bpdy << l
+            done = False
+            for x in (-1, 0, 1):
+                for y in (-1, 0, 1):
+                    if (x == 0 and y == 0) or not (0 <= i + x < nx and 0 <= j + y < ny):
+                        continue
+                    if tree(l, i + x, j + y) != -1:
+                        continue
+                    if st[k] == COMPRESS:
+                        st[k] = LEAVE
+                    bstep = 3 if abs(x) + abs(y) == 2 else 1
+                    for B in range(0, 2, bstep):
+                        aux = B % 2 if abs(x) == 1 else B // 2
+                        fi = 2 * i + max(x, 0) + x + (B % 2) * max(0, 1 - abs(x))
+                        fj = 2 * j + max(y, 0) + y + aux * max(0, 1 - abs(y))
+                        fk = index.get((m + 1, fi, fj))
+                        if fk is not None and st[fk] == REFINE:
+                            st[k] = REFINE
+                            done = True
+                            break
+                    if done:
+                        break
+                if done:
+                    break
+        if m == 0:
+            break
+        for k, (l, i, j) in enumerate(blocks):
+            l, i, j = int(l), int(i), int(j)
+            if l != m or st[k] != COMPRESS:
+                continue
+            nx, ny = bpdx << l, bpdy << l
+            for x in (-1, 0, 1):
+                for y in (-1, 0, 1):
+                    if (x == 0 and y == 0) or not (0 <= i + x < nx and 0 <= j + y < ny):
+                        continue
+                    nk = index.get((l, i + x, j + y))
+                    if nk is not None and st[nk] == REFINE:
+                        st[k] = LEAVE
+    for k, (l, i, j) in enumerate(blocks):
+        l, i, j = int(l), int(i), int(j)
+        sib = [index.get((l, 2 * (i // 2) + a, 2 * (j // 2) + b)) for a in (0, 1) for b in (0, 1)]
+        if any(s is None or st[s] != COMPRESS for s in sib):
+            for s in sib:
+                if s is not None and st[s] == COMPRESS:
+                    st[s] = LEAVE
+    return st
+
+
+def _prolong(tile, dim):
+    """the four children of a block from its tensorial halo-1 tile (10 x 10 x dim), main.cpp:4981-5032: second-order
+    Taylor expansion about the parent cell, operand order kept"""
+    um = tile.reshape(10, 10, dim)
+    kids = np.zeros((2, 2, BS, BS, dim))
+    for J in range(2):
+        for I in range(2):
+            b = kids[J, I]
+            for j in range(0, BS, 2):
+                for i in range(0, BS, 2):
+                    i0, j0 = i // 2 + 4 * I + 1, j // 2 + 4 * J + 1
+                    l00, l0p, l0m = um[j0, i0], um[j0 + 1, i0], um[j0 - 1, i0]
+                    lm0, lmm, lmp = um[j0, i0 - 1], um[j0 - 1, i0 - 1], um[j0 + 1, i0 - 1]
+                    lp0, lpm, lpp = um[j0, i0 + 1], um[j0 - 1, i0 + 1], um[j0 + 1, i0 + 1]
+                    x = 0.5 * (lp0 - lm0)
+                    y = 0.5 * (l0p - l0m)
+                    x2 = (lp0 + lm0) - 2.0 * l00
+                    y2 = (l0p + l0m) - 2.0 * l00
+                    xy = 0.25 * ((lpp + lmm) - (lpm + lmp))
+                    b[j, i] = (l00 + (-0.25 * x - 0.25 * y)) + ((0.03125 * x2 + 0.03125 * y2) + 0.0625 * xy)
+                    b[j, i + 1] = (l00 + (+0.25 * x - 0.25 * y)) + ((0.03125 * x2 + 0.03125 * y2) - 0.0625 * xy)
+                    b[j + 1, i] = (l00 + (-0.25 * x + 0.25 * y)) + ((0.03125 * x2 + 0.03125 * y2) - 0.0625 * xy)
+                    b[j + 1, i + 1] = (l00 + (+0.25 * x + 0.25 * y)) + ((0.03125 * x2 + 0.03125 * y2) + 0.0625 * xy)
+    return kids
+
+
+def _restrict(kids, dim):
+    """the parent of four siblings kids[J][I] (BS x BS x dim each), main.cpp:5149-5166"""
+    out = np.empty((BS, BS, dim))
+    for J in range(2):
+        for I in range(2):
+            b = kids[J][I]
+            out[4 * J:4 * J + 4, 4 * I:4 * I + 4] = (b[0::2, 0::2] + b[1::2, 0::2] + b[0::2, 1::2] + b[1::2, 1::2]) / 4
+    return out
+
+
+def regrid(blocks, states, fields, level_max):
+    """Apply final states: every Refine block becomes its four children (prolonged from the OLD grid's tensorial halo-1
+    tile, cup2d_amd/amr_lab.py), every complete Compress sibling group its parent (2x2 means); everything else is
+    kept.  fields: {name: (array (nb, 64*dim), dim, is_vector)}.  Returns (new_blocks, new_fields) ordered along the
+    Hilbert curve of the finest level (the reference's Info::id2 order, main.cpp:1550-1562)."""
+    from .amr_lab import BlockLab, Tree
+    from .grid import hilbert_index
+    blocks = np.asarray(blocks, dtype=np.int64)
+    tree = Tree(blocks)
+    index = tree.index
+    new_blocks, new_data = [], {k: [] for k in fields}
+    labs = {k: BlockLab(dim, (-1, -1, 2, 2, True), vec) for k, (a, dim, vec) in fields.items()}
+    done = set()
+    for k, (l, i, j) in enumerate(blocks):
+        l, i, j = int(l), int(i), int(j)
+        if states[k] == REFINE:
+            tiles = {f: _prolong(labs[f].load(tree, a.reshape(len(blocks), -1), k), dim) for f, (a, dim, vec) in fields.items()}
+            for J in range(2):
+                for I in range(2):
+                    new_blocks.append((l + 1, 2 * i + I, 2 * j + J))
+                    for f in fields:
+                        new_data[f].append(tiles[f][J, I].reshape(-1))
+        elif states[k] == COMPRESS:
+            key = (l, 2 * (i // 2), 2 * (j // 2))
+            if key in done:
+                continue
+            done.add(key)
+            sib = [[index[(l, key[1] + I, key[2] + J)] for I in (0, 1)] for J in (0, 1)]
+            new_blocks.append((l - 1, i // 2, j // 2))
+            for f, (a, dim, vec) in fields.items():
+                kids = [[a[sib[J][I]].reshape(BS, BS, dim) for I in (0, 1)] for J in (0, 1)]
+                new_data[f].append(_restrict(kids, dim).reshape(-1))
+        else:
+            new_blocks.append((l, i, j))
+            for f, (a, dim, vec) in fields.items():
+                new_data[f].append(a[k].reshape(-1))
+    nb = np.asarray(new_blocks, dtype=np.int64)
+    L = int(max(level_max - 1, nb[:, 0].max()))
+    key = hilbert_index(max(L, 1), nb[:, 1] << (L - nb[:, 0]), nb[:, 2] << (L - nb[:, 0]))
+    order = np.lexsort((nb[:, 0], key))
+    return nb[order], {f: np.asarray(v)[order] for f, v in new_data.items()}

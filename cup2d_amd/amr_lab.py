@@ -1,9 +1,12 @@
-"""Literal CPU transcription of the reference's BlockLab (main.cpp:2231-2996) for ANY stencil on a block-AMR grid --
-TEST INFRASTRUCTURE, NOT PRODUCT.  Written statement for statement (same index formulas, same loop bounds, same
-operand order, C integer semantics) so that it reproduces the reference's ghosted tiles bit for bit, quirks included
-(the unrolled finer-neighbour branch, main.cpp:2476-2534).  Used to pin the halo-3 tensorial lab of KernelAdvectDiffuse
-(Stencil{-3,-3,4,4,true}) that csrc/amr.hip's second stage builds; oracle/amr.py is the compact halo-1 restatement.
-Single rank, bpdx = bpdy = 1."""
+"""Host-side BlockLab for block-AMR grids: the ghosted tile of ANY stencil, written statement for statement after the
+reference's BlockLab (main.cpp:2231-2996: same index formulas, loop bounds, operand order, C integer semantics), so that
+it reproduces the reference's tiles bit for bit, quirks included (the unrolled finer-neighbour branch, main.cpp:2476-2534;
+TestInterp fed component 0, 2753-2763).  Pinned against tiles dumped by the reference itself (tests/test_amr.py: halo-3
+tensorial vector tiles of KernelAdvectDiffuse, halo-1 tensorial scalar and vector tiles of adapt()).
+
+Two users: REGRIDDING (cup2d_amd/amr.py adapt: the tensorial halo-1 tile a refined block is prolonged from,
+main.cpp:4906-5032 -- regrid-time host work in the reference too), and the tests, where it is the full-tile cross-check
+of the closed forms the HIP kernels implement (csrc/amr.hip).  Single rank, bpdx = bpdy = 1."""
 import numpy as np
 
 BS = 8

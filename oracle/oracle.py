@@ -299,7 +299,7 @@ def ref_amr_functors(level_start, level_max, steps, rtol, ctol, nu=1e-3, max_ite
     with tempfile.TemporaryDirectory() as d:
         _run_ref("amr", 8 << int(level_start), d, levelmax=int(level_max), rtol=float(rtol), ctol=float(ctol), steps=int(steps),
                  nu=float(nu), maxiter=int(max_iter), reps=-1)
-        a = np.fromfile(os.path.join(d, "blocks.functors")).reshape(-1, 3 + 192 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128)
+        a = np.fromfile(os.path.join(d, "blocks.functors")).reshape(-1, 3 + 192 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128 + 100 + 200)
         dt, h0 = np.fromfile(os.path.join(d, "functors_scalars"))
     a = a[np.argsort(a[:, 0] * 1e12 + a[:, 2] * 1e6 + a[:, 1])]
     o = 387
@@ -307,7 +307,23 @@ def ref_amr_functors(level_start, level_max, steps, rtol, ctol, nu=1e-3, max_ite
                 vel=a[:, 195:323].reshape(-1, 64, 2), vort=a[:, 323:387], chi=a[:, o:o + 64],
                 udef=a[:, o + 64:o + 192].reshape(-1, 64, 2), prhs=a[:, o + 192:o + 256], pres=a[:, o + 256:o + 320],
                 pcorr=a[:, o + 320:o + 448].reshape(-1, 64, 2), Ax=a[:, o + 448:o + 512], lab3=a[:, o + 512:o + 904].reshape(-1, 14, 14, 2),
-                advdiff=a[:, o + 904:o + 1032].reshape(-1, 64, 2), nu=float(nu), dt=float(dt), h0=float(h0))
+                advdiff=a[:, o + 904:o + 1032].reshape(-1, 64, 2), lab1t_pres=a[:, o + 1032:o + 1132].reshape(-1, 10, 10),
+                lab1t_vel=a[:, o + 1132:o + 1332].reshape(-1, 10, 10, 2), nu=float(nu), dt=float(dt), h0=float(h0))
+
+
+def ref_amr_adapt(level_start, level_max, steps, rtol, ctol, nu=1e-3, max_iter=50):
+    """The reference's own adapt() (main.cpp:4657-5440) on an adapted grid with analytic fields (ref_harness 'amr' with
+    reps=-2): returns (pre, post), each dict(blocks (nb,3), chi, pres, pold (nb,64), vel, vold (nb,64,2)) sorted by
+    (level, j, i)."""
+    def rd(path):
+        a = np.fromfile(path).reshape(-1, 3 + 64 + 128 + 128 + 64 + 64)
+        a = a[np.argsort(a[:, 0] * 1e12 + a[:, 2] * 1e6 + a[:, 1])]
+        return dict(blocks=a[:, :3].astype(np.int64), chi=a[:, 3:67], vel=a[:, 67:195].reshape(-1, 64, 2),
+                    vold=a[:, 195:323].reshape(-1, 64, 2), pres=a[:, 323:387], pold=a[:, 387:451])
+    with tempfile.TemporaryDirectory() as d:
+        _run_ref("amr", 8 << int(level_start), d, levelmax=int(level_max), rtol=float(rtol), ctol=float(ctol), steps=int(steps),
+                 nu=float(nu), maxiter=int(max_iter), reps=-2)
+        return rd(os.path.join(d, "blocks.pre")), rd(os.path.join(d, "blocks.post"))
 
 
 def ref_dump(vel, time=0.0):

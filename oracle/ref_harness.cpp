@@ -515,6 +515,16 @@ struct DumpLab3 {
   }
 };
 
+/* the tile adapt() prolongs from: Stencil{-1,-1,2,2,true} (main.cpp:4906), 10 x 10 x dim doubles per block */
+struct DumpLab1T {
+  Stencil stencil{-1, -1, 2, 2, true};
+  std::vector<double> *out;
+  int dim;
+  void operator()(BlockLab *lab, Info *info) {
+    memcpy(out->data() + (size_t)info->id * 100 * dim, lab->m, 100 * dim * sizeof(double));
+  }
+};
+
 static void usage() {
   fprintf(stderr,
           "usage: ref_harness <mode> <levelStart> <dir> [key=value ...]\n"
@@ -605,6 +615,60 @@ int main(int argc, char **argv) {
       for (auto &I : var.vel->infos) { lmin = std::min(lmin, I.level); lmax = std::max(lmax, I.level); }
       fprintf(meta, "step %d blocks %zu levels %d %d dt %.17g update %d prev_iters %d prev_err %.17g\n", solve_count,
               var.vel->infos.size(), lmin, lmax, sim.dt, (int)withUpdate, hooks.last_iters, hooks.last_error);
+      if (solve_count == steps && reps == -2) {
+        /* adapt=1: leave the time loop here, put ANALYTIC fields on the adapted grid (a vortex pair displaced from
+         * the one that shaped the grid, so that some blocks refine and some compress) and run the reference's own
+         * adapt() (main.cpp:4657-5440: tagging by |vorticity|, state validation / 2:1 balance, prolongation,
+         * restriction).  blocks.pre / blocks.post = per block (level, i, j, chi 64, vel 128, vold 128, pres 64, pold 64)
+         * before / after. */
+        auto fs = [](double x, double y) { return std::sin(5.0 * x + 0.3) * std::cos(3.0 * y - 0.2) + 0.25 * x * y; };
+        auto gs = [](double x, double y) { return 0.1 * std::cos(2.0 * x) - 0.2 * std::sin(4.0 * y + 1.0); };
+        auto dumpall = [&](const std::string &path) {
+          const size_t nb = var.vel->infos.size();
+          const size_t stride = 3 + 64 + 128 + 128 + 64 + 64;
+          std::vector<double> out(nb * stride);
+          for (size_t i = 0; i < nb; i++) {
+            double *o = &out[i * stride];
+            const Info &I = var.vel->infos[i];
+            o[0] = I.level; o[1] = I.index[0]; o[2] = I.index[1];
+            memcpy(o + 3, var.chi->infos[i].block, 64 * sizeof(double));
+            memcpy(o + 3 + 64, var.vel->infos[i].block, 128 * sizeof(double));
+            memcpy(o + 3 + 192, var.vold->infos[i].block, 128 * sizeof(double));
+            memcpy(o + 3 + 320, var.pres->infos[i].block, 64 * sizeof(double));
+            memcpy(o + 3 + 384, var.pold->infos[i].block, 64 * sizeof(double));
+          }
+          write_file(path, out.data(), out.size());
+        };
+        for (size_t i = 0; i < var.vel->infos.size(); i++) {
+          const Info &I = var.vel->infos[i];
+          for (int iy = 0; iy < _BS_; iy++)
+            for (int ix = 0; ix < _BS_; ix++) {
+              const double x = I.origin[0] + (ix + 0.5) * I.h, y = I.origin[1] + (iy + 0.5) * I.h;
+              const int k = iy * _BS_ + ix;
+              double u = 0, v = 0;
+              const double cx[2] = {0.45, 0.7}, cy[2] = {0.55, 0.35}, gam[2] = {1.0, -0.8};
+              for (int q = 0; q < 2; q++) {
+                const double dx = x - cx[q], dy = y - cy[q], r2 = dx * dx + dy * dy;
+                const double f = gam[q] * std::exp(-r2 / (0.06 * 0.06)) / 0.06;
+                u += -dy * f;
+                v += dx * f;
+              }
+              var.vel->infos[i].block[2 * k] = u + 0.01 * fs(x, y);
+              var.vel->infos[i].block[2 * k + 1] = v + 0.01 * gs(x, y);
+              var.vold->infos[i].block[2 * k] = fs(y, x);
+              var.vold->infos[i].block[2 * k + 1] = gs(x + 0.1, y);
+              var.chi->infos[i].block[k] = 0.0; /* no bodies: GradChiOnTmp leaves the vorticity tags alone */
+              var.pres->infos[i].block[k] = gs(x - 0.3, y + 0.2) + fs(y, x + 0.1);
+              var.pold->infos[i].block[k] = fs(x, y);
+            }
+        }
+        dumpall(dir + "/blocks.pre");
+        adapt();
+        dumpall(dir + "/blocks.post");
+        fclose(meta);
+        MPI_Finalize();
+        exit(0);
+      }
       if (solve_count == steps && reps == -1) {
         /* functors=1: leave the time loop here and evaluate block functors on the adapted grid with ANALYTIC
          * fields (cell-centre samples), exactly through the reference's own call sequences:
@@ -616,9 +680,9 @@ int main(int argc, char **argv) {
         const size_t nb = var.vel->infos.size();
         /* + chi (64), udef (128), pressure_rhs out (64), pres (64), pressureCorrectionKernel out (128) */
         /* ... + A x (64) + lab3 of vel (392) + KernelAdvectDiffuse out with flux correction (128) */
-        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128;
+        const size_t stride = 3 + 64 * 3 + 128 + 64 + 64 + 128 + 64 + 64 + 128 + 64 + 392 + 128 + 100 + 200;
         std::vector<double> out(nb * stride);
-        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64, o_ax = o_pc + 128, o_lab = o_ax + 64, o_adv = o_lab + 392;
+        const size_t o_chi = 3 + 192 + 128 + 64, o_udef = o_chi + 64, o_prhs = o_udef + 128, o_pres = o_prhs + 64, o_pc = o_pres + 64, o_ax = o_pc + 128, o_lab = o_ax + 64, o_adv = o_lab + 392, o_l1s = o_adv + 128, o_l1v = o_l1s + 100;
         sim.dt = dt > 0 ? dt : 0.01;
         for (size_t i = 0; i < nb; i++) {
           Info &I = var.pold->infos[i];
@@ -686,6 +750,19 @@ int main(int argc, char **argv) {
             for (int k = 0; k < 64; k++) out[i * stride + o_ax + k] = M->get_x()[i * 64 + k];
         }
 #endif
+        /* the tensorial halo-1 tiles adapt() prolongs from: pres (scalar) and vel (vector) */
+        {
+          std::vector<double> ls(nb * 100), lv(nb * 200);
+          DumpLab1T ds, dv;
+          ds.out = &ls; ds.dim = 1;
+          dv.out = &lv; dv.dim = 2;
+          computeA<ScalarLab>(ds, var.pres, 1);
+          computeA<VectorLab>(dv, var.vel, 2);
+          for (size_t i = 0; i < nb; i++) {
+            memcpy(&out[i * stride + o_l1s], &ls[i * 100], 100 * sizeof(double));
+            memcpy(&out[i * stride + o_l1v], &lv[i * 200], 200 * sizeof(double));
+          }
+        }
         /* halo-3 vector lab of vel, then KernelAdvectDiffuse with its flux correction (main.cpp:6611-6617) */
         {
           std::vector<double> labs(nb * 392);

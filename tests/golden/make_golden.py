@@ -59,6 +59,10 @@ def main():
     # block functors of the reference on an ADAPTED grid (three levels, 76 blocks): the grid its own adapt() builds around
     # an analytic vortex pair, halo-1 functors with their flux correction on analytic fields (ref_harness 'amr' reps=-1)
     np.savez_compressed(os.path.join(HERE, "amr_functors.npz"), **O.ref_amr_functors(2, 5, 4, 2.0, 0.5))
+    # the reference's own adapt() on that grid with analytic fields: blocks and fields before / after
+    pre, post = O.ref_amr_adapt(2, 5, 4, 2.0, 0.5)
+    np.savez_compressed(os.path.join(HERE, "amr_adapt.npz"), pre_blocks=pre["blocks"], pre_vel=pre["vel"], pre_pres=pre["pres"],
+                        post_blocks=post["blocks"], post_vel=post["vel"], post_pres=post["pres"], rtol=2.0, ctol=0.5, level_max=5)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -34,10 +34,10 @@ def test_amr_oracle_bit_exact_vs_reference(oracle):
 
 def test_amr_halo3_tile_and_advect_diffuse_vs_reference(oracle):
     """KernelAdvectDiffuse's ghosted tile (Stencil{-3,-3,4,4,true}): the literal transcription of BlockLab
-    (oracle/amr_lab.py) reproduces the reference's 14x14x2 tiles completely, the closed forms (oracle/amr.py lab3_cross,
+    (cup2d_amd/amr_lab.py) reproduces the reference's 14x14x2 tiles completely, the closed forms (oracle/amr.py lab3_cross,
     what csrc/amr.hip implements) on the cross the functor reads; then the functor with its dim-2 flux correction."""
     from oracle import amr as A
-    from oracle import amr_lab as AL
+    from cup2d_amd import amr_lab as AL
     cross = np.zeros((14, 14), bool)
     cross[3:11, :] = True
     cross[:, 3:11] = True
@@ -51,6 +51,38 @@ def test_amr_halo3_tile_and_advect_diffuse_vs_reference(oracle):
             m = A.lab3_cross(g, F["vel"], b)
             assert np.array_equal(m[cross], F["lab3"][b][cross]), (name, b)
         assert np.array_equal(A.advect_diffuse_amr(g, F["vel"], float(F["nu"]), float(F["dt"])), F["advdiff"]), name
+
+
+def _by_block(blocks, arr):
+    return {tuple(int(v) for v in b): arr[k] for k, b in enumerate(blocks)}
+
+
+def test_amr_regrid_vs_reference_adapt(oracle):
+    """cup2d_amd.amr tag_states / validate_states / regrid against the reference's own adapt() (main.cpp:4657-5440) run
+    on analytic fields: same leaf blocks afterwards (refinement by |vorticity|, 2:1 balance across faces and corners,
+    sibling groups), prolonged and restricted fields bit-identical.  Golden: 76 -> 94 blocks; live: every field."""
+    from cup2d_amd import amr as P
+    from oracle import amr as A
+    G = golden("amr_adapt.npz")
+    cases = [("golden", dict(blocks=G["pre_blocks"], vel=G["pre_vel"], pres=G["pre_pres"]),
+              dict(blocks=G["post_blocks"], vel=G["post_vel"], pres=G["post_pres"]), float(G["rtol"]), float(G["ctol"]), int(G["level_max"]))]
+    if oracle.have_reference():
+        for args in ((1, 5, 6, 1.0, 0.2), (2, 6, 7, 3.0, 1.0)):
+            pre, post = oracle.ref_amr_adapt(*args)
+            cases.append(("live%s" % (args,), pre, post, args[3], args[4], args[1]))
+    for name, pre, post, rtol, ctol, lmax in cases:
+        nb = len(pre["blocks"])
+        linf = np.abs(A.vorticity_amr(A.AmrGrid(pre["blocks"]), pre["vel"])).max(axis=1)
+        st = P.validate_states(pre["blocks"], P.tag_states(linf, pre["blocks"][:, 0], rtol, ctol, lmax), lmax)
+        assert (st == P.REFINE).any() and (st == P.COMPRESS).any(), name  # the fixture exercises both
+        fields = {k: (pre[k].reshape(nb, -1), 2 if pre[k].ndim == 3 else 1, pre[k].ndim == 3) for k in pre if k != "blocks"}
+        blocks, data = P.regrid(pre["blocks"], st, fields, lmax)
+        assert set(map(tuple, blocks.tolist())) == set(map(tuple, post["blocks"].tolist())), name
+        for k in data:
+            ref = _by_block(post["blocks"], post[k].reshape(len(post["blocks"]), -1))
+            mine = _by_block(blocks, data[k])
+            assert all(np.array_equal(ref[b], mine[b]) for b in ref), (name, k)
+        P.AmrBlockGrid(blocks)  # the result is a valid (2:1 balanced) tiling
 
 
 def test_amr_topology_tables(oracle):
@@ -196,6 +228,68 @@ def test_amr_time_step_vs_reference_gpu(gpu_lib, oracle):
         assert abs(r["dt"] - B["steps"][-1]["dt"]) <= 1e-12 * r["dt"]
         assert np.abs(s.get_field(L.VEL) - B["vel"]).max() < 1e-9 * max(1.0, np.abs(B["vel"]).max())
         assert np.abs(s.get_field(L.PRES) - B["pres"]).max() < 1e-8 * max(1.0, np.abs(B["pres"]).max())
+
+
+@pytest.mark.gpu
+def test_amr_adapt_then_step_gpu(gpu_lib, oracle):
+    """AmrSimulation.adapt (vorticity tags on the GPU, host regrid, new context + operator) lands on the reference's
+    post-adapt grid and fields; a time step on the new grid then runs and stays finite and divergence-reducing"""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    G = golden("amr_adapt.npz")
+    with AmrSimulation(AmrBlockGrid(G["pre_blocks"])) as s:
+        s.set_field(L.VEL, G["pre_vel"])
+        s.set_field(L.PRES, G["pre_pres"])
+        assert s.adapt(float(G["rtol"]), float(G["ctol"]), int(G["level_max"]))
+        assert set(map(tuple, s.grid.blocks.tolist())) == set(map(tuple, G["post_blocks"].tolist()))
+        ref_v = _by_block(G["post_blocks"], G["post_vel"].reshape(len(G["post_blocks"]), -1))
+        ref_p = _by_block(G["post_blocks"], G["post_pres"])
+        vel, pres = s.get_field(L.VEL).reshape(s.grid.nblocks, -1), s.get_field(L.PRES)
+        for k, b in enumerate(map(tuple, s.grid.blocks.tolist())):
+            assert np.array_equal(vel[k], ref_v[b]) and np.array_equal(pres[k], ref_p[b]), b
+        r = s.step(tol=1e-9, rel_tol=0.0, max_restarts=100, max_iter=500)
+        assert r["dt"] > 0 and r["err"] <= 1e-9 and np.isfinite(s.get_field(L.VEL)).all()
+        assert not s.adapt(1e30, 0.0, int(G["level_max"]))  # nothing to do with these thresholds
+
+
+@pytest.mark.gpu
+def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle):
+    """BASELINE.json configs[4] end to end on one GPU: from the uniform level-2 grid and the analytic vortex pair, six
+    passes of [adapt(); time step] -- the grid grows 16 -> 40 -> 76 blocks on three levels -- against the reference's own
+    time loop (ref_harness 'amr': its adapt(), labs, flux correction, matrix; solver = CPU restatement of cuda.cu)."""
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/ref_harness")
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    steps, lmax, rtol, ctol = 6, 5, 2.0, 0.5
+    R = oracle.ref_run_amr(level_start=2, level_max=lmax, steps=steps, rtol=rtol, ctol=ctol, nu=1e-3, max_iter=200)
+    g = AmrBlockGrid([(2, i, j) for j in range(4) for i in range(4)])
+    x, y = g.cell_centres()
+    u, v = np.zeros_like(x), np.zeros_like(x)
+    for cx, cy, gam in ((0.35, 0.5, 1.0), (0.65, 0.5, -1.0)):  # ref_harness.cpp inject()
+        dx, dy = x - cx, y - cy
+        f = gam * np.exp(-(dx * dx + dy * dy) / (0.06 * 0.06)) / 0.06
+        u += -dy * f
+        v += dx * f
+    counts, dts = [], []
+    with AmrSimulation(g, nu=1e-3, cfl=0.5) as s:
+        s.install_poisson_matrix()
+        s.set_math(True)
+        s.set_field(L.VEL, np.stack([u, v], axis=-1))
+        for k in range(steps):
+            dt = s.compute_dt()  # before the regrid, as main.cpp:6579-6603 orders them
+            s.adapt(rtol, ctol, lmax)
+            counts.append(s.grid.nblocks)
+            dts.append(s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=200, dt=dt)["dt"])
+        assert counts == [st["blocks"] for st in R["steps"][1:steps + 1]], (counts, [st["blocks"] for st in R["steps"]])
+        assert np.allclose(dts, [st["dt"] for st in R["steps"][1:steps + 1]], rtol=1e-8, atol=0)
+        assert set(map(tuple, s.grid.blocks.tolist())) == set(map(tuple, R["blocks"].tolist()))
+        ref_v = _by_block(R["blocks"], R["vel"].reshape(len(R["blocks"]), -1))
+        ref_p = _by_block(R["blocks"], R["pres"])
+        vel, pres = s.get_field(L.VEL).reshape(s.grid.nblocks, -1), s.get_field(L.PRES)
+        dv = max(np.abs(vel[k] - ref_v[b]).max() for k, b in enumerate(map(tuple, s.grid.blocks.tolist())))
+        dp = max(np.abs(pres[k] - ref_p[b]).max() for k, b in enumerate(map(tuple, s.grid.blocks.tolist())))
+        assert dv < 1e-8 * max(1.0, np.abs(R["vel"]).max()) and dp < 1e-7 * max(1.0, np.abs(R["pres"]).max()), (dv, dp)
 
 
 @pytest.mark.gpu

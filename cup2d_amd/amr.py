@@ -58,6 +58,22 @@ class AmrBlockGrid:
 
     # ---- Poisson matrix of main.cpp:7034-7112 on this adapted grid -------------------------------
     def poisson_coo(self):
+        """COO triplets (row, col, val) of the matrix the reference assembles on this grid, assembled by the library's
+        host routine cup2d_amr_poisson_coo (C++, include/cup2d_hip.h); poisson_coo_py is the same algorithm in Python."""
+        L = _l.load_library()
+        vp = ctypes.c_void_p
+        tabs = [np.ascontiguousarray(a, dtype=np.int32) for a in (self.kind, self.nbr2, self.half)]
+        ptr = [a.ctypes.data_as(vp) for a in tabs]
+        nnz = L.cup2d_amr_poisson_coo(self.nblocks, *ptr, 0, None, None, None)
+        if nnz < 0:
+            _l.check(int(nnz), "amr_poisson_coo")
+        r, c, v = np.empty(nnz, dtype=np.int32), np.empty(nnz, dtype=np.int32), np.empty(nnz, dtype=np.float64)
+        got = L.cup2d_amr_poisson_coo(self.nblocks, *ptr, nnz, r.ctypes.data_as(vp), c.ctypes.data_as(vp), v.ctypes.data_as(vp))
+        if got != nnz:
+            _l.check(int(min(got, -1)), "amr_poisson_coo")
+        return r, c, v
+
+    def poisson_coo_py(self):
         """COO triplets (row, col, val) of the matrix the reference assembles (rows/columns numbered 64 * block + 8 * iy
         + ix in the order of `blocks`): 5-point rows inside a block (main.cpp:7075-7087); on block-edge cells, per side:
         nothing at a domain wall, +1/-1 towards a same-level neighbour, and across coarse-fine faces the reference's

@@ -207,6 +207,15 @@ typedef enum { CUP2D_AMR_WALL = 0, CUP2D_AMR_SAME = 1, CUP2D_AMR_COARSER = 2, CU
 int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
                   const int32_t *half);
 
+/* The Poisson matrix the reference assembles on an adapted grid (the serial host loop main.cpp:7034-7112 with
+ * Solver::makeFlux / interpolate / D1 / D2, main.cpp:5915-5997), from the topology tables of cup2d_set_amr.  Host-side,
+ * regrid-time, no context and no GPU needed.  Returns the number of triplets; when row, col, val are non-NULL (capacity
+ * cap) they are filled: rows/columns numbered 64 * block + 8 * iy + ix, sorted by (row, column), duplicate columns of a
+ * row summed in arrival order like SpRowInfo::mapColVal (cuda.h:1-24).  Negative cup2d_status on error.  Feed the result
+ * to cup2d_set_matrix_coo. */
+long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half, long long cap,
+                                int32_t *row, int32_t *col, double *val);
+
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:
  * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL. */

@@ -117,7 +117,9 @@ def test_amr_poisson_matrix_vs_reference(oracle):
     from cup2d_amd.amr import AmrBlockGrid
     for name, F in _grid_cases(oracle):
         g = AmrBlockGrid(F["blocks"])
-        r, c, v = g.poisson_coo()
+        r, c, v = g.poisson_coo()  # the library's host routine (C++)
+        rp, cp, vp = g.poisson_coo_py()  # the same algorithm in Python: bit for bit
+        assert np.array_equal(r, rp) and np.array_equal(c, cp) and np.array_equal(v, vp), name
         n = 64 * g.nblocks
         A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
         assert np.abs(A @ F["pres"].ravel() - F["Ax"].ravel()).max() < 1e-14, name

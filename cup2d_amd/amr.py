@@ -11,6 +11,10 @@ from . import lib as _l
 BS = 8
 
 
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
 class AmrBlockGrid:
     """blocks: (nb, 3) int array of leaf blocks (level, i, j) of a bpdx x bpdy base grid (level-0 blocks), 2:1
     balanced (the reference's adapt() guarantees it, main.cpp:4734-4861).  h0 = extent / max(bpdx, bpdy) / 8
@@ -21,34 +25,16 @@ class AmrBlockGrid:
         self.nblocks = len(self.blocks)
         self.bpdx, self.bpdy = int(bpdx), int(bpdy)
         self.h0 = float(extent) / max(self.bpdx, self.bpdy) / BS
-        index = {tuple(int(v) for v in b): k for k, b in enumerate(self.blocks)}
         nb = self.nblocks
         self.level = np.ascontiguousarray(self.blocks[:, 0], dtype=np.int32)
         self.kind = np.zeros((nb, 4), dtype=np.int32)
         self.nbr2 = -np.ones((nb, 4, 2), dtype=np.int32)
         self.half = np.zeros((nb, 4), dtype=np.int32)
-        for b, (l, i, j) in enumerate(self.blocks):
-            l, i, j = int(l), int(i), int(j)
-            for s, (di, dj) in enumerate(((-1, 0), (1, 0), (0, -1), (0, 1))):
-                ni, nj = i + di, j + dj
-                if ni < 0 or nj < 0 or ni >= self.bpdx << l or nj >= self.bpdy << l:
-                    self.kind[b, s] = _l.AMR_WALL
-                elif (l, ni, nj) in index:
-                    self.kind[b, s] = _l.AMR_SAME
-                    self.nbr2[b, s, 0] = index[(l, ni, nj)]
-                elif l > 0 and (l - 1, ni // 2, nj // 2) in index:
-                    self.kind[b, s] = _l.AMR_COARSER
-                    self.nbr2[b, s, 0] = index[(l - 1, ni // 2, nj // 2)]
-                    self.half[b, s] = (j % 2) if s < 2 else (i % 2)
-                else:
-                    # the two children of (l, ni, nj) that touch this side, ordered along the face
-                    kids = [(l + 1, 2 * ni + (1 if s == 0 else 0 if s == 1 else a), 2 * nj + (a if s < 2 else 1 if s == 2 else 0))
-                            for a in (0, 1)]
-                    if any(k not in index for k in kids):
-                        raise ValueError("block %s side %d: neither a leaf, a coarser leaf nor two finer leaves across "
-                                         "(grid not 2:1 balanced?)" % ((l, i, j), s))
-                    self.kind[b, s] = _l.AMR_FINER
-                    self.nbr2[b, s] = [index[k] for k in kids]
+        b32 = np.ascontiguousarray(self.blocks, dtype=np.int32)
+        L = _l.load_library()
+        rc = L.cup2d_amr_tables(nb, _p(b32), self.bpdx, self.bpdy, _p(self.kind), _p(self.nbr2), _p(self.half))
+        if rc != 0:
+            raise ValueError(L.cup2d_last_error().decode())
         # same-level neighbour table for cup2d_create (sides that are not same-level: wall)
         self.nbr = np.where(self.kind == _l.AMR_SAME, self.nbr2[:, :, 0], -1).astype(np.int32)
         self.nghost, self.n_inner = 0, nb
@@ -285,7 +271,7 @@ class AmrSimulation:
         nbk = self.grid.nblocks
         names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
         fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
-        blocks, data = regrid(self.grid.blocks, st, fields, level_max)
+        blocks, data = regrid(self.grid.blocks, st, fields, level_max, self.grid.bpdx, self.grid.bpdy)
         device = 0
         self.close()
         self.__init__(AmrBlockGrid(blocks, self.grid.bpdx, self.grid.bpdy, self.grid.h0 * max(self.grid.bpdx, self.grid.bpdy) * BS),
@@ -317,6 +303,16 @@ def tag_states(linf, level, rtol, ctol, level_max):
 
 
 def validate_states(blocks, states, level_max, bpdx=1, bpdy=1):
+    """The reference's state validation (main.cpp:4718-4861) by the library's host routine cup2d_amr_validate_states;
+    validate_states_py states the same algorithm in Python.  Returns the final states."""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.array(states, dtype=np.int32)
+    L = _l.load_library()
+    _l.check(L.cup2d_amr_validate_states(len(b32), _p(b32), bpdx, bpdy, level_max, _p(st)), "amr_validate_states")
+    return st
+
+
+def validate_states_py(blocks, states, level_max, bpdx=1, bpdy=1):
     """The reference's state validation (main.cpp:4718-4861), which keeps the grid 2:1 balanced across faces AND
     corners: from the finest level down, a block next to finer blocks may not compress and refines if one of those is
     refining; a compressing block next to a same-level refining block stays; four siblings compress together or not
@@ -426,7 +422,34 @@ def _restrict(kids, dim):
     return out
 
 
-def regrid(blocks, states, fields, level_max):
+def regrid(blocks, states, fields, level_max, bpdx=1, bpdy=1):
+    """Apply final states with the library's host routine cup2d_amr_regrid (include/cup2d_hip.h); regrid_py states the
+    same algorithm in Python on the general-stencil BlockLab of amr_lab.py.  fields: {name: (array (nb, 64*dim), dim,
+    is_vector)}.  Returns (new_blocks, new_fields)."""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, dtype=np.int32)
+    nb = len(b32)
+    names = list(fields)
+    src = [np.ascontiguousarray(fields[k][0], dtype=np.float64).reshape(nb, -1) for k in names]
+    dims = np.array([fields[k][1] for k in names], dtype=np.int32)
+    vec = np.array([1 if fields[k][2] else 0 for k in names], dtype=np.int32)
+    L = _l.load_library()
+    vp = ctypes.c_void_p
+    n = len(names)
+    srcp = (vp * max(n, 1))(*[a.ctypes.data for a in src])
+    n_new = L.cup2d_amr_regrid(nb, _p(b32), bpdx, bpdy, level_max, _p(st), n, srcp, _p(dims), _p(vec), 0, None, None)
+    if n_new < 0:
+        _l.check(int(n_new), "amr_regrid")
+    new_blocks = np.empty((n_new, 3), dtype=np.int32)
+    dst = [np.empty((n_new, BS * BS * int(d))) for d in dims]
+    dstp = (vp * max(n, 1))(*[a.ctypes.data for a in dst])
+    got = L.cup2d_amr_regrid(nb, _p(b32), bpdx, bpdy, level_max, _p(st), n, srcp, _p(dims), _p(vec), n_new, _p(new_blocks), dstp)
+    if got != n_new:
+        _l.check(int(min(got, -1)), "amr_regrid")
+    return new_blocks.astype(np.int64), dict(zip(names, dst))
+
+
+def regrid_py(blocks, states, fields, level_max):
     """Apply final states: every Refine block becomes its four children (prolonged from the OLD grid's tensorial halo-1
     tile, cup2d_amd/amr_lab.py), every complete Compress sibling group its parent (2x2 means); everything else is
     kept.  fields: {name: (array (nb, 64*dim), dim, is_vector)}.  Returns (new_blocks, new_fields) ordered along the

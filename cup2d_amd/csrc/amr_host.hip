@@ -142,3 +142,445 @@ extern "C" long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, con
       }
   return nnz;
 }
+
+// ======================================================================================================================
+// Regridding on the host: topology tables, state validation, prolongation / restriction.
+//
+// Reference: adapt() (main.cpp:4657-5440) -- tagging 4671-4703, state validation / 2:1 balance 4718-4861, the
+// tensorial halo-1 tile a refined block is prolonged from (BlockLab with Stencil{-1,-1,2,2,true}, 4906-4913),
+// prolongation 4981-5032, restriction 5149-5166 -- and the tree / Znei / Zchild look-ups it leans on (672-738).
+// Here the leaves live in one open-addressing table keyed by (level, i, j); what lies across a side or a corner of a
+// block is a closed form of that table (amr_ghost.h for the sides, the same code the kernels run).
+// ======================================================================================================================
+#include <cmath>
+#include <cstdint>
+#include <limits>
+
+#include "amr_ghost.h"
+
+namespace {
+
+using cup2d::BC;
+
+struct Leaves {
+  const int32_t *blocks;
+  int n, bpdx, bpdy;
+  std::vector<uint64_t> keys;
+  std::vector<int32_t> vals;
+  uint64_t mask;
+  static uint64_t key(int l, int i, int j) { return ((uint64_t)(l + 1) << 56) | ((uint64_t)(uint32_t)i << 28) | (uint32_t)j; }
+  static uint64_t mix(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    return k;
+  }
+  Leaves(int n_, const int32_t *b, int bx, int by) : blocks(b), n(n_), bpdx(bx), bpdy(by) {
+    size_t cap = 16;
+    while (cap < 2 * (size_t)n) cap <<= 1;
+    mask = cap - 1;
+    keys.assign(cap, 0);
+    vals.assign(cap, -1);
+    for (int k = 0; k < n; k++) {
+      const uint64_t kk = key(b[3 * k], b[3 * k + 1], b[3 * k + 2]);
+      uint64_t h = mix(kk) & mask;
+      while (keys[h]) h = (h + 1) & mask;
+      keys[h] = kk;
+      vals[h] = k;
+    }
+  }
+  int find(int l, int i, int j) const {
+    if (l < 0 || i < 0 || j < 0) return -1;
+    const uint64_t kk = key(l, i, j);
+    for (uint64_t h = mix(kk) & mask; keys[h]; h = (h + 1) & mask)
+      if (keys[h] == kk) return vals[h];
+    return -1;
+  }
+  bool inside(int l, int i, int j) const { return i >= 0 && j >= 0 && i < (bpdx << l) && j < (bpdy << l); }
+  int level(int b) const { return blocks[3 * b]; }
+  int bi(int b) const { return blocks[3 * b + 1]; }
+  int bj(int b) const { return blocks[3 * b + 2]; }
+};
+
+struct Side {
+  int kind, n0, n1, half;
+};
+// what lies across side s (W, E, S, N) of block b; kind = -1 when the grid is not 2:1 balanced there
+Side side_of(const Leaves &L, int b, int s) {
+  static const int di[4] = {-1, 1, 0, 0}, dj[4] = {0, 0, -1, 1};
+  const int l = L.level(b), i = L.bi(b), j = L.bj(b), ni = i + di[s], nj = j + dj[s];
+  Side r = {CUP2D_AMR_WALL, -1, -1, 0};
+  if (!L.inside(l, ni, nj)) return r;
+  int k = L.find(l, ni, nj);
+  if (k >= 0) {
+    r.kind = CUP2D_AMR_SAME;
+    r.n0 = k;
+    return r;
+  }
+  k = l > 0 ? L.find(l - 1, ni >> 1, nj >> 1) : -1;
+  if (k >= 0) {
+    r.kind = CUP2D_AMR_COARSER;
+    r.n0 = k;
+    r.half = s < 2 ? (j & 1) : (i & 1);
+    return r;
+  }
+  // the two children of (l, ni, nj) that touch this side, ordered along the face
+  for (int a = 0; a < 2; a++) {
+    const int fi = 2 * ni + (s == 0 ? 1 : s == 1 ? 0 : a), fj = 2 * nj + (s < 2 ? a : s == 2 ? 1 : 0);
+    (a ? r.n1 : r.n0) = L.find(l + 1, fi, fj);
+  }
+  r.kind = (r.n0 >= 0 && r.n1 >= 0) ? CUP2D_AMR_FINER : -1;
+  return r;
+}
+
+bool bad_grid_args(int nblocks, const int32_t *blocks, int bpdx, int bpdy, const char *who) {
+  if (nblocks <= 0 || !blocks || bpdx <= 0 || bpdy <= 0) {
+    cup2d::set_error("%s: bad argument", who);
+    return true;
+  }
+  for (int b = 0; b < nblocks; b++) {
+    const int l = blocks[3 * b];
+    if (l < 0 || l > 20 || blocks[3 * b + 1] < 0 || blocks[3 * b + 2] < 0 || blocks[3 * b + 1] >= (bpdx << l) ||
+        blocks[3 * b + 2] >= (bpdy << l)) {
+      cup2d::set_error("%s: block %d = (%d, %d, %d) outside the %d x %d base grid", who, b, l, blocks[3 * b + 1],
+                       blocks[3 * b + 2], bpdx, bpdy);
+      return true;
+    }
+  }
+  return false;
+}
+
+enum { LEAVE = 0, REFINE = 1, COMPRESS = 2 };
+
+// the tensorial halo-1 tile (10 x 10 x dim, row-major, components interleaved) of block b
+void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, double *T) {
+  constexpr int BS = CUP2D_BS, W = BS + 2;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  const int l = L.level(b), i0 = L.bi(b), j0 = L.bj(b);
+  const auto at = [&](int ix, int iy, int d) -> double & { return T[((iy + 1) * W + ix + 1) * dim + d]; };
+  for (int c = 0; c < BC; c++)
+    for (int d = 0; d < dim; d++) at(c & 7, c >> 3, d) = f[((size_t)b * BC + c) * dim + d];
+  // sides: the closed forms the kernels use
+  for (int s = 0; s < 4; s++) {
+    const Side S = side_of(L, b, s);
+    for (int d = 0; d < dim; d++) {
+      const auto get = [&](int blk, int cell) { return f[((size_t)blk * BC + cell) * dim + d]; };
+      const double sign = (vector && d == (s < 2 ? 0 : 1)) ? -1.0 : 1.0;
+      for (int q = 0; q < BS; q++) {
+        const int gx = s == 0 ? -1 : s == 1 ? BS : q, gy = s == 2 ? -1 : s == 3 ? BS : q;
+        const int ex = s == 0 ? 0 : s == 1 ? BS - 1 : q, ey = s == 2 ? 0 : s == 3 ? BS - 1 : q;
+        const int fx = s == 0 ? 1 : s == 1 ? BS - 2 : q, fy = s == 2 ? 1 : s == 3 ? BS - 2 : q;
+        at(gx, gy, d) = S.kind < 0 ? nan : cup2d::amr_ghost(get, S.kind, S.n0, S.n1, S.half, s, q, at(ex, ey, d), at(fx, fy, d), sign);
+      }
+    }
+  }
+  // comp-0 value of cell (GX, GY) of level l - 1 (global cell coordinates) as the coarse copy of the tile holds it:
+  // a leaf of that level, or the 2 x 2 mean of a leaf of level l (UseCoarseStencil0 / FillCoarseVersion 2934-2996)
+  const auto coarse0 = [&](int GX, int GY) -> double {
+    int k = L.find(l - 1, GX >> 3, GY >> 3);
+    if (k >= 0) return f[((size_t)k * BC + (GY & 7) * BS + (GX & 7)) * dim];
+    k = L.find(l, GX >> 2, GY >> 2);
+    if (k < 0) return nan;
+    const int x = 2 * (GX & 3), y = 2 * (GY & 3);
+    const auto q = [&](int yy, int xx) { return f[((size_t)k * BC + yy * BS + xx) * dim]; };
+    return (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
+  };
+  const int NX = L.bpdx << l, NY = L.bpdy << l;
+  for (int cy = -1; cy <= 1; cy += 2)
+    for (int cx = -1; cx <= 1; cx += 2) {
+      const int gx = cx < 0 ? -1 : BS, gy = cy < 0 ? -1 : BS, ex = cx < 0 ? 0 : BS - 1, ey = cy < 0 ? 0 : BS - 1;
+      const bool xwall = cx < 0 ? i0 == 0 : i0 == NX - 1, ywall = cy < 0 ? j0 == 0 : j0 == NY - 1;
+      if (xwall || ywall) {
+        // walls (3131-3255): x faces over the whole ghost column first, then y faces over the whole ghost row
+        for (int d = 0; d < dim; d++) {
+          double v = ywall ? at(gx, ey, d) : at(ex, gy, d);  // ywall: (gx, ey) is the W/E ghost, or the x-wall ghost
+          if (vector && ((ywall && d == 1) || (!ywall && d == 0))) v = -v;
+          at(gx, gy, d) = v;
+        }
+        continue;
+      }
+      const int ni = i0 + cx, nj = j0 + cy;
+      int k = L.find(l, ni, nj);
+      if (k >= 0) {
+        const int cell = (cy < 0 ? BS - 1 : 0) * BS + (cx < 0 ? BS - 1 : 0);
+        for (int d = 0; d < dim; d++) at(gx, gy, d) = f[((size_t)k * BC + cell) * dim + d];
+      } else if (l > 0 && L.find(l - 1, ni >> 1, nj >> 1) >= 0) {
+        // second-order Taylor expansion about the coarse cell under the ghost (TestInterp 2219-2230); the reference
+        // hands it component 0 for every component (2753-2763) -- kept
+        const int XX = 4 * i0 + (cx < 0 ? -1 : 4), YY = 4 * j0 + (cy < 0 ? -1 : 4);
+        const double dx = cx < 0 ? 0.25 : -0.25, dy = cy < 0 ? 0.25 : -0.25;
+        double C[3][3];
+        for (int a = 0; a < 3; a++)
+          for (int c = 0; c < 3; c++) C[a][c] = coarse0(XX - 1 + a, YY - 1 + c);
+        const double dudx = 0.5 * (C[2][1] - C[0][1]);
+        const double dudy = 0.5 * (C[1][2] - C[1][0]);
+        const double dudxdy = 0.25 * ((C[0][0] + C[2][2]) - (C[2][0] + C[0][2]));
+        const double dudx2 = (C[0][1] + C[2][1]) - 2.0 * C[1][1];
+        const double dudy2 = (C[1][0] + C[1][2]) - 2.0 * C[1][1];
+        const double v = (C[1][1] + (dx * dudx + dy * dudy)) + (((0.5 * dx * dx) * dudx2 + (0.5 * dy * dy) * dudy2) + (dx * dy) * dudxdy);
+        for (int d = 0; d < dim; d++) at(gx, gy, d) = v;
+      } else {
+        k = L.find(l + 1, 2 * i0 + (cx > 0 ? 2 : -1), 2 * j0 + (cy > 0 ? 2 : -1));
+        const int x = cx < 0 ? BS - 2 : 0, y = cy < 0 ? BS - 2 : 0;
+        for (int d = 0; d < dim; d++) {
+          const auto q = [&](int yy, int xx) { return f[((size_t)k * BC + yy * BS + xx) * dim + d]; };
+          at(gx, gy, d) = k < 0 ? nan : (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
+        }
+      }
+    }
+}
+
+// the four children (kid[J][I] -> out[(2 * J + I)][64 * dim]) of a block from its tile: second-order Taylor expansion
+// about the parent cell (main.cpp:4981-5032), operand order kept
+void prolong(const double *T, int dim, double *out) {
+  constexpr int BS = CUP2D_BS, W = BS + 2;
+  for (int J = 0; J < 2; J++)
+    for (int I = 0; I < 2; I++) {
+      double *kid = out + (size_t)(2 * J + I) * BC * dim;
+      for (int j = 0; j < BS; j += 2)
+        for (int i = 0; i < BS; i += 2) {
+          const int ic = i / 2 + 4 * I + 1, jc = j / 2 + 4 * J + 1;
+          for (int d = 0; d < dim; d++) {
+            const auto u = [&](int dj, int di) { return T[((jc + dj) * W + ic + di) * dim + d]; };
+            const double l00 = u(0, 0), l0p = u(1, 0), l0m = u(-1, 0), lm0 = u(0, -1), lmm = u(-1, -1), lmp = u(1, -1);
+            const double lp0 = u(0, 1), lpm = u(-1, 1), lpp = u(1, 1);
+            const double x = 0.5 * (lp0 - lm0), y = 0.5 * (l0p - l0m);
+            const double x2 = (lp0 + lm0) - 2.0 * l00, y2 = (l0p + l0m) - 2.0 * l00;
+            const double xy = 0.25 * ((lpp + lmm) - (lpm + lmp));
+            const double c2 = 0.03125 * x2 + 0.03125 * y2;
+            kid[(j * BS + i) * dim + d] = (l00 + (-0.25 * x - 0.25 * y)) + (c2 + 0.0625 * xy);
+            kid[(j * BS + i + 1) * dim + d] = (l00 + (+0.25 * x - 0.25 * y)) + (c2 - 0.0625 * xy);
+            kid[((j + 1) * BS + i) * dim + d] = (l00 + (-0.25 * x + 0.25 * y)) + (c2 - 0.0625 * xy);
+            kid[((j + 1) * BS + i + 1) * dim + d] = (l00 + (+0.25 * x + 0.25 * y)) + (c2 + 0.0625 * xy);
+          }
+        }
+    }
+}
+
+// distance along the Hilbert curve of a 2^bits square (the order of the reference's blocks, main.cpp:347-360, 1550-1562)
+uint64_t hilbert(int bits, uint64_t x, uint64_t y) {
+  const uint64_t n = 1ull << bits;
+  uint64_t d = 0;
+  for (uint64_t s = n >> 1; s > 0; s >>= 1) {
+    const uint64_t rx = (x & s) ? 1 : 0, ry = (y & s) ? 1 : 0;
+    d += s * s * ((3 * rx) ^ ry);
+    if (ry == 0) {
+      if (rx == 1) {
+        x = n - 1 - x;
+        y = n - 1 - y;
+      }
+      std::swap(x, y);
+    }
+  }
+  return d;
+}
+
+}  // namespace
+
+extern "C" int cup2d_amr_tables(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int32_t *kind, int32_t *nbr2,
+                                int32_t *half) {
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_tables")) return CUP2D_ERR_ARG;
+  if (!kind || !nbr2 || !half) {
+    cup2d::set_error("amr_tables: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  for (int b = 0; b < nblocks; b++)
+    for (int s = 0; s < 4; s++) {
+      const Side S = side_of(L, b, s);
+      if (S.kind < 0) {
+        cup2d::set_error("amr_tables: block (%d, %d, %d) side %d: neither a leaf, a coarser leaf nor two finer leaves across "
+                         "(grid not 2:1 balanced?)", L.level(b), L.bi(b), L.bj(b), s);
+        return CUP2D_ERR_ARG;
+      }
+      kind[4 * b + s] = S.kind;
+      nbr2[(4 * b + s) * 2] = S.n0;
+      nbr2[(4 * b + s) * 2 + 1] = S.n1;
+      half[4 * b + s] = S.half;
+    }
+  return CUP2D_OK;
+}
+
+extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                         int32_t *st) {
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_validate_states")) return CUP2D_ERR_ARG;
+  if (!st || level_max < 1) {
+    cup2d::set_error("amr_validate_states: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  bool any = false;
+  for (int k = 0; k < nblocks; k++) {
+    if ((st[k] == REFINE && L.level(k) == level_max - 1) || (st[k] == COMPRESS && L.level(k) == 0)) st[k] = LEAVE;
+    any = any || st[k] != LEAVE;
+  }
+  if (!any) return CUP2D_OK;
+  // blocks of every level (the passes below go level by level, finest first)
+  std::vector<std::vector<int>> of_level(level_max);
+  for (int k = 0; k < nblocks; k++)
+    if (L.level(k) < level_max) of_level[L.level(k)].push_back(k);
+  for (int m = level_max - 1; m >= 0; m--) {
+    // next to finer blocks: may not compress; refines if one of those is refining (main.cpp:4734-4803)
+    if (m < level_max - 1)
+      for (int k : of_level[m]) {
+        if (st[k] == REFINE) continue;
+        const int i = L.bi(k), j = L.bj(k);
+        bool done = false;
+        for (int x = -1; x <= 1 && !done; x++)
+          for (int y = -1; y <= 1 && !done; y++) {
+            if ((x == 0 && y == 0) || !L.inside(m, i + x, j + y)) continue;
+            if (L.find(m, i + x, j + y) >= 0 || (m > 0 && L.find(m - 1, (i + x) >> 1, (j + y) >> 1) >= 0)) continue;
+            if (st[k] == COMPRESS) st[k] = LEAVE;
+            const int bstep = (x != 0 && y != 0) ? 3 : 1;
+            for (int B = 0; B < 2; B += bstep) {
+              const int aux = x != 0 ? B % 2 : B / 2;
+              const int fi = 2 * i + (x > 0 ? x : 0) + x + (B % 2) * (x == 0 ? 1 : 0);
+              const int fj = 2 * j + (y > 0 ? y : 0) + y + aux * (y == 0 ? 1 : 0);
+              const int fk = L.find(m + 1, fi, fj);
+              if (fk >= 0 && st[fk] == REFINE) {
+                st[k] = REFINE;
+                done = true;
+                break;
+              }
+            }
+          }
+      }
+    if (m == 0) break;
+    // a compressing block next to a same-level refining block stays (main.cpp:4804-4830)
+    for (int k : of_level[m]) {
+      if (st[k] != COMPRESS) continue;
+      const int i = L.bi(k), j = L.bj(k);
+      for (int x = -1; x <= 1; x++)
+        for (int y = -1; y <= 1; y++) {
+          if ((x == 0 && y == 0) || !L.inside(m, i + x, j + y)) continue;
+          const int nk = L.find(m, i + x, j + y);
+          if (nk >= 0 && st[nk] == REFINE) st[k] = LEAVE;
+        }
+    }
+  }
+  // four siblings compress together or not at all (main.cpp:4831-4861)
+  for (int k = 0; k < nblocks; k++) {
+    const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+    int sib[4];
+    bool all = true;
+    for (int a = 0; a < 2; a++)
+      for (int c = 0; c < 2; c++) {
+        const int s = L.find(l, 2 * (i >> 1) + a, 2 * (j >> 1) + c);
+        sib[2 * a + c] = s;
+        all = all && s >= 0 && st[s] == COMPRESS;
+      }
+    if (!all)
+      for (int s : sib)
+        if (s >= 0 && st[s] == COMPRESS) st[s] = LEAVE;
+  }
+  return CUP2D_OK;
+}
+
+extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                      const int32_t *st, int nfields, const double *const *fields, const int32_t *dims,
+                                      const int32_t *is_vector, long long cap, int32_t *new_blocks,
+                                      double *const *new_fields) {
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid")) return CUP2D_ERR_ARG;
+  if (!st || nfields < 0 || (nfields && (!fields || !dims || !is_vector))) {
+    cup2d::set_error("amr_regrid: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  // a Compress state counts only where the four siblings agree (validated states guarantee it)
+  long long n_new = 0;
+  for (int k = 0; k < nblocks; k++) {
+    if (st[k] == REFINE) n_new += 4;
+    else if (st[k] == COMPRESS) {
+      const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+      for (int a = 0; a < 4; a++) {
+        const int s = L.find(l, 2 * (i >> 1) + (a & 1), 2 * (j >> 1) + (a >> 1));
+        if (l == 0 || s < 0 || st[s] != COMPRESS) {
+          cup2d::set_error("amr_regrid: block %d compresses without its siblings (states not validated)", k);
+          return CUP2D_ERR_ARG;
+        }
+      }
+      if ((i & 1) == 0 && (j & 1) == 0) n_new += 1;
+    } else n_new += 1;
+  }
+  if (!new_blocks) return n_new;
+  if (cap < n_new || (nfields && !new_fields)) {
+    cup2d::set_error("amr_regrid: capacity %lld < %lld new blocks", cap, n_new);
+    return CUP2D_ERR_ARG;
+  }
+  // new blocks in the order they are produced, then sorted along the Hilbert curve of the finest level
+  struct New {
+    int32_t l, i, j;
+    int src, part;  // part -1: copy of src; 0..3: child 2J+I of src; 4: parent of the sibling group whose (0,0) member is src
+    uint64_t key;
+  };
+  std::vector<New> nb;
+  nb.reserve(n_new);
+  int lmax_new = 0;
+  for (int k = 0; k < nblocks; k++) {
+    const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+    if (st[k] == REFINE) {
+      for (int J = 0; J < 2; J++)
+        for (int I = 0; I < 2; I++) nb.push_back({l + 1, 2 * i + I, 2 * j + J, k, 2 * J + I, 0});
+    } else if (st[k] == COMPRESS) {
+      if ((i & 1) == 0 && (j & 1) == 0) nb.push_back({l - 1, i >> 1, j >> 1, k, 4, 0});
+    } else {
+      nb.push_back({l, i, j, k, -1, 0});
+    }
+  }
+  for (const New &b : nb) lmax_new = std::max(lmax_new, (int)b.l);
+  const int Lf = std::max(level_max - 1, lmax_new);
+  int base_bits = 0;
+  while ((1 << base_bits) < std::max(bpdx, bpdy)) base_bits++;
+  const int bits = std::max(1, Lf + base_bits);
+  for (New &b : nb) b.key = hilbert(bits, (uint64_t)b.i << (Lf - b.l), (uint64_t)b.j << (Lf - b.l));
+  std::vector<int> order(nb.size());
+  for (size_t k = 0; k < nb.size(); k++) order[k] = (int)k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+    return nb[a].key != nb[c].key ? nb[a].key < nb[c].key : nb[a].l < nb[c].l;
+  });
+  std::vector<int> where(nb.size());  // position of produced block k in the output
+  for (size_t p = 0; p < order.size(); p++) {
+    where[order[p]] = (int)p;
+    const New &b = nb[order[p]];
+    new_blocks[3 * p] = b.l;
+    new_blocks[3 * p + 1] = b.i;
+    new_blocks[3 * p + 2] = b.j;
+  }
+  constexpr int BS = CUP2D_BS;
+  for (int fi = 0; fi < nfields; fi++) {
+    const int dim = dims[fi];
+    if (dim < 1 || dim > 2 || !fields[fi] || !new_fields[fi]) {
+      cup2d::set_error("amr_regrid: field %d: bad dim or pointer", fi);
+      return CUP2D_ERR_ARG;
+    }
+    const double *f = fields[fi];
+    double *g = new_fields[fi];
+    const size_t bsz = (size_t)BC * dim;
+    for (long long p = 0; p < (long long)nb.size(); p++) {
+      const New &b = nb[p];
+      if (b.part == -1) {
+        std::copy(f + b.src * bsz, f + (b.src + 1) * bsz, g + where[p] * bsz);
+      } else if (b.part == 4) {  // mean of the 2 x 2 cells of the four siblings (main.cpp:5149-5166)
+        const int l = L.level(b.src), i = L.bi(b.src), j = L.bj(b.src);
+        double *o = g + where[p] * bsz;
+        for (int J = 0; J < 2; J++)
+          for (int I = 0; I < 2; I++) {
+            const double *kid = f + (size_t)L.find(l, i + I, j + J) * bsz;
+            for (int y = 0; y < BS / 2; y++)
+              for (int x = 0; x < BS / 2; x++)
+                for (int d = 0; d < dim; d++) {
+                  const auto q = [&](int yy, int xx) { return kid[(yy * BS + xx) * dim + d]; };
+                  o[((4 * J + y) * BS + 4 * I + x) * dim + d] =
+                      (q(2 * y, 2 * x) + q(2 * y + 1, 2 * x) + q(2 * y, 2 * x + 1) + q(2 * y + 1, 2 * x + 1)) / 4;
+                }
+          }
+      } else if (b.part == 0) {  // the four children are produced consecutively: prolong once
+        double T[(BS + 2) * (BS + 2) * 2], kids[4 * BC * 2];
+        halo1_tile(L, f, dim, is_vector[fi] != 0, b.src, T);
+        prolong(T, dim, kids);
+        for (int c = 0; c < 4; c++) std::copy(kids + c * bsz, kids + (c + 1) * bsz, g + where[p + c] * bsz);
+      }
+    }
+  }
+  return n_new;
+}

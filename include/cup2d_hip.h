@@ -216,6 +216,29 @@ int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t
 long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half, long long cap,
                                 int32_t *row, int32_t *col, double *val);
 
+/* ---- regridding on the host (no context, no GPU): the reference's adapt() (main.cpp:4657-5440) on dense tables ----
+ * blocks = [nblocks][3] leaves (level, i, j) of a bpdx x bpdy base grid.  Fields are per-block arrays
+ * [nblocks][64 * dim], components interleaved, in the order of `blocks` (what cup2d_download_slab returns).
+ *
+ * cup2d_amr_tables: the topology tables cup2d_set_amr takes (replaces the tree / Znei / Zchild look-ups, main.cpp:672-738);
+ * CUP2D_ERR_ARG when a side is neither wall, leaf, coarser leaf nor two finer leaves (grid not 2:1 balanced).
+ *
+ * cup2d_amr_validate_states: states[] (0 leave, 1 refine, 2 compress -- the tags of main.cpp:4671-4703) made
+ * consistent in place exactly as main.cpp:4718-4861 does: 2:1 balance across faces and corners, finest level first;
+ * four siblings compress together or not at all.
+ *
+ * cup2d_amr_regrid: applies validated states.  A refined block becomes its four children, prolonged from its
+ * tensorial halo-1 tile (BlockLab Stencil{-1,-1,2,2,true}, main.cpp:4906-4913, 4981-5032) of the OLD grid; four
+ * compressing siblings become their parent (2 x 2 means, main.cpp:5149-5166).  is_vector selects the wall condition
+ * of the tile (VectorLab / ScalarLab).  Returns the new block count; with new_blocks == NULL nothing else is done;
+ * otherwise new_blocks[cap][3] and new_fields[f][cap][64 * dims[f]] are filled, ordered along the Hilbert curve of
+ * the finest level (main.cpp:1550-1562).  Bit-identical to the reference's adapt() (tests/test_amr.py). */
+int cup2d_amr_tables(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int32_t *kind, int32_t *nbr2, int32_t *half);
+int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, int32_t *states);
+long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
+                           int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
+                           long long cap, int32_t *new_blocks, double *const *new_fields);
+
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:
  * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL. */

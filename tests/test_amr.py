@@ -85,6 +85,50 @@ def test_amr_regrid_vs_reference_adapt(oracle):
         P.AmrBlockGrid(blocks)  # the result is a valid (2:1 balanced) tiling
 
 
+def test_amr_host_regrid_library_vs_python_statement():
+    """the library's host regridding (cup2d_amr_validate_states, cup2d_amr_regrid: leaf table + closed-form sides and
+    corners) against the Python statement on the general-stencil BlockLab (amr_lab.py, itself pinned to tiles dumped
+    by the reference): random tags on random balanced grids, bit for bit, every kind of side and corner visited"""
+    from cup2d_amd import amr as A
+    from cup2d_amd.amr_lab import Tree
+    seen = dict(coarse_corner=0, fine_corner=0, coarse_face=0, fine_face=0, compress=0)
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        level_max, l0 = 4 + seed % 3, 1 + seed % 2
+        blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
+        vel, pres = rng.uniform(-1, 1, (len(blocks), 128)), rng.uniform(-1, 1, (len(blocks), 64))
+        pr, pc = [0.15, 0.3, 0.1][seed % 3], [0.3, 0.15, 0.5][seed % 3]
+        for it in range(6):
+            nb = len(blocks)
+            if nb > 300:
+                break
+            st0 = rng.choice([0, 1, 2], size=nb, p=[1 - pr - pc, pr, pc]).astype(np.int32)
+            st = A.validate_states(blocks, st0, level_max)
+            assert np.array_equal(st, A.validate_states_py(blocks, st0, level_max)), (seed, it)
+            tree = Tree(blocks)
+            for k, (l, i, j) in enumerate(blocks):
+                if st[k] != A.REFINE:
+                    continue
+                for cx in (-1, 0, 1):
+                    for cy in (-1, 0, 1):
+                        if (cx or cy) and 0 <= i + cx < 1 << l and 0 <= j + cy < 1 << l:
+                            t = tree.state(int(l), int(i + cx), int(j + cy))
+                            what = "corner" if cx and cy else "face"
+                            seen["coarse_" + what] += t == -2
+                            seen["fine_" + what] += t == -1
+            seen["compress"] += int((st == A.COMPRESS).sum())
+            fields = {"vel": (vel, 2, True), "pres": (pres, 1, False)}
+            b_c, d_c = A.regrid(blocks, st, fields, level_max)
+            b_py, d_py = A.regrid_py(blocks, st, fields, level_max)
+            assert np.array_equal(b_c, b_py), (seed, it)
+            for k in d_py:
+                assert np.array_equal(d_c[k], d_py[k]) and not np.isnan(d_c[k]).any(), (seed, it, k)
+            blocks, vel, pres = b_c, d_c["vel"], d_c["pres"]
+            g = A.AmrBlockGrid(blocks)  # stays 2:1 balanced (raises otherwise)
+            assert g.nblocks == len(blocks)
+    assert all(v > 10 for v in seen.values()), seen
+
+
 def test_amr_topology_tables(oracle):
     """cup2d_amd.amr.AmrBlockGrid (product) against the oracle's neighbour logic; level jumps are 2:1"""
     from cup2d_amd import lib as L

@@ -101,6 +101,8 @@ class TorchComm:
         self.send = torch.zeros(max(1, topo.nsend) * self.MAX_STRIP, dtype=torch.float64, device=dev)
         self.recv = torch.zeros(max(1, topo.nrecv) * self.MAX_STRIP, dtype=torch.float64, device=dev)
         self.red = torch.zeros(8, dtype=torch.float64, device=dev)
+        self._ops = {}
+        self._red_views = {}
         if mode == "staged":
             self.h_send = torch.zeros_like(self.send, device="cpu").pin_memory()
             self.h_recv = torch.zeros_like(self.recv, device="cpu").pin_memory()
@@ -117,12 +119,19 @@ class TorchComm:
 
     # ---- point-to-point -----------------------------------------------------------------------
     def _p2p(self, send, recv, strip_doubles):
+        """post all receives, then all sends, as one batch (one ncclGroup on RCCL).  The P2POp lists are built once
+        per strip width: an exchange happens twice per BiCGSTAB iteration, its host cost is on the critical path of
+        keeping the GPU fed."""
         dist = self.dist
-        ops = []
-        for peer, soff, roff, n in self.topo.peers:
-            ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer))
-        for peer, soff, roff, n in self.topo.peers:
-            ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer))
+        key = (send.data_ptr(), recv.data_ptr(), strip_doubles)
+        ops = self._ops.get(key)
+        if ops is None:
+            ops = []
+            for peer, soff, roff, n in self.topo.peers:
+                ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer))
+            for peer, soff, roff, n in self.topo.peers:
+                ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer))
+            self._ops[key] = ops
         return dist.batch_isend_irecv(ops) if ops else []
 
     def exchange(self, strip_doubles):
@@ -157,8 +166,11 @@ class TorchComm:
         torch, dist = self.torch, self.dist
         rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
         if self.mode == "device":
+            view = self._red_views.get((offset, count))
+            if view is None:
+                view = self._red_views[(offset, count)] = self.red[offset:offset + count]
             with torch.cuda.stream(self.compute_stream):
-                dist.all_reduce(self.red[offset:offset + count], op=rop)
+                dist.all_reduce(view, op=rop)
         elif self.mode == "staged":
             with torch.cuda.stream(self.compute_stream):
                 self.h_red[offset:offset + count].copy_(self.red[offset:offset + count], non_blocking=True)

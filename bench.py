@@ -151,6 +151,21 @@ def main():
     if not args.no_kernel_timers:
         elapsed_plain, _ = timed_steps(False)
 
+    # ---- outside the timed region: the Poisson smoother sweep ---------------------------------------------
+    # BASELINE.json configs[1] words the pressure part "50 Jacobi pressure iters/step"; the reference has no smoother
+    # (SURVEY.md F4), the step above runs its real solver.  The weighted-Jacobi sweep (csrc/smoother.hip, 24 B/cell)
+    # is timed here on the Poisson system of the last step, every launch bracketed by HIP events.
+    if not args.no_kernel_timers and world == 1:
+        try:
+            sim.jacobi_sweeps(5, omega=0.8)
+            sim.set_timing(1)
+            sim.jacobi_sweeps(50, omega=0.8)
+            ms, calls = sim.get_timing(L.TIMER_NAMES.index("smoother"))
+            timers["smoother"] = {"ms_total": round(ms, 4), "launches": calls, "ms_avg": round(ms / calls, 5) if calls else None}
+            sim.set_timing(False)
+        except Exception as e:  # an extra, never the reason the bench line is missing
+            timers["smoother"] = {"ms_total": 0.0, "launches": 0, "ms_avg": None, "error": str(e)[:200]}
+
     # ---- rooflines --------------------------------------------------------------------------------
     # Algorithmic (compulsory) bytes per cell and launch of every kernel family, FP64, halo re-reads
     # excluded (DESIGN.md section 4 derives each line):
@@ -159,15 +174,16 @@ def main():
     #   sweep_A       reads p, nu, r 24 + writes p, z 16 = 40      sweep_C  reads r, nu 16 + writes r, z2 16 = 32
     #   sweep_B / D   reads z (z2) 8 + rhat (r) 8, writes nu (t) 8 = 24
     #   sweep_E       reads x, z, z2, r, t, rhat 48 + writes x, r 16 = 64
+    #   smoother      weighted-Jacobi sweep (not part of the step): reads x, b 16 + writes x' 8 = 24
     #   fused solver (krylov_fused.hip): sweep_A = A+B in one launch: reads p, nu, r, rhat 32 + writes p', nu' 16 = 48
     #   sweep_C = C+D: reads r, nu 16 + writes s, t 16 = 32     sweep_E: reads y, p, s, t, rhat 40 + writes y, r 16 = 56
     ALGO_BYTES = {"advect_stage": 40.0, "poisson_rhs": 32.0, "sweep_A": 40.0, "sweep_B": 24.0, "sweep_C": 32.0,
-                  "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0}
+                  "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0, "smoother": 24.0}
     mk = "true" if args.finish == "kernel" and world == 1 else "false"
     KERNEL_OF = {"advect_stage": "k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>",
                  "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1, %s>" % mk,
                  "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2, %s>" % mk, "sweep_E": "k_sweepE<%s>" % mk,
-                 "init_residual": "k_init_residual"}
+                 "init_residual": "k_init_residual", "smoother": "k_smoother<0, false>"}
     sweeps = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")
     if fused:
         ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 32.0, "sweep_E": 56.0})

@@ -196,6 +196,19 @@ class Simulation:
                  "poisson_solve")
         return dict(iters=it.value, restarts=rs.value, err=e.value, err_init=e0.value)
 
+    def jacobi_sweeps(self, nsweeps, omega=0.8):
+        """nsweeps weighted-Jacobi sweeps on A pres = tmp (cup2d_jacobi_sweeps); returns max|tmp - A pres| of the
+        iterate before the last sweep (left in pold)"""
+        e = ctypes.c_double()
+        _l.check(self.L.cup2d_jacobi_sweeps(self._ctx, float(omega), int(nsweeps), ctypes.byref(e)), "jacobi_sweeps")
+        return e.value
+
+    def poisson_residual(self):
+        """pold = tmp - A pres; returns its max norm (cup2d_poisson_residual)"""
+        e = ctypes.c_double()
+        _l.check(self.L.cup2d_poisson_residual(self._ctx, ctypes.byref(e)), "poisson_residual")
+        return e.value
+
     def step(self, tol=None, rel_tol=None, max_restarts=None, max_iter=1000):
         """One pass of the time-loop body.  Like main.cpp:7028-7030 the first ten steps run the
         solver with zero tolerances unless tolerances are given explicitly."""

@@ -216,6 +216,19 @@ int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t
 long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half, long long cap,
                                 int32_t *row, int32_t *col, double *val);
 
+/* ---- Poisson smoother sweep and residual (the streaming 5-point kernels of the path) ----
+ * A = the matrix-free Poisson operator: pressure_rhs1's 5-point sum (main.cpp:6209-6230) with the homogeneous-Neumann
+ * walls of the assembled matrix (main.cpp:7034-7112), x = PRES, b = TMP.
+ * cup2d_jacobi_sweeps: nsweeps times x <- x + (b - A x) * (omega / diag(A)), diag(A) = -(number of neighbours of the
+ *   cell).  The reference has no smoother (its solve is BiCGSTAB, cup2d_poisson_solve); this is the "50 Jacobi
+ *   pressure iters/step" unit of BASELINE.json configs[1] (24 B/cell).  POLD is the second buffer: the
+ *   iterate before the last sweep is left there.  linf (may be NULL) = max|b - A x| of that previous iterate.
+ * cup2d_poisson_residual: POLD = b - A x, linf = max|b - A x| (the reference's stopping norm, cuda.cu:303-311).
+ * Same-level grids with the matrix-free operator only (CUP2D_ERR_UNSUPPORTED otherwise); with a communicator the
+ * width-1 halo of x is exchanged before every sweep and linf is reduced over the ranks. */
+int cup2d_jacobi_sweeps(cup2d_ctx *ctx, double omega, int nsweeps, double *linf);
+int cup2d_poisson_residual(cup2d_ctx *ctx, double *linf);
+
 /* ---- regridding on the host (no context, no GPU): the reference's adapt() (main.cpp:4657-5440) on dense tables ----
  * blocks = [nblocks][3] leaves (level, i, j) of a bpdx x bpdy base grid.  Fields are per-block arrays
  * [nblocks][64 * dim], components interleaved, in the order of `blocks` (what cup2d_download_slab returns).
@@ -301,7 +314,8 @@ typedef enum {
   CUP2D_T_REDUCE = 9,       /* max|u| (dt) */
   CUP2D_T_HALO = 10,        /* pack / unpack */
   CUP2D_T_INIT_RESIDUAL = 11, /* r = b - A x0 + its reductions (once per solve) */
-  CUP2D_T_NTIMERS = 12
+  CUP2D_T_SMOOTHER = 12,    /* weighted-Jacobi sweep / Poisson residual (k_smoother) */
+  CUP2D_T_NTIMERS = 13
 } cup2d_timer;
 int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);

@@ -124,6 +124,35 @@ def apply_A(x):
     return y
 
 
+def poisson_diag(ny, nx):
+    """diagonal of the assembled Poisson matrix on a same-level grid (main.cpp:7034-7112): -(number of neighbours)"""
+    d = np.full((ny, nx), -4.0)
+    d[0, :] += 1
+    d[-1, :] += 1
+    d[:, 0] += 1
+    d[:, -1] += 1
+    return d
+
+
+def poisson_residual(x, b):
+    """r = b - A x and its max norm (the reference's stopping norm, cuda.cu:303-311)"""
+    r = _c(b) - apply_A(x)
+    return r, float(np.abs(r).max())
+
+
+def jacobi_sweeps(x, b, omega, nsweeps):
+    """nsweeps times x <- x + (b - A x) * (omega / diag(A)) (the benchmark smoother; the reference
+    has none).  Returns (x, max|b - A x| of the iterate before the last sweep)."""
+    x, b = _c(x).copy(), _c(b)
+    c = omega / poisson_diag(*x.shape)
+    linf = 0.0
+    for _ in range(nsweeps):
+        r = b - apply_A(x)
+        linf = float(np.abs(r).max())
+        x = x + r * c
+    return x, linf
+
+
 def precond(x, P=None):
     x = _c(x)
     ny, nx = x.shape

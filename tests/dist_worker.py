@@ -96,6 +96,16 @@ def run_gpu(rank, world, px, py, nbx, nby):
     sim.poisson_rhs(dt)
     bref = O.laplacian_sub(pres, O.pressure_rhs(ref, h, dt))
     assert np.array_equal(sim.tmp, bref[sl]), "poisson rhs mismatch"
+    # smoother sweeps and residual (csrc/smoother.hip): a width-1 exchange per sweep, max norm through the all-reduce
+    # callback; bit-identical to the global oracle
+    x0 = rng.uniform(-1, 1, (gny, gnx))
+    sim.pres = x0[sl]
+    e = sim.jacobi_sweeps(3, omega=0.8)
+    xj, ej = O.jacobi_sweeps(x0, bref, 0.8, 3)
+    assert np.array_equal(sim.pres, xj[sl]) and e == ej, "jacobi mismatch on rank %d" % rank
+    assert sim.poisson_residual() == O.poisson_residual(xj, bref)[1]
+    sim.pold = pres[sl]
+    sim.fill(L.PRES, 0.0)
     # solve: reductions through the all-reduce callback, Krylov halos overlapped
     info = sim.poisson_solve(tol=1e-9, rel_tol=0.0, max_restarts=100)
     # the default (tile-fused) solver with ghost blocks: z edges of the boundary blocks exchanged per sweep

@@ -116,6 +116,58 @@ def test_poisson_operator_preconditioner(gpu_lib, oracle):
         assert np.abs(s.tmp - oracle.precond(x, P)).max() < 1e-14
 
 
+@pytest.mark.parametrize("nx,ny,order", [(64, 64, "hilbert"), (128, 128, "hilbert"), (40, 24, "hilbert"), (24, 40, "rowmajor"),
+                                         (16, 8, "rowmajor"), (8, 8, "hilbert"), (136, 72, "hilbert"), (256, 256, "rowmajor")])
+def test_jacobi_sweep_and_residual_bit_exact(gpu_lib, oracle, nx, ny, order):
+    """the tile kernels of csrc/smoother.hip (weighted-Jacobi sweep, Poisson residual) against the oracle, bit for
+    bit: full tiles, a moved last tile (block count not a multiple of 16), fewer than 16 blocks, one block, walls on
+    every side, both block orders; pointer roles after an odd and an even number of sweeps"""
+    import cup2d_amd
+    rng = np.random.default_rng(nx * 1000 + ny)
+    x0 = rng.uniform(-1, 1, (ny, nx))
+    b = rng.uniform(-1, 1, (ny, nx))
+    with cup2d_amd.Simulation(nx // 8, ny // 8, order=order) as s:
+        s.pres, s.tmp = x0, b
+        e = s.poisson_residual()
+        r, eo = oracle.poisson_residual(x0, b)
+        assert np.array_equal(s.pold, r) and e == eo
+        assert np.array_equal(s.pres, x0) and np.array_equal(s.tmp, b)
+        for nsweeps in (1, 2, 5):
+            s.pres = x0
+            e = s.jacobi_sweeps(nsweeps, omega=0.8)
+            xo, eo = oracle.jacobi_sweeps(x0, b, 0.8, nsweeps)
+            assert np.array_equal(s.pres, xo), (nsweeps, np.abs(s.pres - xo).max())
+            assert e == eo
+            assert np.array_equal(s.pold, oracle.jacobi_sweeps(x0, b, 0.8, nsweeps - 1)[0])  # the previous iterate
+        assert s.jacobi_sweeps(0) == 0.0 and np.array_equal(s.pres, xo)
+
+
+def test_jacobi_smoother_reduces_the_residual_at_2048(gpu_lib):
+    """BASELINE.json configs[1] (2048^2, 50 Jacobi pressure iterations): properties that need no oracle -- constants
+    are a fixed point for b = 0, the residual norm of a zero-mean problem does not grow, the norm the sweep
+    reports is the norm cup2d_poisson_residual computes for the same iterate"""
+    n = 2048
+    rng = np.random.default_rng(11)
+    with make_sim(n) as s:
+        s.fill(L.TMP, 0.0)
+        s.fill(L.PRES, 3.25)
+        assert s.jacobi_sweeps(3) == 0.0 and np.all(s.pres == 3.25)
+        b = rng.uniform(-1, 1, (n, n))
+        b -= b.mean()
+        s.tmp = b
+        s.fill(L.PRES, 0.0)
+        e0 = s.poisson_residual()
+        assert e0 == np.abs(b).max()
+        s.fill(L.PRES, 0.0)
+        e_prev = s.jacobi_sweeps(50, omega=0.8)   # norm of the iterate before sweep 50 ...
+        x49 = s.pold.copy()
+        x50 = s.pres.copy()
+        s.pres = x49
+        assert s.poisson_residual() == e_prev     # ... is what the residual kernel gives for that iterate
+        s.pres = x50
+        assert s.poisson_residual() < 0.5 * e0 and e_prev < 0.5 * e0
+
+
 def test_solver_vs_golden_and_oracle(gpu_lib, oracle):
     G = golden("poisson_n32.npz")
     with make_sim(32) as s:

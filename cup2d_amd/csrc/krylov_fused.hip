@@ -37,14 +37,49 @@ constexpr int XS = 66;   // LDS stride of one block in the staging tile: the A-o
                          // (block = lane%16, k = 4ks + lane/16) then fall on 32 distinct 8-byte banks
 constexpr int FWG = 512;         // threads per workgroup of the fused sweeps: 8 waves, ONE workgroup per CU
 constexpr int FWAVES = FWG / 64;
-#ifndef CUP2D_FUSED_NT
-#define CUP2D_FUSED_NT 0  // 1: AB 195 -> 189 us at 4096^2 but its HBM reads 40 -> 50 B/cell (ring re-reads miss L2)
+// Cache policy of the individual streams of an iteration (bit set = non-temporal access).  An iteration moves ~20
+// vectors of 134 MB (4096^2) through a 256 MB memory-side cache and 8 x 4 MiB of L2: left alone, everything evicts
+// everything.  Policy: a stream that is consumed once, or whose consumer is a whole iteration away, bypasses
+// (p', t, y' stores; y, p, t, rhat loads of sweep E; rhat of sweep AB); the streams the NEXT launch consumes first
+// allocate (nu' for CD, s for E, r for AB) -- and so do the tile and ring loads of AB / CD, whose second touch by the
+// neighbouring tile must find them in L2.  Measured at 4096^2 (tools/build_policy_variants.sh, tools/gpu_call6.sh;
+// A / C / E in us, step in ms):
+//   0x000 nothing non-temporal             200 / 153 / 187   27.9
+//   0x00F stores of AB and CD              201 / 153 / 175   27.4    (the previous default)
+//   0xED9 this policy                      202 / 153 / 147   26.1
+//   0xED9 | 0x4000 (all AB loads)          224 / 160 / 156   27.9    ring re-reads miss L2
+//   0xED9 & ~0x208 (keep t as well as s)   202 / 152 / 169   27.1    two kept vectors overflow the cache
+//   0xED9 | 0x020 (r store)                198 / 154 / 158   26.3
+// Sweep E (pure streaming, 56 B/cell) gains 16 %: s comes out of the cache; AB and CD do not react -- they are bound
+// by their own load -> LDS -> MFMA pipeline, not by what the memory side delivers.
+//   0x001 AB store p'   0x002 AB store nu'   0x004 CD store s   0x008 CD store t
+//   0x010 E store y'    0x020 E store r      0x040 E load y     0x080 E load p    0x100 E load s   0x200 E load t
+//   0x400 E load rhat   0x800 AB load rhat   0x1000 AB tile load p   0x2000 AB tile load nu
+//   0x4000 AB every load of p, nu, r (tile and ring)   0x8000 CD loads of r   0x10000 CD loads of nu'
+#ifndef CUP2D_POLICY
+#define CUP2D_POLICY 0xED9
 #endif
-constexpr bool NT_LOADS = CUP2D_FUSED_NT != 0;
-#ifndef CUP2D_FUSED_NTS
-#define CUP2D_FUSED_NTS 1
-#endif
-constexpr bool NT_STORES = CUP2D_FUSED_NTS != 0;  // outputs are not re-read in the sweep: do not let them evict the inputs the ring re-reads need
+constexpr unsigned POL = CUP2D_POLICY;
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <bool NT>
+static __device__ __forceinline__ double2 ld2(const double2 *p) {
+  if (NT) {
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *p;
+}
+template <bool NT>
+static __device__ __forceinline__ void st2(double2 *p, double2 v) {
+  if (NT) {
+    v2d w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(p));
+  } else {
+    *p = v;
+  }
+}  // 
 constexpr int PL_DOUBLES = 16 * 4 * 64;  // P_inv as MFMA B fragments: [k-step][n-tile][lane]
 
 struct FusedLds {
@@ -226,10 +261,17 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const size_t o = (size_t)uniform(blk[e]) * BC + lane;
-      if (NT_LOADS && tile_job) {  // streamed once by the tile's own job: keep L2 for the ring re-reads
+      if (MODE == 0 && (POL & 0x4000)) {
         R.a[e] = __builtin_nontemporal_load(A.in0 + o);
         R.b[e] = __builtin_nontemporal_load(A.in1 + o);
-        if (MODE == 0) R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+        R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+      } else if (MODE == 1 && (POL & 0x18000)) {
+        R.a[e] = (POL & 0x8000) ? __builtin_nontemporal_load(A.in0 + o) : A.in0[o];
+        R.b[e] = (POL & 0x10000) ? __builtin_nontemporal_load(A.in1 + o) : A.in1[o];
+      } else if (MODE == 0 && tile_job && (POL & 0x3000)) {
+        R.a[e] = (POL & 0x1000) ? __builtin_nontemporal_load(A.in0 + o) : A.in0[o];
+        R.b[e] = (POL & 0x2000) ? __builtin_nontemporal_load(A.in1 + o) : A.in1[o];
+        R.c[e] = A.in2[o];
       } else {
         R.a[e] = A.in0[o];
         R.b[e] = A.in1[o];
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           if (MODE == 0 && restart) W[idx] = R.c[e];
           if (idx < nvalid) {
             const size_t o = (size_t)(b0 + idx) * BC + lane;
-            if (NT_STORES) __builtin_nontemporal_store(v, A.vout + o);
+            if (POL & (MODE == 0 ? 0x001 : 0x004)) __builtin_nontemporal_store(v, A.vout + o);
             else A.vout[o] = v;
             if (MODE == 0 && restart) A.w[o] = R.c[e];  // rhat = r
           }
@@ -280,7 +322,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         issue(Ra, T, j + 1, 0);
       } else if (MODE == 0 && !restart) {
 #pragma unroll
-        for (int i = 0; i < TB; i++) W[i] = A.w[(size_t)(b0 + min(i, nvalid - 1)) * BC + lane];
+        for (int i = 0; i < TB; i++) {
+          const double *pw = A.w + (size_t)(b0 + min(i, nvalid - 1)) * BC + lane;
+          W[i] = (POL & 0x800) ? __builtin_nontemporal_load(pw) : *pw;
+        }
       }
       stage(Rb, is_tile, 1);
       if (is_tile && t + t_stride < t_end) {
@@ -333,7 +378,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         const double l3 = *(iy > 0 ? zb - BS : ge + 2 * BS + ix);
         const double l4 = *(iy < BS - 1 ? zb + BS : ge + 3 * BS + ix);
         const double yv = l1 + l2 + l3 + l4 - 4 * l0;
-        if (NT_STORES) __builtin_nontemporal_store(yv, A.yout + (size_t)(b0 + i) * BC + lane);
+        if (POL & (MODE == 0 ? 0x002 : 0x008)) __builtin_nontemporal_store(yv, A.yout + (size_t)(b0 + i) * BC + lane);
         else A.yout[(size_t)(b0 + i) * BC + lane] = yv;
         acc[0] = __builtin_fma(yv, W[i], acc[0]);
         if constexpr (NDOT == 2) acc[1] = __builtin_fma(yv, yv, acc[1]);
@@ -423,17 +468,18 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, doubl
   double2 *__restrict__ yout = out == 0 ? y0 : (out == 1 ? y1 : y2);
   double sm[2] = {0.0, 0.0}, m[1] = {0.0};
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
-    double2 yv = yin[i];
-    const double2 pv = p[i], sv = s[i], tv = t[i], hv = rhat[i];
+    double2 yv = ld2<(POL & 0x040) != 0>(yin + i);
+    const double2 pv = ld2<(POL & 0x080) != 0>(p + i), sv = ld2<(POL & 0x100) != 0>(s + i);
+    const double2 tv = ld2<(POL & 0x200) != 0>(t + i), hv = ld2<(POL & 0x400) != 0>(rhat + i);
     yv.x = yv.x + alpha * pv.x;
     yv.y = yv.y + alpha * pv.y;
     yv.x = yv.x + omega * sv.x;
     yv.y = yv.y + omega * sv.y;
-    yout[i] = yv;
+    st2<(POL & 0x010) != 0>(yout + i, yv);
     double2 rv;
     rv.x = sv.x + momega * tv.x;
     rv.y = sv.y + momega * tv.y;
-    r[i] = rv;
+    st2<(POL & 0x020) != 0>(r + i, rv);
     sm[0] = __builtin_fma(hv.x, rv.x, sm[0]);
     sm[0] = __builtin_fma(hv.y, rv.y, sm[0]);
     sm[1] = __builtin_fma(rv.x, rv.x, sm[1]);

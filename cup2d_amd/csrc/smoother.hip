@@ -37,7 +37,7 @@ struct SmootherTile {
   int nb;  // neighbour of this lane's slot
 };
 
-template <int MODE, bool SMALL>
+template <int MODE, bool SMALL, int NT = 0>
 __global__ __launch_bounds__(WG, 3) void k_smoother(const double *__restrict__ x, const double *__restrict__ b,
                                                  double *__restrict__ out, const int *__restrict__ nbr, int first,
                                                  int count, double c4, double c3, double c2,
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(WG, 3) void k_smoother(const double *__restrict__ x
   const auto fetch_x = [&](SmootherTile &T, int tb) {
     const double *xb = x + (size_t)tb * BC + lane;
 #pragma unroll
-    for (int i = 0; i < JT; i++) T.xv[i] = xb[(SMALL ? min(i, nvalid - 1) : i) * BC];
+    for (int i = 0; i < JT; i++) {
+      const double *px = xb + (SMALL ? min(i, nvalid - 1) : i) * BC;
+      T.xv[i] = (NT & 4) ? __builtin_nontemporal_load(px) : *px;
+    }
   };
   const auto fetch_rim = [&](SmootherTile &T, int tb, int nb) {
     const bool rim = is_rim(nb, tb);  // <= 16 lanes: a W/E edge is 8 cells 64 B apart, an S/N edge 64 contiguous bytes
@@ -112,7 +115,10 @@ __global__ __launch_bounds__(WG, 3) void k_smoother(const double *__restrict__ x
       fetch_rim(T, tb, nb);
       const double *bb = b + (size_t)tb * BC + lane;
 #pragma unroll
-      for (int i = 0; i < JT; i++) T.bv[i] = bb[(SMALL ? min(i, nvalid - 1) : i) * BC];
+      for (int i = 0; i < JT; i++) {
+        const double *pb = bb + (SMALL ? min(i, nvalid - 1) : i) * BC;
+        T.bv[i] = (NT & 1) ? __builtin_nontemporal_load(pb) : *pb;
+      }
     }
     const auto body = [&](auto has_next, int t) {
       constexpr bool HAS_NEXT = decltype(has_next)::value;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(WG, 3) void k_smoother(const double *__restrict__ x
 #pragma unroll
       for (int i = 0; i < JT; i++) {
         const double bi = T.bv[i];
-        if constexpr (HAS_NEXT) T.bv[i] = bn[i * BC];
+        if constexpr (HAS_NEXT) T.bv[i] = (NT & 1) ? __builtin_nontemporal_load(bn + i * BC) : bn[i * BC];
         if (!SMALL || i < nvalid) {
           const double *rb = L.rec + i * REC;
           const double l0 = rb[lane], l1 = rb[o1], l2 = rb[o2], l3 = rb[o3], l4 = rb[o4];
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(WG, 3) void k_smoother(const double *__restrict__ x
             }
             o = l0 + r * c;
           }
-          ob[i * BC] = o;
+          if (NT & 2) __builtin_nontemporal_store(o, ob + i * BC);
+          else ob[i * BC] = o;
         }
       }
       wave_lds_sync();  // the next tile overwrites the records
@@ -200,16 +207,20 @@ static int smoother_grid(cup2d_ctx *c, int count, const void *kernel) {
 // one launch over the owned blocks; max|r| lands in d_red[0]
 template <int MODE>
 static int launch_smoother(cup2d_ctx *c, const double *x, const double *b, double *out, double omega) {
+  // cache policy (bit 0: b loads, bit 1: out stores, bit 2: x loads non-temporal).  x' of one sweep is x of the next
+  // and 134 MB at 4096^2: it survives in the 256 MB memory-side cache only if b, read once per sweep, does not
+  // allocate.  Measured at 4096^2, us per sweep: 0: 92   1: 73.5   2: 76.5   4: 84   5: 80   6: 79   3, 7: 90-99.
+  static const int nt = [] { const char *e = getenv("CUP2D_SMOOTHER_NT"); return e ? atoi(e) : 1; }();
   const bool small = c->nblocks < JT;
-  const void *k = small ? reinterpret_cast<const void *>(&k_smoother<MODE, true>) : reinterpret_cast<const void *>(&k_smoother<MODE, false>);
-  const int g = smoother_grid(c, c->nblocks, k);
-  const double c4 = omega / -4.0, c3 = omega / -3.0, c2 = omega / -2.0;
-  if (small)
-    hipLaunchKernelGGL((k_smoother<MODE, true>), dim3(g), dim3(WG), 0, c->stream, x, b, out, c->d_nbr, 0, c->nblocks, c4, c3, c2,
-                       c->d_partials, c->d_ticket, c->d_red);
-  else
-    hipLaunchKernelGGL((k_smoother<MODE, false>), dim3(g), dim3(WG), 0, c->stream, x, b, out, c->d_nbr, 0, c->nblocks, c4, c3, c2,
-                       c->d_partials, c->d_ticket, c->d_red);
+  using K = void (*)(const double *, const double *, double *, const int *, int, int, double, double, double, double *,
+                     unsigned *, double *);
+  static const K tab[8] = {(K)k_smoother<MODE, false, 0>, (K)k_smoother<MODE, false, 1>, (K)k_smoother<MODE, false, 2>,
+                           (K)k_smoother<MODE, false, 3>, (K)k_smoother<MODE, false, 4>, (K)k_smoother<MODE, false, 5>,
+                           (K)k_smoother<MODE, false, 6>, (K)k_smoother<MODE, false, 7>};
+  const K k = small ? (K)k_smoother<MODE, true> : tab[nt & 7];
+  const int g = smoother_grid(c, c->nblocks, reinterpret_cast<const void *>(k));
+  hipLaunchKernelGGL(k, dim3(g), dim3(WG), 0, c->stream, x, b, out, c->d_nbr, 0, c->nblocks, omega / -4.0, omega / -3.0,
+                     omega / -2.0, c->d_partials, c->d_ticket, c->d_red);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }

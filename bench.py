@@ -183,7 +183,7 @@ def main():
     KERNEL_OF = {"advect_stage": "k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>",
                  "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1, %s>" % mk,
                  "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2, %s>" % mk, "sweep_E": "k_sweepE<%s>" % mk,
-                 "init_residual": "k_init_residual", "smoother": "k_smoother<0, false>"}
+                 "init_residual": "k_init_residual", "smoother": "k_smoother<0, false, 1>"}
     sweeps = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")
     if fused:
         ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 32.0, "sweep_E": 56.0})

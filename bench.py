@@ -69,6 +69,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(cores, 16): the reference's per-block loops stop scaling there)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: libraries that talk on fd 1 (RCCL prints a version banner there from C)
+    # are sent to stderr for the whole run, the line is written to the saved descriptor at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import cup2d_amd
     from cup2d_amd import lib as L
@@ -300,10 +306,12 @@ def main():
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "kernels": timers, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     sim.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

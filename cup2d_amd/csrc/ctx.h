@@ -234,6 +234,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                      int *iters, int *restarts, double *linf, double *linf_init);
 // reduction finish + scalar update of `stage` as its own launch(es) (+ all-reduce callback with N GPUs)
 int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr);
+int finish_local(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status = nullptr);
 // halo-1 block operators on a block-AMR grid (amr.hip)
 int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract);
 int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt);

@@ -682,6 +682,19 @@ int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded,
   return CUP2D_OK;
 }
 
+// after a sweep whose last workgroup already summed this rank's partials into d_red (krylov_fused.hip, MERGE 2):
+// all-reduce over the ranks, then the scalar update
+int finish_local(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status) {
+  ProfScope prof(c, CUP2D_T_SCALARS);
+  if (c->allreduce) {
+    if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
+    if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+  }
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage, host_status);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // b = TMP, x0 = PRES, result -> PRES
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                int *restarts, double *linf, double *linf_init) {

@@ -157,7 +157,7 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 // is two batches of 8 blocks.  The global loads of a batch are issued one batch ahead of their use, across
 // job boundaries, so a wave always has 8 blocks x {3|2} vectors in flight while it stages, multiplies,
 // gathers; the w operand of the dot product (rhat) is requested before the tile's MFMA.
-template <int MODE, bool MERGE>
+template <int MODE, int MERGE>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                   int first, int count, int poff, int nowned,
@@ -387,8 +387,12 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     wave_lds_sync();  // the next tile overwrites S and GE
     T = N;
   }
-  fused_reduce_store<FWAVES, NDOT, MERGE>(acc, partials + poff);
-  if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, NDOT, 0, red, sc, MODE + 1, nullptr);
+  // MERGE 1: the last workgroup finishes the reduction and runs the scalar update (one GPU).  MERGE 2: it only sums
+  // this rank's partials -- those of an earlier launch of the same sweep included, poff of them -- into red; the
+  // all-reduce and the scalar update follow on the stream (N GPUs).
+  fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
+  if (MERGE && arrive_last(ticket))
+    finish_reduce<true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr);
 }
 
 // ---- z on the faces other ranks need (multi-GPU) ---------------------------------------------------
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double
 // with x = x0 + P_inv y).  y lives in three buffers: y' goes to the one that holds neither y nor the best
 // iterate so far, so the reference's copy of the best iterate (cuda.cu:535-538) is a change of index
 // (krylov_common.h y_out_buffer) and the sweep moves a flat 56 B/cell.
-template <bool MERGE>
+template <int MERGE>
 __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, double2 *y2, const double2 *__restrict__ p,
                                                  double2 *__restrict__ r, const double2 *__restrict__ s,
                                                  const double2 *__restrict__ t, const double2 *__restrict__ rhat,
@@ -486,9 +490,10 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, doubl
     sm[1] = __builtin_fma(rv.y, rv.y, sm[1]);
     m[0] = fmax(m[0], fmax(fabs(rv.x), fabs(rv.y)));
   }
-  workgroup_reduce_store<2, false, MERGE>(sm, partials, 0);
-  workgroup_reduce_store<1, true, MERGE>(m, partials, 2);
-  if (MERGE && arrive_last(ticket)) finish_reduce<true>(partials, gridDim.x, 2, 1, red, sc, 3, host_status);
+  workgroup_reduce_store<2, false, MERGE != 0>(sm, partials, 0);
+  workgroup_reduce_store<1, true, MERGE != 0>(m, partials, 2);
+  if (MERGE && arrive_last(ticket))
+    finish_reduce<true>(partials, gridDim.x, 2, 1, red, sc, MERGE == 1 ? 3 : -1, MERGE == 1 ? host_status : nullptr);
 }
 
 bool fused_supported(const cup2d_ctx *c) { return !c->mat.active && (c->nghost == 0 || c->exchange != nullptr); }
@@ -522,7 +527,7 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
 template <int MODE>
-static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, bool merge, int dbg, int *GP) {
+static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP) {
   const int nb = c->nblocks;
   const bool ghosts = c->nghost > 0 && c->exchange;
   const int n_in = ghosts ? c->n_inner : nb, n_ha = nb - n_in;
@@ -537,17 +542,22 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, bool merge, int dbg, in
     CUP2D_HIP_CHECK(hipGetLastError());
   }
   if (ghosts) CUP2D_TRY(exchange_begin(c, zg, 1, 1));
-  const auto launch = [&](int first, int count, int poff, int g) {
-    if (merge)
-      hipLaunchKernelGGL((k_fused<MODE, true>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
+  // merge 1 (one GPU, one launch): the launch finishes the reduction and updates the scalars; merge 2: the LAST
+  // launch of the sweep sums this rank's partials, finish_local() does the rest
+  const auto launch = [&](int first, int count, int poff, int g, int mg) {
+    if (mg == 1)
+      hipLaunchKernelGGL((k_fused<MODE, 1>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+    else if (mg == 2)
+      hipLaunchKernelGGL((k_fused<MODE, 2>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
                          c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
     else
-      hipLaunchKernelGGL((k_fused<MODE, false>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
+      hipLaunchKernelGGL((k_fused<MODE, 0>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
                          c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
   };
-  if (n_in > 0) launch(0, n_in, 0, G_in);
+  if (n_in > 0) launch(0, n_in, 0, G_in, n_ha > 0 && merge == 2 ? 0 : merge);
   if (ghosts) CUP2D_TRY(exchange_end(c, zg, 1, 1));
-  if (n_ha > 0) launch(n_in, n_ha, G_in, G_ha);
+  if (n_ha > 0) launch(n_in, n_ha, G_in, G_ha, merge);
   CUP2D_HIP_CHECK(hipGetLastError());
   *GP = G_in + G_ha;
   return CUP2D_OK;
@@ -574,14 +584,16 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   if (gridE > c->grid) gridE = c->grid;
   static bool lds_set = false;
   if (!lds_set) {  // > 64 KiB of LDS is an opt-in per kernel
-    const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, true>), reinterpret_cast<const void *>(&k_fused<0, false>),
-                        reinterpret_cast<const void *>(&k_fused<1, true>), reinterpret_cast<const void *>(&k_fused<1, false>)};
+    const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, 0>), reinterpret_cast<const void *>(&k_fused<0, 1>),
+                        reinterpret_cast<const void *>(&k_fused<0, 2>), reinterpret_cast<const void *>(&k_fused<1, 0>),
+                        reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     lds_set = true;
   }
-  // in-kernel finish: one launch per sweep and no all-reduce between the partials and the scalar update
-  const bool merge = c->finish_in_kernel && !c->allreduce && !(c->nghost > 0 && c->exchange);
+  // in-kernel finish.  1: one GPU -- one launch per sweep, the last workgroup also runs the scalar update.
+  // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars
+  const int merge = !c->finish_in_kernel ? 0 : (c->allreduce || (c->nghost > 0 && c->exchange)) ? 2 : 1;
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
   int GP = 0;
@@ -615,28 +627,30 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
       CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP));
     }
-    if (!merge) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
+    if (merge == 0) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
+    if (merge == 2) CUP2D_TRY(finish_local(c, 1, 0, 1));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
       CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP));
     }
-    if (!merge) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
+    if (merge == 0) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
+    if (merge == 2) CUP2D_TRY(finish_local(c, 2, 0, 2));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_E);
-      if (merge)
-        hipLaunchKernelGGL(k_sweepE_y<true>, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
+      const auto launchE = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
                            (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
                            (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
                            &c->h_status[slot]);
-      else
-        hipLaunchKernelGGL(k_sweepE_y<false>, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
-                           (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
-                           (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
-                           &c->h_status[slot]);
+      };
+      if (merge == 1) launchE(k_sweepE_y<1>);
+      else if (merge == 2) launchE(k_sweepE_y<2>);
+      else launchE(k_sweepE_y<0>);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
-    if (!merge) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
+    if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
+    if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, &c->h_status[slot]));
     CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;

@@ -60,6 +60,15 @@ constexpr int FWAVES = FWG / 64;
 #define CUP2D_POLICY 0xED9
 #endif
 constexpr unsigned POL = CUP2D_POLICY;
+// Load schedule of a job's two half-batches (8 blocks each).  0: the second half is requested when the first is being
+// staged -- it has one staging (< 1 us) of lead and the wave then waits out the memory latency once per job.  1: both
+// halves of the NEXT job are requested as soon as both halves of this one are staged, i.e. before this job's MFMA,
+// epilogue and stencil; same registers.
+// Bit MODE of CUP2D_FUSED_DEEP selects it per sweep.  Measured at 4096^2: CD 153 -> 149 us; AB has the rhat operand in
+// registers at the same time and spills under it (204 -> 467 us), so AB keeps schedule 0.
+#ifndef CUP2D_FUSED_DEEP
+#define CUP2D_FUSED_DEEP 2
+#endif
 typedef double v2d __attribute__((ext_vector_type(2)));
 template <bool NT>
 static __device__ __forceinline__ double2 ld2(const double2 *p) {
@@ -167,6 +176,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   // edges were computed by their owner rank (k_fused_edges) and unpacked into zg
   extern __shared__ double fsm[];
   if (sc->status != 0) return;
+  constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
   double *PL = fsm;
   for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
     const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   if (t_begin < t_end) {
     T = classify(t_begin, load_nb(t_begin));
     issue(Ra, T, 0, 0);
+    if (DEEP) issue(Rb, T, 0, 1);
   }
   int nb_next = load_nb(t_begin + t_stride);
   for (int t = t_begin; t < t_end; t += t_stride) {
@@ -316,10 +327,12 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     Tile N = T;  // the next tile, once classified
     for (int j = 0; j <= T.npass; j++) {
       const bool is_tile = j == T.npass;
-      issue(Rb, T, j, 1);
+      if (!DEEP) issue(Rb, T, j, 1);
       stage(Ra, is_tile, 0);
+      if (DEEP) stage(Rb, is_tile, 1);
       if (!is_tile) {
         issue(Ra, T, j + 1, 0);
+        if (DEEP) issue(Rb, T, j + 1, 1);
       } else if (MODE == 0 && !restart) {
 #pragma unroll
         for (int i = 0; i < TB; i++) {
@@ -327,13 +340,14 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           W[i] = (POL & 0x800) ? __builtin_nontemporal_load(pw) : *pw;
         }
       }
-      stage(Rb, is_tile, 1);
+      if (!DEEP) stage(Rb, is_tile, 1);
       if (is_tile && t + t_stride < t_end) {
-        // this tile's ring list is dead: classify the NEXT tile into it and put its first batch in flight
+        // this tile's ring list is dead: classify the NEXT tile into it and put its first job in flight
         // behind this tile's MFMA, edge fill and stencil
         N = classify(t + t_stride, nb_next);
         nb_next = load_nb(t + 2 * t_stride);
         issue(Ra, N, 0, 0);
+        if (DEEP) issue(Rb, N, 0, 1);
       } else {
         wave_lds_sync();
       }

@@ -263,7 +263,8 @@ class AmrSimulation:
         rebuild the device context on the new grid and re-assemble the Poisson operator.  Returns True if the grid
         changed."""
         self.vorticity()
-        linf = np.abs(self.get_field(_l.TMP)).max(axis=1)
+        linf = np.empty(self.grid.nblocks)
+        _l.check(self.L.cup2d_block_linf(self._ctx, _l.TMP, _p(linf)), "block_linf")  # one double per block crosses PCIe
         st = validate_states(self.grid.blocks, tag_states(linf, self.grid.level, rtol, ctol, level_max), level_max,
                              self.grid.bpdx, self.grid.bpdy)
         if not (st != LEAVE).any():

@@ -489,6 +489,18 @@ int cup2d_max_abs_vel(cup2d_ctx *c, double *umax) {
   *umax = c->h_red[0];
   return CUP2D_OK;
 }
+int cup2d_block_linf(cup2d_ctx *c, int field, double *linf) {
+  CUP2D_CHECK_CTX(c);
+  if (!linf || field < 0 || field >= CUP2D_NFIELDS || dim_of(field) != 1) {
+    set_error("block_linf: a scalar field and an output array expected");
+    return CUP2D_ERR_ARG;
+  }
+  double *d_out = c->d_t;  // a solver work vector: at least one double per block, free between solves
+  CUP2D_TRY(launch_block_linf(c, c->d_field[field], d_out));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(linf, d_out, (size_t)c->nblocks * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
 int cup2d_compute_dt(cup2d_ctx *c, double nu, double cfl, double *dt) {
   CUP2D_CHECK_CTX(c);
   if (!dt) return CUP2D_ERR_ARG;

@@ -234,6 +234,20 @@ static int reduce_field(cup2d_ctx *c, const double *v, size_t n, int op, double 
 }
 int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out) { return reduce_field(c, v, n, 1, d_out); }
 
+// out[b] = max |f| over the 64 cells of block b (the per-block Linf norm the reference tags blocks by, main.cpp:4671-4690)
+__global__ __launch_bounds__(WG) void k_block_linf(const double *__restrict__ f, double *__restrict__ out, int nblocks) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+    const double m = wave_max(fabs(f[(size_t)b * BC + lane]));
+    if (lane == 0) out[b] = m;
+  }
+}
+int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out) {
+  hipLaunchKernelGGL(k_block_linf, dim3(grid_for(c, c->nblocks)), dim3(WG), 0, c->stream, f, d_out, c->nblocks);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // out = (a - shift[0]*s0) (+ b - shift2...) helpers for the mean removal, main.cpp:7120-7173
 // MODE 0: p = p - mean0                    (7143-7148)   mean0 = red[0] / ncells_total
 // MODE 1: p = p + pold - mean1             (7166-7172)

@@ -32,7 +32,7 @@ SYMBOLS = [
     "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_timing", "cup2d_get_timing",
     "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather",
     "cup2d_set_solver", "cup2d_get_last_solver", "cup2d_set_amr", "cup2d_amr_poisson_coo", "cup2d_amr_tables", "cup2d_amr_validate_states", "cup2d_amr_regrid",
-    "cup2d_jacobi_sweeps", "cup2d_poisson_residual",
+    "cup2d_jacobi_sweeps", "cup2d_poisson_residual", "cup2d_block_linf",
 ]
 AMR_WALL, AMR_SAME, AMR_COARSER, AMR_FINER = range(4)
 SOLVER_SWEEPS, SOLVER_FUSED = 0, 1
@@ -100,6 +100,7 @@ def load_library():
     L.cup2d_set_amr.argtypes = [vp, d, vp, vp, vp, vp]
     L.cup2d_amr_poisson_coo.argtypes = [i, vp, vp, vp, ctypes.c_longlong, vp, vp, vp]
     L.cup2d_amr_poisson_coo.restype = ctypes.c_longlong
+    L.cup2d_block_linf.argtypes = [vp, i, vp]
     L.cup2d_jacobi_sweeps.argtypes = [vp, d, i, vp]
     L.cup2d_poisson_residual.argtypes = [vp, vp]
     L.cup2d_amr_tables.argtypes = [i, vp, i, i, vp, vp, vp]

@@ -196,6 +196,12 @@ class Simulation:
                  "poisson_solve")
         return dict(iters=it.value, restarts=rs.value, err=e.value, err_init=e0.value)
 
+    def block_linf(self, field=_l.TMP):
+        """max |field| per block, in block order (cup2d_block_linf)"""
+        out = np.empty(self.grid.nblocks)
+        _l.check(self.L.cup2d_block_linf(self._ctx, int(field), out.ctypes.data_as(ctypes.c_void_p)), "block_linf")
+        return out
+
     def jacobi_sweeps(self, nsweeps, omega=0.8):
         """nsweeps weighted-Jacobi sweeps on A pres = tmp (cup2d_jacobi_sweeps); returns max|tmp - A pres| of the
         iterate before the last sweep (left in pold)"""

@@ -125,6 +125,9 @@ int cup2d_project(cup2d_ctx *ctx, double dt);
 /* ---------------------------------------------------------------- scalars ---------------- */
 /* main.cpp:6585-6591: max |vel| over all owned blocks */
 int cup2d_max_abs_vel(cup2d_ctx *ctx, double *umax);
+/* linf[b] = max |field| over the cells of block b, b < nblocks: the norm adapt() tags blocks by (main.cpp:4671-4690,
+ * after cup2d_vorticity: field = CUP2D_TMP).  linf is a host array; scalar fields only. */
+int cup2d_block_linf(cup2d_ctx *ctx, int field, double *linf);
 /* main.cpp:6593-6595 */
 int cup2d_compute_dt(cup2d_ctx *ctx, double nu, double cfl, double *dt);
 

@@ -277,6 +277,33 @@ def test_amr_time_step_vs_reference_gpu(gpu_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_block_linf_is_the_tagging_norm_gpu(gpu_lib):
+    """cup2d_block_linf (the per-block max norm adapt() tags by, main.cpp:4671-4690) against numpy, bit for bit, on an
+    adapted grid and on a uniform one"""
+    import ctypes
+    import cup2d_amd
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    rng = np.random.default_rng(4)
+    with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
+        s.set_field(L.VEL, F["vel"])
+        s.vorticity()
+        w = s.get_field(L.TMP)
+        out = np.empty(s.grid.nblocks)
+        ptr = out.ctypes.data_as(ctypes.c_void_p)
+        L.check(s.L.cup2d_block_linf(s._ctx, L.TMP, ptr))
+        assert np.array_equal(out, np.abs(w).reshape(s.grid.nblocks, -1).max(axis=1))
+        assert s.L.cup2d_block_linf(s._ctx, L.VEL, ptr) == -1  # scalar fields only
+    with cup2d_amd.Simulation(5, 3) as s:
+        a = rng.uniform(-1, 1, (24, 40))
+        s.tmp = a
+        out = s.block_linf(L.TMP)
+        assert out.shape == (15,) and np.isclose(out.max(), np.abs(a).max(), rtol=0, atol=0)
+        assert np.array_equal(np.sort(out), np.sort(np.abs(a).reshape(3, 8, 5, 8).max(axis=(1, 3)).ravel()))
+
+
+@pytest.mark.gpu
 def test_amr_adapt_then_step_gpu(gpu_lib, oracle):
     """AmrSimulation.adapt (vorticity tags on the GPU, host regrid, new context + operator) lands on the reference's
     post-adapt grid and fields; a time step on the new grid then runs and stays finite and divergence-reducing"""

@@ -194,7 +194,10 @@ def main():
     if fused:
         ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 32.0, "sweep_E": 56.0})
         del ALGO_BYTES["sweep_B"], ALGO_BYTES["sweep_D"]
-        KERNEL_OF.update({"sweep_A": "k_fused<0, %s>" % mk, "sweep_C": "k_fused<1, %s>" % mk, "sweep_E": "k_sweepE_y<%s>" % mk})
+        # fused kernels: MERGE 1 = the last workgroup finishes the reduction and updates the scalars (one GPU),
+        # 2 = it sums the rank's partials, all-reduce + scalar kernel follow (N GPUs), 0 = finish launch
+        mf = 0 if args.finish != "kernel" else (1 if dist is None else 2)
+        KERNEL_OF.update({"sweep_A": "k_fused<0, %d>" % mf, "sweep_C": "k_fused<1, %d>" % mf, "sweep_E": "k_sweepE_y<%d>" % mf})
         sweeps = ("sweep_A", "sweep_C", "sweep_E")
     finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on

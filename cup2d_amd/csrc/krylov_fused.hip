@@ -69,6 +69,13 @@ constexpr unsigned POL = CUP2D_POLICY;
 #ifndef CUP2D_FUSED_DEEP
 #define CUP2D_FUSED_DEEP 2
 #endif
+// CUP2D_FUSED_WLATE 1: AB reads rhat in the stencil loop, four blocks ahead, instead of holding 16 values per lane across
+// the MFMA (220 VGPRs instead of 255, and schedule 1 then fits: 2 spills).  Measured: AB 194 -> 199 us (WLATE), 204 us
+// (WLATE + schedule 1) -- AB is bound by the L2-miss traffic its ring re-reads add, not by requests in
+// flight.  Off.
+#ifndef CUP2D_FUSED_WLATE
+#define CUP2D_FUSED_WLATE 0
+#endif
 typedef double v2d __attribute__((ext_vector_type(2)));
 template <bool NT>
 static __device__ __forceinline__ double2 ld2(const double2 *p) {
@@ -177,6 +184,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   extern __shared__ double fsm[];
   if (sc->status != 0) return;
   constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
+  constexpr bool WLATE = MODE == 0 && CUP2D_FUSED_WLATE != 0;
   double *PL = fsm;
   for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
     const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
@@ -305,7 +313,9 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = 0.0;
     }
-    double W[TB];  // dot-product operand of the tile's cells: rhat (AB; r on a restart) or s itself (CD)
+    // dot-product operand of the tile's cells: s itself (CD); rhat (AB; r on a restart) -- with WLATE not held in
+    // registers across the MFMA but read in the stencil loop, four blocks ahead
+    double W[WLATE ? 1 : TB];
     const auto stage = [&](const Raw &R, bool is_tile, int half) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         L.S[idx * XS + lane] = v;
         if (is_tile) {
           if (MODE == 1) W[idx] = v;
-          if (MODE == 0 && restart) W[idx] = R.c[e];
+          if (MODE == 0 && restart && !WLATE) W[idx] = R.c[e];
           if (idx < nvalid) {
             const size_t o = (size_t)(b0 + idx) * BC + lane;
             if (POL & (MODE == 0 ? 0x001 : 0x004)) __builtin_nontemporal_store(v, A.vout + o);
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       if (!is_tile) {
         issue(Ra, T, j + 1, 0);
         if (DEEP) issue(Rb, T, j + 1, 1);
-      } else if (MODE == 0 && !restart) {
+      } else if (MODE == 0 && !restart && !WLATE) {
 #pragma unroll
         for (int i = 0; i < TB; i++) {
           const double *pw = A.w + (size_t)(b0 + min(i, nvalid - 1)) * BC + lane;
@@ -381,8 +391,27 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
     wave_lds_sync();
     // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products ----
+    constexpr int LA = 4;
+    double wq[LA];
+    const double *wsrc = nullptr;
+    const auto wload = [&](int i) -> double {
+      const double *pw = wsrc + (size_t)min(i, nvalid - 1) * BC;
+      return (POL & 0x800) ? __builtin_nontemporal_load(pw) : *pw;
+    };
+    if constexpr (WLATE) {
+      wsrc = (restart ? A.in2 : A.w) + (size_t)b0 * BC + lane;  // restart: rhat = r (cuda.cu:461-476)
+#pragma unroll
+      for (int k = 0; k < LA; k++) wq[k] = wload(k);
+    }
 #pragma unroll
     for (int i = 0; i < TB; i++) {
+      double wv;
+      if constexpr (WLATE) {
+        wv = wq[i % LA];
+        if (i + LA < TB) wq[i % LA] = wload(i + LA);
+      } else {
+        wv = W[i];
+      }
       if (i < nvalid) {
         const double *zb = L.S + i * XS + lane;
         const double *ge = L.GE + i * 4 * BS;
@@ -394,7 +423,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         const double yv = l1 + l2 + l3 + l4 - 4 * l0;
         if (POL & (MODE == 0 ? 0x002 : 0x008)) __builtin_nontemporal_store(yv, A.yout + (size_t)(b0 + i) * BC + lane);
         else A.yout[(size_t)(b0 + i) * BC + lane] = yv;
-        acc[0] = __builtin_fma(yv, W[i], acc[0]);
+        acc[0] = __builtin_fma(yv, wv, acc[0]);
         if constexpr (NDOT == 2) acc[1] = __builtin_fma(yv, yv, acc[1]);
       }
     }

@@ -450,7 +450,7 @@ int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
   double *tmp = c->d_field[CUP2D_POLD];
   c->d_field[CUP2D_POLD] = c->d_field[CUP2D_PRES];
   c->d_field[CUP2D_PRES] = tmp;
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_field[CUP2D_PRES], 0, slab_doubles(c, 1) * sizeof(double), c->stream));
+  CUP2D_TRY(launch_zero(c, c->d_field[CUP2D_PRES], slab_doubles(c, 1)));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_POLD], 1, 1));
   if (use_bodies) CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_TMPV], 2, 1));

@@ -221,9 +221,11 @@ int launch_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int
 int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double *vel, double dt,
                                int fused_update, int first, int count);
 int launch_axpy_field(cup2d_ctx *c, double *y, const double *x, double a, size_t n);
+int launch_zero(cup2d_ctx *c, double *v, size_t n);
 int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out);
 int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
+int launch_precond_add(cup2d_ctx *c, const double *y, double *x, double *tmp);
 int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the installed SellMatrix
 int matrix_exchange(cup2d_ctx *c, double *vec);         // fill vec[m .. m+halo) from the neighbour ranks
 int project_impl(cup2d_ctx *c, double dt);

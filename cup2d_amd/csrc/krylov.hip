@@ -119,6 +119,8 @@ static __device__ __forceinline__ double precond_fd(double v, const FdBasis &B, 
   return z;
 }
 
+// ADD: out += P_inv in (the solver's last step x = x0 + P_inv y, cuda.cu:546-547, without a vector in between)
+template <bool ADD>
 __global__ __launch_bounds__(WG) void k_precond_fd(const double *__restrict__ in, double *__restrict__ out,
                                                    const double *__restrict__ fd, int first, int count) {
   __shared__ double buf[WPG][2][BC];
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(WG) void k_precond_fd(const double *__restrict__ in
     const int rel = g * WPG + wave;
     if (rel < count) {
       const size_t o = (size_t)(first + rel) * BC + lane;
-      out[o] = precond_fd(in[o], B, buf[wave][0], buf[wave][1], ix, iy, lane);
+      const double z = precond_fd(in[o], B, buf[wave][0], buf[wave][1], ix, iy, lane);
+      out[o] = ADD ? out[o] + z : z;
     }
   }
 }
@@ -214,13 +217,25 @@ __global__ void k_precond_mfma(const double *__restrict__ in, double *__restrict
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count) {
   if (count <= 0) return CUP2D_OK;
   if (c->precond == PRECOND_FD)
-    hipLaunchKernelGGL(k_precond_fd, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_fd, first, count);
+    hipLaunchKernelGGL(k_precond_fd<false>, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_fd, first, count);
   else if (use_mfma(c))
     hipLaunchKernelGGL(k_precond_mfma, dim3(mfma_grid(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
   else
     hipLaunchKernelGGL(k_precond, dim3(grid_for(c, count)), dim3(WG), 0, c->stream, in, out, c->d_Pinv, first, count);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
+}
+
+// x += P_inv y over the owned blocks; tmp is a work vector for the preconditioner forms that have no fused kernel
+int launch_precond_add(cup2d_ctx *c, const double *y, double *x, double *tmp) {
+  const int nb = c->nblocks;
+  if (c->precond == PRECOND_FD) {
+    hipLaunchKernelGGL(k_precond_fd<true>, dim3(grid_for(c, nb)), dim3(WG), 0, c->stream, y, x, c->d_fd, 0, nb);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    return CUP2D_OK;
+  }
+  CUP2D_TRY(launch_precond(c, y, tmp, 0, nb));
+  return launch_axpy_field(c, x, tmp, 1.0, (size_t)nb * BC);
 }
 
 // ---- sweep A --------------------------------------------------------------------------------
@@ -754,8 +769,8 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
   // p, nu start at zero (cuda.cu:436-437)
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
+  CUP2D_TRY(launch_zero(c, c->d_p, n));
+  CUP2D_TRY(launch_zero(c, c->d_nu, n));
 
   // The loop is driven by the device-side status word: every kernel of an iteration returns at once
   // when it is non-zero, so iterations may be enqueued speculatively.  The host never drains the

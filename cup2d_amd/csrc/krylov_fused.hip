@@ -646,9 +646,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
   // p, nu start at zero (cuda.cu:436-437); so does the accumulated correction
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_p, 0, n * sizeof(double), c->stream));
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_nu, 0, n * sizeof(double), c->stream));
-  CUP2D_HIP_CHECK(hipMemsetAsync(c->d_y, 0, n * sizeof(double), c->stream));
+  CUP2D_TRY(launch_zero(c, c->d_p, n));
+  CUP2D_TRY(launch_zero(c, c->d_nu, n));
+  CUP2D_TRY(launch_zero(c, c->d_y, n));
 
   static const int AHEAD = [] {
     const char *e = getenv("CUP2D_SOLVE_AHEAD");
@@ -702,8 +702,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
   const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];
-  CUP2D_TRY(launch_precond(c, ybest, c->d_s, 0, nb));
-  CUP2D_TRY(launch_axpy_field(c, x, c->d_s, 1.0, n));
+  CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (iters) *iters = c->h_sc->iter;
   if (restarts) *restarts = c->h_sc->restarts;

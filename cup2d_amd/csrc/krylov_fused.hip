@@ -565,13 +565,30 @@ static int fused_grid(const cup2d_ctx *c, int count) {
   return g < 1 ? 1 : g;
 }
 
-// One fused sweep (MODE 0: A+B, MODE 1: C+D) over all owned blocks.  With ghost blocks: z on the faces the
+// One fused sweep (MODE 0: A+B, MODE 1: C+D) over all owned blocks.  With ghost blocks, edge form (CUP2D_FUSED_GHOST=edges;
+// the default is the ghost-block form below): z on the faces the
 // other ranks need first (k_fused_edges -> zg = the otherwise unused z vector), its width-1 halo exchange
 // overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
 template <int MODE>
-static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP) {
+static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks) {
   const int nb = c->nblocks;
+  if (ghost_blocks) {
+    // N ranks, ghost-block form: the ghost copies of the sweep's input vectors are complete (solve_fused_impl
+    // exchanges whole boundary blocks behind the reductions), so a ghost block is a ring entry like any other
+    // neighbour outside the tile -- its z edge is recomputed here -- and the sweep is ONE launch over the owned blocks
+    const int g = fused_grid(c, nb);
+    const auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials,
+                         0, nb, 0, c->ntotal, c->d_z, c->d_red, c->d_ticket, dbg);
+    };
+    if (merge == 1) go(k_fused<MODE, 1>);
+    else if (merge == 2) go(k_fused<MODE, 2>);
+    else go(k_fused<MODE, 0>);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    *GP = g;
+    return CUP2D_OK;
+  }
   const bool ghosts = c->nghost > 0 && c->exchange;
   const int n_in = ghosts ? c->n_inner : nb, n_ha = nb - n_in;
   const int G_in = n_in > 0 ? fused_grid(c, n_in) : 0, G_ha = n_ha > 0 ? fused_grid(c, n_ha) : 0;
@@ -637,6 +654,15 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // in-kernel finish.  1: one GPU -- one launch per sweep, the last workgroup also runs the scalar update.
   // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars
   const int merge = !c->finish_in_kernel ? 0 : (c->allreduce || (c->nghost > 0 && c->exchange)) ? 2 : 1;
+  // N ranks: how a sweep learns z on the other side of a rank boundary.
+  //   blocks (default)  whole boundary blocks of nu', p', r are exchanged as they are produced -- nu' behind the
+  //                     reduction of AB, p' behind sweep E, r behind the reduction of E -- and the sweeps recompute the
+  //                     z edge of a ghost block like that of any other block outside the tile: one launch per sweep,
+  //                     no exchange on its critical path
+  //   edges             per sweep: z of the send-list blocks (k_fused_edges), a width-1 exchange overlapped with the
+  //                     inner tiles, then a second launch for the tiles that touch ghost blocks
+  static const bool ghost_edges = [] { const char *e = getenv("CUP2D_FUSED_GHOST"); return e && !strcmp(e, "edges"); }();
+  const bool gb = c->nghost > 0 && c->exchange && !ghost_edges;
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
   int GP = 0;
@@ -646,9 +672,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
   // p, nu start at zero (cuda.cu:436-437); so does the accumulated correction
-  CUP2D_TRY(launch_zero(c, c->d_p, n));
-  CUP2D_TRY(launch_zero(c, c->d_nu, n));
+  CUP2D_TRY(launch_zero(c, c->d_p, gb ? (size_t)c->ntotal * BC : n));
+  CUP2D_TRY(launch_zero(c, c->d_nu, gb ? (size_t)c->ntotal * BC : n));
   CUP2D_TRY(launch_zero(c, c->d_y, n));
+  if (gb) CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
 
   static const int AHEAD = [] {
     const char *e = getenv("CUP2D_SOLVE_AHEAD");
@@ -668,15 +695,18 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
-      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP));
+      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb));
     }
+    if (gb) CUP2D_TRY(exchange_begin(c, nu_out, 1, BS));  // CD needs the ghost nu': in flight behind the reduction
     if (merge == 0) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 1, 0, 1));
+    if (gb) CUP2D_TRY(exchange_end(c, nu_out, 1, BS));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
-      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP));
+      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb));
     }
+    if (gb) CUP2D_TRY(exchange_begin(c, p_out, 1, BS));  // the next AB needs the ghost p': in flight behind sweep E
     if (merge == 0) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 0, 2));
     {
@@ -692,8 +722,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       else launchE(k_sweepE_y<0>);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
+    if (gb) {
+      CUP2D_TRY(exchange_end(c, p_out, 1, BS));
+      CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // the new r: in flight behind the reduction of E
+    }
     if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, &c->h_status[slot]));
+    if (gb) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));
     CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;

@@ -91,7 +91,7 @@ class TorchComm:
     mode "host"  : tensors already live on the host (CPU tests of the plan).
     """
 
-    MAX_STRIP = 48  # 3 layers x 8 cells x 2 components
+    MAX_STRIP = 64  # 3 layers x 8 cells x 2 components (WENO halo) = 48; a whole scalar block (Krylov ghost blocks) = 64
 
     def __init__(self, topo, mode, device=None):
         import torch

@@ -254,6 +254,9 @@ int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double
 int exchange_begin(cup2d_ctx *c, const double *vec, int dim, int width);
 int exchange_end(cup2d_ctx *c, double *vec, int dim, int width);
 int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
+// whole blocks of two scalar vectors in one message (128 doubles per strip)
+int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
+int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
 static inline bool overlapped(const cup2d_ctx *c) { return c->nghost > 0 && c->exchange && c->n_inner < c->nblocks; }
 
 }  // namespace cup2d

@@ -60,6 +60,55 @@ int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double
   return CUP2D_OK;
 }
 
+// Whole blocks of TWO scalar vectors in one message: strip s = [64 cells of f0 | 64 cells of f1] of block blocks[s]
+// (cell order of a width-8 strip of that face).  The Krylov ghost-block exchange of nu' and p' (krylov_fused.hip).
+template <bool PACK>
+__global__ __launch_bounds__(WG) void k_halo_blocks2(double *__restrict__ f0, double *__restrict__ f1, double *__restrict__ buf,
+                                                     const int32_t *__restrict__ blocks, const int32_t *__restrict__ faces,
+                                                     int nstrips) {
+  const size_t total = (size_t)nstrips * 2 * BC;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const int s = (int)(i / (2 * BC)), q = (int)(i - (size_t)s * 2 * BC);
+    double *f = q < BC ? f0 : f1;
+    const size_t cell = (size_t)blocks[s] * BC + strip_cell(faces[s], BS, q & (BC - 1));
+    if (PACK) buf[i] = f[cell];
+    else f[cell] = buf[i];
+  }
+}
+int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  if (c->plan.nsend > 0) {
+    const size_t total = (size_t)c->plan.nsend * 2 * BC;
+    int grid = (int)((total + WG - 1) / WG);
+    if (grid > c->grid) grid = c->grid;
+    ProfScope prof(c, CUP2D_T_HALO);
+    hipLaunchKernelGGL(k_halo_blocks2<true>, dim3(grid), dim3(WG), 0, c->stream, const_cast<double *>(v0), const_cast<double *>(v1),
+                       c->d_send, c->plan.d_send_block, c->plan.d_send_face, c->plan.nsend);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  if (c->exchange(c->comm_user, c->d_send, c->d_recv, 2 * BC, c->stream) != 0) {
+    set_error("exchange callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  return CUP2D_OK;
+}
+int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+    set_error("wait callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  if (c->plan.nrecv == 0) return CUP2D_OK;
+  const size_t total = (size_t)c->plan.nrecv * 2 * BC;
+  int grid = (int)((total + WG - 1) / WG);
+  if (grid > c->grid) grid = c->grid;
+  ProfScope prof(c, CUP2D_T_HALO);
+  hipLaunchKernelGGL(k_halo_blocks2<false>, dim3(grid), dim3(WG), 0, c->stream, v0, v1, c->d_recv, c->plan.d_recv_block,
+                     c->plan.d_recv_face, c->plan.nrecv);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // pack + start the transfer (exchange callback)
 int exchange_begin(cup2d_ctx *c, const double *vec, int dim, int width) {
   if (c->nghost == 0 || !c->exchange) return CUP2D_OK;

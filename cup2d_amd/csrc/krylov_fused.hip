@@ -655,8 +655,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars
   const int merge = !c->finish_in_kernel ? 0 : (c->allreduce || (c->nghost > 0 && c->exchange)) ? 2 : 1;
   // N ranks: how a sweep learns z on the other side of a rank boundary.
-  //   blocks (default)  whole boundary blocks of nu', p', r are exchanged as they are produced -- nu' behind the
-  //                     reduction of AB, p' behind sweep E, r behind the reduction of E -- and the sweeps recompute the
+  //   blocks (default)  whole boundary blocks of nu', p', r are exchanged as they are produced -- nu' and p' in one
+  //                     message behind the reduction of AB, r behind the reduction of E -- and the sweeps recompute the
   //                     z edge of a ghost block like that of any other block outside the tile: one launch per sweep,
   //                     no exchange on its critical path
   //   edges             per sweep: z of the send-list blocks (k_fused_edges), a width-1 exchange overlapped with the
@@ -697,16 +697,16 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
       CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb));
     }
-    if (gb) CUP2D_TRY(exchange_begin(c, nu_out, 1, BS));  // CD needs the ghost nu': in flight behind the reduction
+    // CD needs the ghost nu', the next AB the ghost p': one message, in flight behind the reduction
+    if (gb) CUP2D_TRY(exchange_begin_blocks2(c, nu_out, p_out));
     if (merge == 0) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 1, 0, 1));
-    if (gb) CUP2D_TRY(exchange_end(c, nu_out, 1, BS));
+    if (gb) CUP2D_TRY(exchange_end_blocks2(c, nu_out, p_out));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
       CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb));
     }
-    if (gb) CUP2D_TRY(exchange_begin(c, p_out, 1, BS));  // the next AB needs the ghost p': in flight behind sweep E
     if (merge == 0) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 0, 2));
     {
@@ -722,10 +722,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       else launchE(k_sweepE_y<0>);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
-    if (gb) {
-      CUP2D_TRY(exchange_end(c, p_out, 1, BS));
-      CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // the new r: in flight behind the reduction of E
-    }
+    if (gb) CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // the new r: in flight behind the reduction of E
     if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, &c->h_status[slot]));
     if (gb) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));

@@ -91,7 +91,7 @@ class TorchComm:
     mode "host"  : tensors already live on the host (CPU tests of the plan).
     """
 
-    MAX_STRIP = 64  # 3 layers x 8 cells x 2 components (WENO halo) = 48; a whole scalar block (Krylov ghost blocks) = 64
+    MAX_STRIP = 128  # WENO halo: 3 layers x 8 cells x 2 components = 48; Krylov ghost blocks: two whole scalar blocks = 128
 
     def __init__(self, topo, mode, device=None):
         import torch

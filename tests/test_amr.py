@@ -129,6 +129,49 @@ def test_amr_host_regrid_library_vs_python_statement():
     assert all(v > 10 for v in seen.values()), seen
 
 
+def test_amr_host_routines_reject_bad_input():
+    """the regrid-time host routines (no GPU): argument checks and the error text, through the C ABI"""
+    import ctypes
+    from cup2d_amd import lib as L
+    lib = L.load_library()
+    vp = ctypes.c_void_p
+
+    def ptr(a):
+        return a.ctypes.data_as(vp)
+    blocks = np.array([(1, i, j) for j in range(2) for i in range(2)], dtype=np.int32)
+    kind, nbr2, half = np.zeros((4, 4), np.int32), np.zeros((4, 4, 2), np.int32), np.zeros((4, 4), np.int32)
+    assert lib.cup2d_amr_tables(4, ptr(blocks), 1, 1, ptr(kind), ptr(nbr2), ptr(half)) == 0
+    assert (kind[0] == [L.AMR_WALL, L.AMR_SAME, L.AMR_WALL, L.AMR_SAME]).all() and nbr2[0, 1, 0] == 1 and nbr2[0, 3, 0] == 2
+    bad = blocks.copy()
+    bad[3] = (1, 2, 0)  # outside the 2 x 2 level-1 grid
+    assert lib.cup2d_amr_tables(4, ptr(bad), 1, 1, ptr(kind), ptr(nbr2), ptr(half)) == -1
+    assert b"outside" in lib.cup2d_last_error()
+    hole = np.array([(1, 0, 0), (1, 1, 0), (1, 0, 1)], dtype=np.int32)  # (1, 1, 1) missing: not a tiling
+    assert lib.cup2d_amr_tables(3, ptr(hole), 1, 1, ptr(kind), ptr(nbr2), ptr(half)) == -1
+    assert b"balanced" in lib.cup2d_last_error()
+    assert lib.cup2d_amr_tables(0, ptr(blocks), 1, 1, ptr(kind), ptr(nbr2), ptr(half)) == -1
+    st = np.array([2, 0, 0, 0], dtype=np.int32)  # one sibling alone cannot compress
+    assert lib.cup2d_amr_validate_states(4, ptr(blocks), 1, 1, 3, ptr(st)) == 0 and (st == 0).all()
+    st = np.array([2, 2, 2, 0], dtype=np.int32)
+    f = np.zeros((4, 64))
+    srcs = (vp * 1)(f.ctypes.data)
+    dims, vec = np.array([1], np.int32), np.array([0], np.int32)
+    assert lib.cup2d_amr_regrid(4, ptr(blocks), 1, 1, 3, ptr(st), 1, srcs, ptr(dims), ptr(vec), 0, None, None) == -1
+    assert b"siblings" in lib.cup2d_last_error()
+    st[:] = 2
+    assert lib.cup2d_amr_regrid(4, ptr(blocks), 1, 1, 3, ptr(st), 1, srcs, ptr(dims), ptr(vec), 0, None, None) == 1  # one parent
+    st[:] = 1
+    assert lib.cup2d_amr_regrid(4, ptr(blocks), 1, 1, 3, ptr(st), 1, srcs, ptr(dims), ptr(vec), 0, None, None) == 16
+    nb2 = np.zeros((16, 3), np.int32)
+    out = np.zeros((16, 64))
+    dsts = (vp * 1)(out.ctypes.data)
+    assert lib.cup2d_amr_regrid(4, ptr(blocks), 1, 1, 3, ptr(st), 1, srcs, ptr(dims), ptr(vec), 8, ptr(nb2), dsts) == -1  # capacity
+    f[:] = 2.5  # a constant field prolongs to the same constant
+    assert lib.cup2d_amr_regrid(4, ptr(blocks), 1, 1, 3, ptr(st), 1, srcs, ptr(dims), ptr(vec), 16, ptr(nb2), dsts) == 16
+    assert (out == 2.5).all() and (nb2[:, 0] == 2).all() and len({tuple(b) for b in nb2.tolist()}) == 16
+    assert lib.cup2d_amr_poisson_coo(0, ptr(kind), ptr(nbr2), ptr(half), 0, None, None, None) == -1
+
+
 def test_amr_topology_tables(oracle):
     """cup2d_amd.amr.AmrBlockGrid (product) against the oracle's neighbour logic; level jumps are 2:1"""
     from cup2d_amd import lib as L

@@ -50,12 +50,14 @@ constexpr int FWAVES = FWG / 64;
 //   0xED9 | 0x4000 (all AB loads)          224 / 160 / 156   27.9    ring re-reads miss L2
 //   0xED9 & ~0x208 (keep t as well as s)   202 / 152 / 169   27.1    two kept vectors overflow the cache
 //   0xED9 | 0x020 (r store)                198 / 154 / 158   26.3
+//   0xED9 | 0x20000 (ring loads)           +2 % / -2 % / =   (same box as a 186 / 144 / 144 run of 0xED9: noise)
 // Sweep E (pure streaming, 56 B/cell) gains 16 %: s comes out of the cache; AB and CD do not react -- they are bound
 // by their own load -> LDS -> MFMA pipeline, not by what the memory side delivers.
 //   0x001 AB store p'   0x002 AB store nu'   0x004 CD store s   0x008 CD store t
 //   0x010 E store y'    0x020 E store r      0x040 E load y     0x080 E load p    0x100 E load s   0x200 E load t
 //   0x400 E load rhat   0x800 AB load rhat   0x1000 AB tile load p   0x2000 AB tile load nu
 //   0x4000 AB every load of p, nu, r (tile and ring)   0x8000 CD loads of r   0x10000 CD loads of nu'
+//   0x20000 ring loads of AB and CD
 #ifndef CUP2D_POLICY
 #define CUP2D_POLICY 0xED9
 #endif
@@ -279,7 +281,11 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const size_t o = (size_t)uniform(blk[e]) * BC + lane;
-      if (MODE == 0 && (POL & 0x4000)) {
+      if (!tile_job && (POL & 0x20000)) {  // ring loads only
+        R.a[e] = __builtin_nontemporal_load(A.in0 + o);
+        R.b[e] = __builtin_nontemporal_load(A.in1 + o);
+        if (MODE == 0) R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+      } else if (MODE == 0 && (POL & 0x4000)) {
         R.a[e] = __builtin_nontemporal_load(A.in0 + o);
         R.b[e] = __builtin_nontemporal_load(A.in1 + o);
         R.c[e] = __builtin_nontemporal_load(A.in2 + o);

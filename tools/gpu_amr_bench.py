@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Timing of the block-AMR path on a three-level grid (BASELINE.json configs[4] shape: finest level = LFINE,
+a refined band around a circle) next to the uniform path at the same cell count: development aid."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cup2d_amd  # noqa: E402
+from cup2d_amd import amr as A, lib as L  # noqa: E402
+
+LF = int(os.environ.get("LFINE", "8"))  # finest level: 2^LF blocks per side (8 -> 2048^2 equivalent, 9 -> 4096^2)
+l0 = LF - 2
+blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
+t0 = time.perf_counter()
+for lvl in range(l0, LF):  # refine the blocks near a circle of radius 0.25 twice
+    n = 1 << lvl
+    cx = (blocks[:, 1] + 0.5) / (1 << blocks[:, 0]) - 0.5
+    cy = (blocks[:, 2] + 0.5) / (1 << blocks[:, 0]) - 0.5
+    d = np.abs(np.hypot(cx, cy) - 0.25)
+    st = np.where((blocks[:, 0] == lvl) & (d < 0.06), A.REFINE, A.LEAVE).astype(np.int32)
+    st = A.validate_states(blocks, st, LF + 1)
+    blocks, _ = A.regrid(blocks, st, {}, LF + 1)
+g = A.AmrBlockGrid(blocks)
+t_grid = time.perf_counter() - t0
+nb = g.nblocks
+print("grid: %d blocks, levels %s, host regrid+tables %.2f s" % (nb, np.bincount(blocks[:, 0]).tolist(), t_grid), flush=True)
+with A.AmrSimulation(g) as s:
+    xc, yc = g.cell_centres()
+    vel = np.stack([np.sin(2 * np.pi * xc) * np.cos(2 * np.pi * yc), -np.cos(2 * np.pi * xc) * np.sin(2 * np.pi * yc)], -1)
+    s.set_field(L.VEL, vel)
+    s.set_math(False)
+    t0 = time.perf_counter()
+    s.install_poisson_matrix()
+    print("operator assembly + sliced-ELL upload %.2f s" % (time.perf_counter() - t0), flush=True)
+    for _ in range(2):
+        r = s.step(max_iter=50)
+    L.check(s.L.cup2d_set_timing(s._ctx, 1))
+    t0 = time.perf_counter()
+    nst = 3
+    for _ in range(nst):
+        r = s.step(max_iter=50)
+    L.check(s.L.cup2d_synchronize(s._ctx)) if hasattr(s.L, "cup2d_synchronize") else None
+    el = (time.perf_counter() - t0) / nst
+    print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e" % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"]), flush=True)
+    import ctypes
+    for i, name in enumerate(L.TIMER_NAMES):
+        ms, calls = ctypes.c_double(), ctypes.c_int()
+        s.L.cup2d_get_timing(s._ctx, i, ctypes.byref(ms), ctypes.byref(calls))
+        if calls.value:
+            print("   %-14s %8.1f us avg x %d" % (name, 1e3 * ms.value / calls.value, calls.value))

@@ -71,6 +71,7 @@ struct HaloPlan {
 // columns and values with unit stride; every slice is as wide as its longest row (5 on a same-level
 // block, more where coarse-fine interpolation rows exist), padded with (col = own row, val = 0).
 // Columns >= 64*nblocks address halo entries appended to the Krylov vector (cuda.cu:344-402).
+constexpr int32_t SELL_STORED = -2;
 struct SellMatrix {
   bool active = false;
   int halo = 0;
@@ -78,6 +79,10 @@ struct SellMatrix {
   long long *d_ptr = nullptr;  // [nblocks + 1]
   int32_t *d_col = nullptr;
   double *d_val = nullptr;
+  // hybrid form: reg[4 s .. 4 s + 3] = the W, E, S, N neighbour blocks (CUP2D_WALL at a wall) of a slice whose 64 rows
+  // are exactly the same-level 5-point rows (no stored entries: its width is 0); reg[4 s] = SELL_STORED otherwise
+  int32_t *d_reg = nullptr;
+  int nregular = 0;
   int ngather = 0;             // send_buff_pack (cuda.cu:338-343): d_send[i] = vec[gather[i]]
   int32_t *d_gather = nullptr;
 };

@@ -571,9 +571,11 @@ template <int MODE>
 __global__ __launch_bounds__(WG) void k_sell(const double *__restrict__ x, double *__restrict__ y,
                                              const double *__restrict__ w, double *__restrict__ y2,
                                              const long long *__restrict__ sptr, const int32_t *__restrict__ col,
-                                             const double *__restrict__ val, const KrylovScalars *__restrict__ sc,
+                                             const double *__restrict__ val, const int32_t *__restrict__ reg,
+                                             const KrylovScalars *__restrict__ sc,
                                              double *__restrict__ partials, int count, int poff) {
   if ((MODE == 1 || MODE == 2) && sc->status != 0) return;
+  const int4 *reg4 = (const int4 *)reg;
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double acc[2] = {0.0, 0.0}, mx[1] = {0.0};
   const GroupRange gr = group_range(count);
@@ -586,6 +588,19 @@ __global__ __launch_bounds__(WG) void k_sell(const double *__restrict__ x, doubl
       const double *vp = val + base + lane;
       double a = 0.0;
       int k = 0;
+      const int4 rg = reg4[s];  // wave-uniform
+      if (rg.x != SELL_STORED) {
+        // a slice of plain same-level rows (ctx.h SellMatrix::d_reg): the 5-point sum straight from x, ghost = own
+        // cell at a wall (the row has no entry there and one neighbour less on the diagonal: the same number)
+        const int ix = lane & 7, iy = lane >> 3;
+        const double *own = x + (size_t)s * BC;
+        const double l0 = own[lane];
+        const double l1 = ix > 0 ? own[lane - 1] : rg.x >= 0 ? x[(size_t)rg.x * BC + iy * BS + (BS - 1)] : l0;
+        const double l2 = ix < BS - 1 ? own[lane + 1] : rg.y >= 0 ? x[(size_t)rg.y * BC + iy * BS] : l0;
+        const double l3 = iy > 0 ? own[lane - BS] : rg.z >= 0 ? x[(size_t)rg.z * BC + (BS - 1) * BS + ix] : l0;
+        const double l4 = iy < BS - 1 ? own[lane + BS] : rg.w >= 0 ? x[(size_t)rg.w * BC + ix] : l0;
+        a = l1 + l2 + l3 + l4 - 4 * l0;
+      }
       for (; k + 4 <= width; k += 4) {  // four independent gathers in flight
         const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
         const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
@@ -659,7 +674,7 @@ int launch_matvec(cup2d_ctx *c, double *x, double *y) {
   const SellMatrix &M = c->mat;
   CUP2D_TRY(matrix_exchange(c, x));
   hipLaunchKernelGGL(k_sell<0>, dim3(grid_for(c, c->nblocks)), dim3(WG), 0, c->stream, x, y, nullptr, nullptr, M.d_ptr,
-                     M.d_col, M.d_val, nullptr, nullptr, c->nblocks, 0);
+                     M.d_col, M.d_val, M.d_reg, nullptr, nullptr, c->nblocks, 0);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
@@ -761,7 +776,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     CUP2D_TRY(stencil_sweep(x, [&](int first, int count, int poff, int g) {
       if (matrix)
         hipLaunchKernelGGL(k_sell<3>, dim3(g), dim3(WG), 0, c->stream, x, c->d_r, b, c->d_rhat, M.d_ptr, M.d_col, M.d_val,
-                           c->d_sc, c->d_partials, count, poff);
+                           M.d_reg, c->d_sc, c->d_partials, count, poff);
       else
         hipLaunchKernelGGL(k_init_residual, dim3(g), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
                            c->d_partials, first, count, poff);
@@ -808,7 +823,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
       CUP2D_TRY(stencil_sweep(c->d_z, [&](int first, int count, int poff, int g) {
         if (matrix)
           hipLaunchKernelGGL(k_sell<1>, dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, nullptr, M.d_ptr,
-                             M.d_col, M.d_val, c->d_sc, c->d_partials, count, poff);
+                             M.d_col, M.d_val, M.d_reg, c->d_sc, c->d_partials, count, poff);
         else if (merge)
           hipLaunchKernelGGL((k_sweepBD<1, true>), dim3(g), dim3(WG), 0, c->stream, c->d_z, c->d_nu, c->d_rhat, c->d_nbr,
                              c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);
@@ -833,7 +848,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
       CUP2D_TRY(stencil_sweep(c->d_z2, [&](int first, int count, int poff, int g) {
         if (matrix)
           hipLaunchKernelGGL(k_sell<2>, dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, nullptr, M.d_ptr, M.d_col,
-                             M.d_val, c->d_sc, c->d_partials, count, poff);
+                             M.d_val, M.d_reg, c->d_sc, c->d_partials, count, poff);
         else if (merge)
           hipLaunchKernelGGL((k_sweepBD<2, true>), dim3(g), dim3(WG), 0, c->stream, c->d_z2, c->d_t, c->d_r, c->d_nbr,
                              c->d_sc, c->d_partials, first, count, poff, c->d_red, c->d_ticket);

@@ -291,7 +291,7 @@ def _test_interp(C, dx, dy):
 def lab3_cross(grid, vel, b):
     """The 14x14x2 tile of block b with the CROSS ghosts (3 layers per side) as BlockLab::load/post_load leaves them
     (corners are not read by KernelAdvectDiffuse and stay NaN here).  Closed forms derived from the literal
-    transcription cup2d_amd/amr_lab.py, pinned against the reference's own tiles (tests/test_amr.py):
+    transcription oracle/amr_lab.py, pinned against the reference's own tiles (tests/test_amr.py):
       wall    edge cell, wall-normal component negated                                    (main.cpp:3131-3204)
       same    the neighbour's cells
       finer   2x2 means; on W/E faces the first of every four rows pairs fine rows 0 and 2 (main.cpp:2528-2531)

@@ -4,9 +4,10 @@ it reproduces the reference's tiles bit for bit, quirks included (the unrolled f
 TestInterp fed component 0, 2753-2763).  Pinned against tiles dumped by the reference itself (tests/test_amr.py: halo-3
 tensorial vector tiles of KernelAdvectDiffuse, halo-1 tensorial scalar and vector tiles of adapt()).
 
-Two users: REGRIDDING (cup2d_amd/amr.py adapt: the tensorial halo-1 tile a refined block is prolonged from,
-main.cpp:4906-5032 -- regrid-time host work in the reference too), and the tests, where it is the full-tile cross-check
-of the closed forms the HIP kernels implement (csrc/amr.hip).  Single rank, bpdx = bpdy = 1."""
+Test infrastructure (never imported by the product).  Two users: the Python statement of regridding (oracle/amr_regrid.py:
+the tensorial halo-1 tile a refined block is prolonged from, main.cpp:4906-5032), which the library's host routines
+must reproduce bit for bit, and the full-tile cross-check of the closed forms the HIP kernels implement (csrc/amr.hip).
+Single rank, bpdx = bpdy = 1."""
 import numpy as np
 
 BS = 8

@@ -34,10 +34,10 @@ def test_amr_oracle_bit_exact_vs_reference(oracle):
 
 def test_amr_halo3_tile_and_advect_diffuse_vs_reference(oracle):
     """KernelAdvectDiffuse's ghosted tile (Stencil{-3,-3,4,4,true}): the literal transcription of BlockLab
-    (cup2d_amd/amr_lab.py) reproduces the reference's 14x14x2 tiles completely, the closed forms (oracle/amr.py lab3_cross,
+    (oracle/amr_lab.py) reproduces the reference's 14x14x2 tiles completely, the closed forms (oracle/amr.py lab3_cross,
     what csrc/amr.hip implements) on the cross the functor reads; then the functor with its dim-2 flux correction."""
     from oracle import amr as A
-    from cup2d_amd import amr_lab as AL
+    from oracle import amr_lab as AL
     cross = np.zeros((14, 14), bool)
     cross[3:11, :] = True
     cross[:, 3:11] = True
@@ -90,7 +90,8 @@ def test_amr_host_regrid_library_vs_python_statement():
     corners) against the Python statement on the general-stencil BlockLab (amr_lab.py, itself pinned to tiles dumped
     by the reference): random tags on random balanced grids, bit for bit, every kind of side and corner visited"""
     from cup2d_amd import amr as A
-    from cup2d_amd.amr_lab import Tree
+    from oracle.amr_lab import Tree
+    from oracle import amr_regrid as R
     seen = dict(coarse_corner=0, fine_corner=0, coarse_face=0, fine_face=0, compress=0)
     for seed in range(6):
         rng = np.random.default_rng(100 + seed)
@@ -104,7 +105,7 @@ def test_amr_host_regrid_library_vs_python_statement():
                 break
             st0 = rng.choice([0, 1, 2], size=nb, p=[1 - pr - pc, pr, pc]).astype(np.int32)
             st = A.validate_states(blocks, st0, level_max)
-            assert np.array_equal(st, A.validate_states_py(blocks, st0, level_max)), (seed, it)
+            assert np.array_equal(st, R.validate_states_py(blocks, st0, level_max)), (seed, it)
             tree = Tree(blocks)
             for k, (l, i, j) in enumerate(blocks):
                 if st[k] != A.REFINE:
@@ -119,7 +120,7 @@ def test_amr_host_regrid_library_vs_python_statement():
             seen["compress"] += int((st == A.COMPRESS).sum())
             fields = {"vel": (vel, 2, True), "pres": (pres, 1, False)}
             b_c, d_c = A.regrid(blocks, st, fields, level_max)
-            b_py, d_py = A.regrid_py(blocks, st, fields, level_max)
+            b_py, d_py = R.regrid_py(blocks, st, fields, level_max)
             assert np.array_equal(b_c, b_py), (seed, it)
             for k in d_py:
                 assert np.array_equal(d_c[k], d_py[k]) and not np.isnan(d_c[k]).any(), (seed, it, k)
@@ -205,7 +206,8 @@ def test_amr_poisson_matrix_vs_reference(oracle):
     for name, F in _grid_cases(oracle):
         g = AmrBlockGrid(F["blocks"])
         r, c, v = g.poisson_coo()  # the library's host routine (C++)
-        rp, cp, vp = g.poisson_coo_py()  # the same algorithm in Python: bit for bit
+        from oracle import amr_regrid as R
+        rp, cp, vp = R.poisson_coo_py(g)  # the same algorithm in Python: bit for bit
         assert np.array_equal(r, rp) and np.array_equal(c, cp) and np.array_equal(v, vp), name
         n = 64 * g.nblocks
         A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WG) void k_amr_fillcases(double *__restrict__ y, Am
 
 // ---- halo 3: the tile of KernelAdvectDiffuse (Stencil{-3,-3,4,4,true}, main.cpp:5442) -----------------------------
 // Closed forms of the CROSS ghosts of BlockLab::load/post_load for this stencil (use_averages = true), derived from
-// and pinned against a literal transcription of the reference (cup2d_amd/amr_lab.py) and the reference's own tiles:
+// and pinned against a literal transcription of the reference (kept with the tests) and the reference's own tiles:
 //   wall / same / finer as for halo 1, three layers; on W/E faces the first of every four rows of a finer neighbour
 //   pairs fine rows 0 and 2 (main.cpp:2528-2531)
 //   coarser, layers 1-2: the halo-1 tangential quadratic, then LI (layer 1) / LE (layer 2) with the two interior cells

@@ -2,8 +2,8 @@
 //
 // Reference: the serial row-assembly loop main.cpp:7034-7112 with Solver::makeFlux / interpolate / D1 / D2
 // (main.cpp:5915-5997) and SpRowInfo::mapColVal (cuda.h:1-24).  In the reference this is host C++ too; here it works
-// on the dense topology tables of cup2d_set_amr instead of the tree / Info hash maps.  (cup2d_amd/amr.py keeps the
-// same algorithm in Python as its readable statement; tests require the two to agree bit for bit.)
+// on the dense topology tables of cup2d_set_amr instead of the tree / Info hash maps.  (The tests keep a Python
+// statement of the same algorithm and require the two to agree bit for bit.)
 #include <algorithm>
 #include <vector>
 

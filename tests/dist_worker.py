@@ -29,7 +29,7 @@ def run_cpu(rank, world, px, py, nbx, nby):
     topo = PatchTopology(nbx, nby, px, py, cx, cy)
     g = topo.grid
     comm = TorchComm(topo, "host")
-    for dim, width in ((2, 3), (1, 1)):
+    for dim, width in ((2, 3), (1, 1), (1, 8)):  # WENO halo, Krylov strips, whole ghost blocks (Krylov vectors)
         G = global_field(px * nbx * 8, py * nby * 8, dim, seed=100 + dim).reshape(py * nby * 8, px * nbx * 8, dim)
         patch = G[cy * nby * 8:(cy + 1) * nby * 8, cx * nbx * 8:(cx + 1) * nbx * 8]
         slab = np.zeros((g.nblocks + g.nghost, 64, dim))
@@ -57,6 +57,32 @@ def run_cpu(rank, world, px, py, nbx, nby):
             assert np.array_equal(slab[gb, cells], blockG[cells]), (rank, side, pos)
             checked += len(cells)
         assert checked == topo.nrecv * 8 * width
+    # two whole-block vectors in one message (halo.hip k_halo_blocks2): strip = [64 cells of f0 | 64 cells of f1]
+    G0 = global_field(px * nbx * 8, py * nby * 8, 1, seed=7)
+    G1 = global_field(px * nbx * 8, py * nby * 8, 1, seed=8)
+    slabs = []
+    for G in (G0, G1):
+        sl = np.zeros((g.nblocks + g.nghost, 64))
+        sl[:g.nblocks] = g.to_blocks(G[cy * nby * 8:(cy + 1) * nby * 8, cx * nbx * 8:(cx + 1) * nbx * 8]).reshape(g.nblocks, 64)
+        slabs.append(sl)
+    send = np.zeros(topo.nsend * 128)
+    for k in range(topo.nsend):
+        cells = strip_cells(int(topo.send_face[k]), 8)
+        send[k * 128:k * 128 + 64] = slabs[0][topo.send_block[k], cells]
+        send[k * 128 + 64:(k + 1) * 128] = slabs[1][topo.send_block[k], cells]
+    comm.send[:send.size] = torch.from_numpy(send)
+    comm.exchange(128)
+    comm.wait()
+    recv = comm.recv[:topo.nrecv * 128].numpy()
+    for k in range(topo.nrecv):
+        cells = strip_cells(int(topo.recv_face[k]), 8)
+        slabs[0][topo.recv_block[k], cells] = recv[k * 128:k * 128 + 64]
+        slabs[1][topo.recv_block[k], cells] = recv[k * 128 + 64:(k + 1) * 128]
+    for gi, (side, pos) in enumerate(g.ghost_coords):
+        bx = cx * nbx + (-1 if side == 0 else nbx if side == 1 else pos)
+        by = cy * nby + (pos if side < 2 else (-1 if side == 2 else nby))
+        for sl, G in zip(slabs, (G0, G1)):
+            assert np.array_equal(sl[g.nblocks + gi], G[by * 8:(by + 1) * 8, bx * 8:(bx + 1) * 8].reshape(64)), (rank, side, pos)
     # reductions as the library drives them: sum of 2 at offset 0, max of 1 at offset 2
     comm.red[:] = torch.tensor([rank + 1.0, 2.0 * rank, -5.0 + rank, 0, 0, 0, 0, 0], dtype=torch.float64)
     comm.allreduce(0, 2, 0)

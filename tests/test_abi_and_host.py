@@ -80,3 +80,19 @@ def test_ghost_sides_order_halo_blocks_last():
     touch = (g.coords[:, 0] == 3) | (g.coords[:, 1] == 3)
     assert not touch[:g.n_inner].any() and touch[g.n_inner:].all()
     assert (g.nbr[g.n_inner:] >= g.nblocks).any(axis=1).all()
+
+
+def test_cpp_host_driver_fails_loudly_without_gpu():
+    """cup2d_amd/cup2d_run (csrc/cup2d_run.cpp, the C++ host driver over the C ABI) has no CPU path: without a GPU it
+    stops at cup2d_create with the library's error text; bad options are rejected before that"""
+    import subprocess
+    exe = os.path.join(ROOT, "cup2d_amd", "cup2d_run")
+    assert os.path.exists(exe), "build with __graft_entry__.build()"
+    r = subprocess.run([exe, "-n", "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 2 and b"multiples of 8" in r.stderr
+    r = subprocess.run([exe, "-bogus", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 2 and b"unknown option" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "-n", "16", "-steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"cup2d_create" in r.stderr and b"step 1" not in r.stdout

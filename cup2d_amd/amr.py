@@ -77,12 +77,15 @@ class AmrSimulation:
     def __init__(self, grid, nu=1e-3, cfl=0.5, device=0):
         self.L = _l.load_library()
         self.grid, self.nu, self.cfl = grid, float(nu), float(cfl)
+        self._strict = getattr(self, "_strict", None)  # arithmetic policy: survives the context rebuild of adapt()
         self._ctx = ctypes.c_void_p()
         vp = ctypes.c_void_p
         _l.check(self.L.cup2d_create(ctypes.byref(self._ctx), grid.nblocks, 0, grid.nblocks,
                                      np.ascontiguousarray(grid.nbr).ctypes.data_as(vp), grid.h0, int(device)), "cup2d_create")
         self._tables = [np.ascontiguousarray(a, dtype=np.int32) for a in (grid.level, grid.kind, grid.nbr2, grid.half)]
         _l.check(self.L.cup2d_set_amr(self._ctx, grid.h0, *[a.ctypes.data_as(vp) for a in self._tables]), "cup2d_set_amr")
+        if self._strict is not None:
+            self.set_math(self._strict)
 
     def close(self):
         if self._ctx:
@@ -106,6 +109,7 @@ class AmrSimulation:
         return a.reshape(self.grid.nblocks, 64, 2) if dim == 2 else a
 
     def set_math(self, strict):
+        self._strict = bool(strict)
         _l.check(self.L.cup2d_set_math(self._ctx, _l.MATH_STRICT if strict else _l.MATH_FAST), "set_math")
 
     def advect_diffuse_rhs(self, dt):

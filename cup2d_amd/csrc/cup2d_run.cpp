@@ -5,12 +5,20 @@
 //
 //   cup2d_run -n 256 [-ny 256] [-steps 10] [-nu 1e-3] [-cfl 0.5] [-poissonTol 1e-3] [-poissonTolRel 1e-2]
 //             [-maxPoissonRestarts 0] [-maxiter 1000] [-init vel.f64] [-dump prefix] [-every k] [-device 0]
+//             [-math fast|strict]
+//   cup2d_run -levelMax 5 -levelStart 2 [-Rtol 2] [-Ctol 0.5] ... [-state prefix]      block-AMR (below)
 //
 // Grid: nx x ny cells in 8 x 8 blocks, ordered along the Hilbert curve like the reference's (main.cpp:347-360,
 // 1550-1562), walls on all four sides, h = extent / max(nx, ny) (main.cpp:6338, extent 1).  Initial velocity: the file
 // given with -init (float64, row-major [ny][nx][2]) or the Taylor-Green vortex.  The first ten steps solve with zero
 // tolerances and 100 restarts, later ones with the given tolerances (main.cpp:7028-7030).  -dump writes the
 // reference's dump() files (main.cpp:3367-3466: <prefix>.<step>.xyz.raw / .attr.raw / .xdmf2) every k-th step.
+// With -levelMax the grid is the reference's block-AMR grid (one level-0 block as base, uniform at -levelStart to begin
+// with): every step computes dt, regrids (adapt(), main.cpp:4657-5440: vorticity and its per-block max on the GPU,
+// states validated, fields prolonged / restricted and the Poisson rows re-assembled by the library's host routines,
+// the device context rebuilt on the new leaves) and advances (main.cpp:6579-7187).  -init is then a block-ordered slab
+// [nblocks][64][2] of the start grid (blocks row-major), default two Gaussian vortices; -state writes
+// <prefix>.blocks.i32, .vel.f64, .pres.f64 at the end.
 // Only host code here: no kernels and no CPU fallback -- without the library's GPU path it fails.
 #include <algorithm>
 #include <cmath>
@@ -132,12 +140,155 @@ void dump(const std::string &path, double time, const Grid &g, const double *vel
   std::fclose(f);
 }
 
+// ---- block-AMR run -----------------------------------------------------------------------------------------------
+struct AmrRun {
+  std::vector<int32_t> blocks;  // [nb][3] level, i, j
+  cup2d_ctx *ctx = nullptr;
+  int device = 0, math = CUP2D_MATH_FAST;
+  int nb() const { return (int)blocks.size() / 3; }
+  // context + topology tables + Poisson operator of the current leaves (what the reference redoes after every regrid,
+  // main.cpp:7034-7115)
+  void build() {
+    const int n = nb();
+    std::vector<int32_t> kind(4 * n), nbr2(8 * n), half(4 * n), nbr(4 * n), level(n);
+    RUN(cup2d_amr_tables(n, blocks.data(), 1, 1, kind.data(), nbr2.data(), half.data()));
+    for (int q = 0; q < 4 * n; q++) nbr[q] = kind[q] == CUP2D_AMR_SAME ? nbr2[2 * q] : CUP2D_WALL;
+    for (int b = 0; b < n; b++) level[b] = blocks[3 * b];
+    const double h0 = 1.0 / BS;  // one level-0 block of 8 cells spans the unit square (main.cpp:6338)
+    if (ctx) cup2d_destroy(ctx);
+    ctx = nullptr;
+    RUN(cup2d_create(&ctx, n, 0, n, nbr.data(), h0, device));
+    RUN(cup2d_set_amr(ctx, h0, level.data(), kind.data(), nbr2.data(), half.data()));
+    RUN(cup2d_set_math(ctx, math));
+    const long long nnz = cup2d_amr_poisson_coo(n, kind.data(), nbr2.data(), half.data(), 0, nullptr, nullptr, nullptr);
+    if (nnz < 0) { std::fprintf(stderr, "cup2d_run: amr_poisson_coo: %s\n", cup2d_last_error()); std::exit(1); }
+    std::vector<int32_t> row((size_t)nnz), col((size_t)nnz);
+    std::vector<double> val((size_t)nnz);
+    if (cup2d_amr_poisson_coo(n, kind.data(), nbr2.data(), half.data(), nnz, row.data(), col.data(), val.data()) != nnz) {
+      std::fprintf(stderr, "cup2d_run: amr_poisson_coo: %s\n", cup2d_last_error());
+      std::exit(1);
+    }
+    RUN(cup2d_set_matrix_coo(ctx, 0, nnz, row.data(), col.data(), val.data()));
+  }
+  // adapt(): returns true if the grid changed
+  bool adapt(double rtol, double ctol, int level_max) {
+    const int n = nb();
+    RUN(cup2d_vorticity(ctx, CUP2D_BLOCKS_ALL));
+    std::vector<double> linf(n);
+    RUN(cup2d_block_linf(ctx, CUP2D_TMP, linf.data()));
+    std::vector<int32_t> st(n);
+    bool any = false;
+    for (int b = 0; b < n; b++) {  // main.cpp:4678-4690
+      const int l = blocks[3 * b];
+      st[b] = linf[b] > rtol ? 1 : linf[b] < ctol ? 2 : 0;
+      if ((st[b] == 1 && l == level_max - 1) || (st[b] == 2 && l == 0)) st[b] = 0;
+    }
+    RUN(cup2d_amr_validate_states(n, blocks.data(), 1, 1, level_max, st.data()));
+    for (int b = 0; b < n; b++) any = any || st[b] != 0;
+    if (!any) return false;
+    static const int fields[5] = {CUP2D_CHI, CUP2D_VEL, CUP2D_VOLD, CUP2D_PRES, CUP2D_POLD};
+    static const int32_t dims[5] = {1, 2, 2, 1, 1}, vec[5] = {0, 1, 1, 0, 0};
+    std::vector<std::vector<double>> src(5), dst(5);
+    const double *sp[5];
+    double *dp[5];
+    for (int f = 0; f < 5; f++) {
+      src[f].resize((size_t)n * BC * dims[f]);
+      RUN(cup2d_download_slab(ctx, fields[f], src[f].data()));
+      sp[f] = src[f].data();
+    }
+    const long long n2 = cup2d_amr_regrid(n, blocks.data(), 1, 1, level_max, st.data(), 5, sp, dims, vec, 0, nullptr, nullptr);
+    if (n2 < 0) { std::fprintf(stderr, "cup2d_run: amr_regrid: %s\n", cup2d_last_error()); std::exit(1); }
+    std::vector<int32_t> nblocks2((size_t)3 * n2);
+    for (int f = 0; f < 5; f++) {
+      dst[f].resize((size_t)n2 * BC * dims[f]);
+      dp[f] = dst[f].data();
+    }
+    if (cup2d_amr_regrid(n, blocks.data(), 1, 1, level_max, st.data(), 5, sp, dims, vec, n2, nblocks2.data(), dp) != n2) {
+      std::fprintf(stderr, "cup2d_run: amr_regrid: %s\n", cup2d_last_error());
+      std::exit(1);
+    }
+    blocks.swap(nblocks2);
+    build();
+    for (int f = 0; f < 5; f++) RUN(cup2d_upload_slab(ctx, fields[f], dst[f].data()));
+    return true;
+  }
+};
+
+int run_amr(int level_start, int level_max, double rtol, double ctol, int steps, double nu, double cfl, double tol, double tol_rel,
+            int max_restarts, int max_iter, const std::string &init, const std::string &state, int device, int math) {
+  AmrRun R;
+  R.device = device;
+  R.math = math;
+  const int n0 = 1 << level_start;
+  for (int j = 0; j < n0; j++)
+    for (int i = 0; i < n0; i++) {
+      R.blocks.push_back(level_start);
+      R.blocks.push_back(i);
+      R.blocks.push_back(j);
+    }
+  R.build();
+  std::vector<double> vel((size_t)R.nb() * BC * 2);
+  if (!init.empty()) {
+    FILE *f = std::fopen(init.c_str(), "rb");
+    if (!f || std::fread(vel.data(), sizeof(double), vel.size(), f) != vel.size()) { std::fprintf(stderr, "cup2d_run: cannot read %zu doubles from %s\n", vel.size(), init.c_str()); return 1; }
+    std::fclose(f);
+  } else {
+    const double h = 1.0 / (BS << level_start);
+    for (int b = 0; b < R.nb(); b++)
+      for (int c = 0; c < BC; c++) {
+        const double x = (R.blocks[3 * b + 1] * BS + c % BS + 0.5) * h, y = (R.blocks[3 * b + 2] * BS + c / BS + 0.5) * h;
+        double u = 0, v = 0;
+        const double vort[2][3] = {{0.35, 0.5, 1.0}, {0.65, 0.5, -1.0}};
+        for (const auto &w : vort) {
+          const double dx = x - w[0], dy = y - w[1], fq = w[2] * std::exp(-(dx * dx + dy * dy) / (0.06 * 0.06)) / 0.06;
+          u += -dy * fq;
+          v += dx * fq;
+        }
+        vel[((size_t)b * BC + c) * 2] = u;
+        vel[((size_t)b * BC + c) * 2 + 1] = v;
+      }
+  }
+  RUN(cup2d_upload_slab(R.ctx, CUP2D_VEL, vel.data()));
+  double time = 0.0;
+  for (int step = 0; step < steps; step++) {
+    double dt = 0, err = 0;
+    int iters = 0;
+    RUN(cup2d_compute_dt(R.ctx, nu, cfl, &dt));  // before the regrid, as main.cpp:6579-6603 orders them
+    R.adapt(rtol, ctol, level_max);
+    const bool early = step < 10;
+    RUN(cup2d_advect_diffuse_rk2(R.ctx, nu, dt));
+    RUN(cup2d_poisson_rhs(R.ctx, dt, 0));
+    RUN(cup2d_poisson_solve(R.ctx, early ? 0.0 : tol, early ? 0.0 : tol_rel, early ? 100 : max_restarts, max_iter, &iters, nullptr, &err, nullptr));
+    RUN(cup2d_project(R.ctx, dt));
+    time += dt;
+    std::printf("step %d time %.17g dt %.17g poisson_iters %d poisson_err %.6e blocks %d\n", step + 1, time, dt, iters, err, R.nb());
+  }
+  if (!state.empty()) {
+    const int n = R.nb();
+    std::vector<double> v((size_t)n * BC * 2), p((size_t)n * BC);
+    RUN(cup2d_download_slab(R.ctx, CUP2D_VEL, v.data()));
+    RUN(cup2d_download_slab(R.ctx, CUP2D_PRES, p.data()));
+    const auto put = [](const std::string &file, const void *data, size_t bytes) {
+      FILE *f = std::fopen(file.c_str(), "wb");
+      if (!f || std::fwrite(data, 1, bytes, f) != bytes) { std::fprintf(stderr, "cup2d_run: cannot write %s\n", file.c_str()); std::exit(1); }
+      std::fclose(f);
+    };
+    put(state + ".blocks.i32", R.blocks.data(), R.blocks.size() * sizeof(int32_t));
+    put(state + ".vel.f64", v.data(), v.size() * sizeof(double));
+    put(state + ".pres.f64", p.data(), p.size() * sizeof(double));
+  }
+  std::printf("done: %d steps, %d blocks\n", steps, R.nb());
+  cup2d_destroy(R.ctx);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
-  int nx = 256, ny = 0, steps = 10, max_restarts = 0, max_iter = 1000, every = 0, device = 0;
-  double nu = 1e-3, cfl = 0.5, tol = 1e-3, tol_rel = 1e-2;
-  std::string init, prefix;
+  int nx = 256, ny = 0, steps = 10, max_restarts = 0, max_iter = 1000, every = 0, device = 0, level_max = 0, level_start = 2;
+  int math = CUP2D_MATH_FAST;
+  double nu = 1e-3, cfl = 0.5, tol = 1e-3, tol_rel = 1e-2, rtol = 2.0, ctol = 0.5;
+  std::string init, prefix, state;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     const char *v = argv[i + 1];
@@ -154,7 +305,17 @@ int main(int argc, char **argv) {
     else if (k == "-dump") prefix = v;
     else if (k == "-every") every = std::atoi(v);
     else if (k == "-device") device = std::atoi(v);
+    else if (k == "-levelMax") level_max = std::atoi(v);
+    else if (k == "-levelStart") level_start = std::atoi(v);
+    else if (k == "-Rtol") rtol = std::atof(v);
+    else if (k == "-Ctol") ctol = std::atof(v);
+    else if (k == "-state") state = v;
+    else if (k == "-math") math = std::strcmp(v, "strict") == 0 ? CUP2D_MATH_STRICT : CUP2D_MATH_FAST;
     else { std::fprintf(stderr, "cup2d_run: unknown option %s\n", k.c_str()); return 2; }
+  }
+  if (level_max > 0) {
+    if (level_start < 0 || level_start >= level_max || level_max > 16) { std::fprintf(stderr, "cup2d_run: 0 <= -levelStart < -levelMax <= 16 expected\n"); return 2; }
+    return run_amr(level_start, level_max, rtol, ctol, steps, nu, cfl, tol, tol_rel, max_restarts, max_iter, init, state, device, math);
   }
   if (ny == 0) ny = nx;
   if (nx < BS || ny < BS || nx % BS || ny % BS || steps < 0) { std::fprintf(stderr, "cup2d_run: -n / -ny must be positive multiples of 8\n"); return 2; }
@@ -181,6 +342,7 @@ int main(int argc, char **argv) {
 
   cup2d_ctx *ctx = nullptr;
   RUN(cup2d_create(&ctx, g.nblocks, 0, g.nblocks, g.nbr.data(), h, device));
+  RUN(cup2d_set_math(ctx, math));
   RUN(cup2d_upload_slab(ctx, CUP2D_VEL, slab.data()));
   double time = 0.0;
   const auto maybe_dump = [&](int step) {

@@ -411,6 +411,49 @@ def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle):
 
 
 @pytest.mark.gpu
+def test_cpp_host_driver_amr_run_matches_python_gpu(gpu_lib, tmp_path):
+    """the block-AMR flow of the C++ host driver (csrc/cup2d_run.cpp -levelMax: dt, adapt() through the library's host
+    routines, context rebuild, operator re-assembly, step) against the same sequence driven from Python: same leaves in
+    the same order, same dt and iteration count per step, bit-identical fields"""
+    import os
+    import subprocess
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps, lstart, lmax, rtol, ctol = 4, 2, 5, 2.0, 0.5
+    g = AmrBlockGrid([(lstart, i, j) for j in range(1 << lstart) for i in range(1 << lstart)])
+    x, y = g.cell_centres()
+    u, v = np.zeros_like(x), np.zeros_like(x)
+    for cx, cy, gam in ((0.35, 0.5, 1.0), (0.65, 0.5, -1.0)):
+        dx, dy = x - cx, y - cy
+        f = gam * np.exp(-(dx * dx + dy * dy) / (0.06 * 0.06)) / 0.06
+        u += -dy * f
+        v += dx * f
+    vel0 = np.stack([u, v], axis=-1)
+    init = str(tmp_path / "vel0.f64")
+    np.ascontiguousarray(vel0).tofile(init)
+    r = subprocess.run([os.path.join(root, "cup2d_amd", "cup2d_run"), "-levelStart", str(lstart), "-levelMax", str(lmax), "-Rtol", str(rtol),
+                        "-Ctol", str(ctol), "-steps", str(steps), "-maxiter", "200", "-math", "strict", "-init", init, "-state",
+                        str(tmp_path / "cpp")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l.split() for l in r.stdout.decode().splitlines() if l.startswith("step ")]
+    assert len(lines) == steps
+    with AmrSimulation(g, nu=1e-3, cfl=0.5) as s:
+        s.install_poisson_matrix()
+        s.set_math(True)
+        s.set_field(L.VEL, vel0)
+        for k in range(steps):
+            dt = s.compute_dt()
+            s.adapt(rtol, ctol, lmax)
+            info = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=200, dt=dt)
+            assert float(lines[k][5]) == dt and int(lines[k][7]) == info["iters"] and int(lines[k][11]) == s.grid.nblocks, (k, lines[k], info)
+        blocks = np.fromfile(str(tmp_path / "cpp.blocks.i32"), dtype=np.int32).reshape(-1, 3)
+        assert np.array_equal(blocks, s.grid.blocks) and len(blocks) > 16
+        assert np.array_equal(np.fromfile(str(tmp_path / "cpp.vel.f64")).reshape(len(blocks), 64, 2), s.get_field(L.VEL))
+        assert np.array_equal(np.fromfile(str(tmp_path / "cpp.pres.f64")).reshape(len(blocks), 64), s.get_field(L.PRES))
+
+
+@pytest.mark.gpu
 def test_amr_unsupported_entry_points_say_so(gpu_lib):
     import ctypes
     from cup2d_amd import lib as L

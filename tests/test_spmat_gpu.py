@@ -52,7 +52,8 @@ def test_amr_time_loop_with_hip_spmat(gpu_lib, oracle):
     libcup2d_spmat.so's general sliced-ELL operator on the GPU, against the same run with the CPU restatement
     of cuda.cu behind the seam.  Same regrid history, same fields to the solve tolerance."""
     assert oracle.have_reference_hip(), "oracle/_ref/ref_harness_hip was not shipped"
-    kw = dict(level_start=2, level_max=5, steps=8, rtol=2.0, ctol=0.5, nu=1e-3, max_iter=200)
+    # one OpenMP thread: a fixed reduction order in the reference's own loops, so that the two runs differ by the solver only
+    kw = dict(level_start=2, level_max=5, steps=8, rtol=2.0, ctol=0.5, nu=1e-3, max_iter=200, env={"OMP_NUM_THREADS": "1"})
     C = oracle.ref_run_amr(**kw)
     G = oracle.ref_run_amr(hip=True, **kw)
     assert [s["blocks"] for s in G["steps"]] == [s["blocks"] for s in C["steps"]]

@@ -541,9 +541,8 @@ int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
 // main.cpp:7007-7027: tmp = pressure_rhs (+ flux correction); pold = pres; pres = 0; tmp -= Lap(pold) (+ flux correction)
 int amr_poisson_rhs(cup2d_ctx *c, double dt) {
   CUP2D_TRY(amr_pressure_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], c->d_field[CUP2D_CHI], c->d_field[CUP2D_TMP], dt));
-  double *tmp = c->d_field[CUP2D_POLD];
-  c->d_field[CUP2D_POLD] = c->d_field[CUP2D_PRES];
-  c->d_field[CUP2D_PRES] = tmp;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_POLD], c->d_field[CUP2D_PRES], (size_t)c->nblocks * BC * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c->stream));  // a copy: the public slab pointers stay put
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_field[CUP2D_PRES], 0, (size_t)c->ntotal * BC * sizeof(double), c->stream));
   return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1);
 }

@@ -106,6 +106,8 @@ using namespace cup2d;
 
 extern "C" {
 
+static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const int32_t *nbr, double h, int device);
+
 const char *cup2d_last_error(void) { return g_err; }
 const char *cup2d_version(void) { return "cup2d_hip 0.1 (gfx950)"; }
 
@@ -130,6 +132,15 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   }
   CUP2D_HIP_CHECK(hipSetDevice(device));
   cup2d_ctx *c = new cup2d_ctx;
+  const int st = create_impl(c, nblocks, nghost, n_inner, nbr, h, device);
+  if (st != CUP2D_OK) {  // nothing of a half-built context leaks: cup2d_destroy frees whatever was allocated
+    cup2d_destroy(c);
+    return st;
+  }
+  *out = c;
+  return CUP2D_OK;
+}
+static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const int32_t *nbr, double h, int device) {
   c->device = device;
   c->nblocks = nblocks;
   c->nghost = nghost;
@@ -190,7 +201,6 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_status, sizeof(int) * cup2d_ctx::SOLVE_AHEAD));
   for (auto &e : c->solve_ev) CUP2D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  *out = c;
   return CUP2D_OK;
 }
 
@@ -198,6 +208,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)comm_finalize_impl(c);
   (void)hipFree(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
   (void)hipFree(c->d_vscratch);
@@ -218,7 +229,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
   (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(c->own_stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -447,10 +458,10 @@ int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
     return amr_poisson_rhs(c, dt);
   }
   if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
-  // pold = pres; pres = 0 (main.cpp:7016-7021) as a pointer swap + memset
-  double *tmp = c->d_field[CUP2D_POLD];
-  c->d_field[CUP2D_POLD] = c->d_field[CUP2D_PRES];
-  c->d_field[CUP2D_PRES] = tmp;
+  // pold = pres; pres = 0 (main.cpp:7016-7021): a device copy, not a pointer swap -- the slab pointers a caller got
+  // from cup2d_field_ptr stay valid for the life of the context
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_POLD], c->d_field[CUP2D_PRES], (size_t)c->nblocks * BC * sizeof(double),
+                                 hipMemcpyDeviceToDevice, c->stream));
   CUP2D_TRY(launch_zero(c, c->d_field[CUP2D_PRES], slab_doubles(c, 1)));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_POLD], 1, 1));

@@ -1,0 +1,276 @@
+// comm.hip -- the communicator inside the library: RCCL over xGMI, no host language in the data path.
+//
+// Replaces, for a domain-decomposed block grid (one process per GPU):
+//   * the face exchange of the reference's synchroniser -- MPI_Irecv / MPI_Isend of the packed strips and the
+//     MPI_Waitall before the halo blocks are swept (main.cpp:2040-2047, 2133-2139, computeA's overlap 3035-3057;
+//     for the assembled operator cuda.cu:365-380): ncclRecv / ncclSend pairs of one ncclGroup on a SECOND HIP stream,
+//     ordered after the pack kernel by an event; the compute stream waits for the arrival event only where the
+//     library unpacks, so the inner blocks are swept while the strips are on the links;
+//   * the scalar reductions -- MPI_Allreduce of max|u| and of the pressure means (main.cpp:6583-6592, 7138, 7162)
+//     and the solver's dot products and norms (cuda.cu:445-449, 491-493, 513-515, 533-534): ncclAllReduce of <= 3
+//     doubles on the compute stream, or ONE ncclAllGather of {sum, sum, max} per rank followed by a fixed-order
+//     finish on the device where a sum and a max are due together (a sum and a max cannot share an all-reduce).
+// Two communicators, one per stream: RCCL serialises the operations of ONE communicator in issue order, and a
+// reduction must not queue behind an exchange that is deliberately left in flight.
+//
+// librccl.so.1 is opened on first use (dlopen), not linked: a process that never decomposes its grid never loads it.
+// The callback interface of cup2d_set_comm stays for callers that bring their own transport (the gloo tests).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ctx.h"
+
+namespace cup2d {
+
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi *rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  const char *names[] = {getenv("CUP2D_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names)
+    if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) {
+    set_error("comm: cannot open librccl.so.1 (%s)", dlerror());
+    return nullptr;
+  }
+  bool ok = true;
+  const auto sym = [&](const char *name) -> void * {
+    void *p = dlsym(h, name);
+    if (!p) {
+      set_error("comm: librccl lacks %s", name);
+      ok = false;
+    }
+    return p;
+  };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!ok) {
+    dlclose(h);
+    return nullptr;
+  }
+  api.handle = h;
+  return &api;
+}
+
+struct RcclComm {
+  RcclApi *api = nullptr;
+  ncclComm_t p2p = nullptr, red = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  int nranks = 1, rank = 0;
+  std::vector<int> peer, soff, roff, cnt;   // per peer: rank, first strip in the send / receive list, strips
+  double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
+  long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
+};
+
+#define CUP2D_NCCL(rc, expr)                                                                     \
+  do {                                                                                           \
+    ncclResult_t _r = (expr);                                                                    \
+    if (_r != ncclSuccess) {                                                                     \
+      set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, (rc)->api->GetErrorString(_r));     \
+      return -1;                                                                                 \
+    }                                                                                            \
+  } while (0)
+#define CUP2D_HIP_CB(expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));             \
+      return -1;                                                                                 \
+    }                                                                                            \
+  } while (0)
+
+// exchange callback: the strips packed by work already enqueued on `stream` go out on the communication stream
+static int rccl_exchange(void *user, double *send, double *recv, int strip_doubles, void *stream) {
+  RcclComm *rc = static_cast<RcclComm *>(user);
+  rc->n_exchange++;
+  if (rc->peer.empty()) return 0;
+  CUP2D_HIP_CB(hipEventRecord(rc->ev_packed, (hipStream_t)stream));
+  CUP2D_HIP_CB(hipStreamWaitEvent(rc->comm_stream, rc->ev_packed, 0));
+  const size_t sd = (size_t)strip_doubles;
+  CUP2D_NCCL(rc, rc->api->GroupStart());
+  for (size_t i = 0; i < rc->peer.size(); i++)  // receives first, as main.cpp:2040-2047 posts them
+    CUP2D_NCCL(rc, rc->api->Recv(recv + rc->roff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+  for (size_t i = 0; i < rc->peer.size(); i++)
+    CUP2D_NCCL(rc, rc->api->Send(send + rc->soff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+  CUP2D_NCCL(rc, rc->api->GroupEnd());
+  CUP2D_HIP_CB(hipEventRecord(rc->ev_arrived, rc->comm_stream));
+  return 0;
+}
+// wait callback: the compute stream goes on once the strips of the last exchange have arrived
+static int rccl_wait(void *user, void *stream) {
+  RcclComm *rc = static_cast<RcclComm *>(user);
+  if (rc->peer.empty()) return 0;
+  CUP2D_HIP_CB(hipStreamWaitEvent((hipStream_t)stream, rc->ev_arrived, 0));
+  return 0;
+}
+static int rccl_allreduce(void *user, double *buf, int count, int op, void *stream) {
+  RcclComm *rc = static_cast<RcclComm *>(user);
+  rc->n_allreduce++;
+  CUP2D_NCCL(rc, rc->api->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, rc->red, (hipStream_t)stream));
+  return 0;
+}
+
+// {sum, sum, max} of every rank side by side, then one wave adds / maximises them in rank order: a sum and a max in ONE
+// collective, and a summation order that does not depend on the algorithm RCCL picks
+__global__ void k_gather_finish(const double *__restrict__ g, int nranks, double *__restrict__ red) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0, b = 0, m = 0;
+  for (int r = 0; r < nranks; r++) {
+    a += g[3 * r];
+    b += g[3 * r + 1];
+    m = fmax(m, g[3 * r + 2]);
+  }
+  red[0] = a; red[1] = b; red[2] = m;
+}
+int comm_sum2_max1(cup2d_ctx *c) {
+  RcclComm *rc = c->rccl;
+  rc->n_allgather++;
+  CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, 3, ncclDouble, rc->red, c->stream));
+  hipLaunchKernelGGL(k_gather_finish, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, c->d_red);
+  CUP2D_HIP_CB(hipGetLastError());
+  return 0;
+}
+
+int comm_finalize_impl(cup2d_ctx *c) {
+  RcclComm *rc = c->rccl;
+  if (!rc) return CUP2D_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (rc->comm_stream) (void)hipStreamSynchronize(rc->comm_stream);
+  if (c->comm_user == rc) {
+    c->exchange = nullptr; c->wait = nullptr; c->allreduce = nullptr; c->comm_user = nullptr;
+    c->d_send = c->d_recv = nullptr;
+    c->d_red = c->d_red_own;
+  }
+  if (rc->p2p) (void)rc->api->CommDestroy(rc->p2p);
+  if (rc->red) (void)rc->api->CommDestroy(rc->red);
+  if (rc->ev_packed) (void)hipEventDestroy(rc->ev_packed);
+  if (rc->ev_arrived) (void)hipEventDestroy(rc->ev_arrived);
+  if (rc->comm_stream) (void)hipStreamDestroy(rc->comm_stream);
+  (void)hipFree(rc->d_send); (void)hipFree(rc->d_recv); (void)hipFree(rc->d_red); (void)hipFree(rc->d_gather);
+  delete rc;
+  c->rccl = nullptr;
+  return CUP2D_OK;
+}
+
+}  // namespace cup2d
+
+using namespace cup2d;
+
+extern "C" {
+
+int cup2d_comm_unique_id(void *id_bytes) {
+  if (!id_bytes) { set_error("comm_unique_id: null"); return CUP2D_ERR_ARG; }
+  RcclApi *api = rccl_api();
+  if (!api) return CUP2D_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) * 2 == CUP2D_COMM_ID_BYTES, "CUP2D_COMM_ID_BYTES = two ncclUniqueIds");
+  ncclUniqueId ids[2];
+  for (auto &id : ids) {
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { set_error("ncclGetUniqueId -> %s", api->GetErrorString(r)); return CUP2D_ERR_COMM; }
+  }
+  memcpy(id_bytes, ids, sizeof ids);
+  return CUP2D_OK;
+}
+
+int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
+                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips) {
+  CUP2D_CHECK_CTX(c);
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id_bytes || npeers < 0 ||
+      (npeers && (!peer_rank || !send_offset || !recv_offset || !nstrips))) {
+    set_error("comm_init: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  for (int i = 0; i < npeers; i++)
+    if (peer_rank[i] < 0 || peer_rank[i] >= nranks || nstrips[i] < 0 || send_offset[i] < 0 || recv_offset[i] < 0 ||
+        send_offset[i] + nstrips[i] > c->plan.nsend || recv_offset[i] + nstrips[i] > c->plan.nrecv) {
+      set_error("comm_init: peer %d (rank %d, strips %d at %d / %d) does not fit the halo plan (%d sent, %d received): "
+                "call cup2d_halo_plan first", i, peer_rank[i], nstrips[i], send_offset[i], recv_offset[i], c->plan.nsend, c->plan.nrecv);
+      return CUP2D_ERR_ARG;
+    }
+  if (c->rccl) CUP2D_TRY(comm_finalize_impl(c));
+  RcclApi *api = rccl_api();
+  if (!api) return CUP2D_ERR_COMM;
+  RcclComm *rc = new RcclComm;
+  c->rccl = rc;  // owned by the context from here on: cup2d_destroy / comm_finalize release whatever exists
+  rc->api = api;
+  rc->nranks = nranks;
+  rc->rank = rank;
+  for (int i = 0; i < npeers; i++) {
+    if (nstrips[i] == 0) continue;
+    rc->peer.push_back(peer_rank[i]); rc->soff.push_back(send_offset[i]);
+    rc->roff.push_back(recv_offset[i]); rc->cnt.push_back(nstrips[i]);
+  }
+  // widest message: whole blocks of two Krylov vectors = 128 doubles per strip (the WENO halo is 3 x 8 x 2 = 48)
+  const size_t strip = 2 * BC;
+  CUP2D_HIP_CHECK(hipMalloc(&rc->d_send, sizeof(double) * strip * (size_t)(c->plan.nsend > 0 ? c->plan.nsend : 1)));
+  CUP2D_HIP_CHECK(hipMalloc(&rc->d_recv, sizeof(double) * strip * (size_t)(c->plan.nrecv > 0 ? c->plan.nrecv : 1)));
+  CUP2D_HIP_CHECK(hipMalloc(&rc->d_red, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(hipMalloc(&rc->d_gather, sizeof(double) * 3 * (size_t)nranks));
+  CUP2D_HIP_CHECK(hipMemset(rc->d_red, 0, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&rc->comm_stream, hipStreamNonBlocking));
+  CUP2D_HIP_CHECK(hipEventCreateWithFlags(&rc->ev_packed, hipEventDisableTiming));
+  CUP2D_HIP_CHECK(hipEventCreateWithFlags(&rc->ev_arrived, hipEventDisableTiming));
+  ncclUniqueId ids[2];
+  memcpy(ids, id_bytes, sizeof ids);
+  ncclResult_t r = api->CommInitRank(&rc->p2p, nranks, ids[0], rank);
+  if (r == ncclSuccess) r = api->CommInitRank(&rc->red, nranks, ids[1], rank);
+  if (r != ncclSuccess) {
+    set_error("ncclCommInitRank(%d of %d) -> %s", rank, nranks, api->GetErrorString(r));
+    return CUP2D_ERR_COMM;
+  }
+  return cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red);
+}
+
+int cup2d_comm_finalize(cup2d_ctx *c) {
+  CUP2D_CHECK_CTX(c);
+  return comm_finalize_impl(c);
+}
+
+int cup2d_comm_stats(cup2d_ctx *c, int *nranks, int *npeers, long long *exchanges, long long *allreduces, long long *allgathers) {
+  CUP2D_CHECK_CTX(c);
+  if (!c->rccl) { set_error("comm_stats: no communicator"); return CUP2D_ERR_ARG; }
+  if (nranks) *nranks = c->rccl->nranks;
+  if (npeers) *npeers = (int)c->rccl->peer.size();
+  if (exchanges) *exchanges = c->rccl->n_exchange;
+  if (allreduces) *allreduces = c->rccl->n_allreduce;
+  if (allgathers) *allgathers = c->rccl->n_allgather;
+  return CUP2D_OK;
+}
+
+int cup2d_halo_exchange(cup2d_ctx *c, int field, int width) {
+  CUP2D_CHECK_CTX(c);
+  if (!field_ok(field) || width < 1 || width > BS) { set_error("halo_exchange: field %d width %d", field, width); return CUP2D_ERR_ARG; }
+  if (c->nghost > 0 && !c->exchange) { set_error("halo_exchange: no communicator (cup2d_comm_init / cup2d_set_comm)"); return CUP2D_ERR_COMM; }
+  return exchange_halo(c, c->d_field[field], dim_of(field), width);
+}
+
+}  // extern "C"

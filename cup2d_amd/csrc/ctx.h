@@ -89,6 +89,8 @@ struct SellMatrix {
 
 enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
 
+struct RcclComm;  // comm.hip: the in-library RCCL communicator (cup2d_comm_init)
+
 // Block-AMR topology (amr.hip): per block its level and, per side W,E,S,N, what lies across it
 struct AmrTopo {
   bool active = false;
@@ -150,6 +152,8 @@ struct cup2d_ctx {
   double *d_red_own = nullptr;
   void *comm_user = nullptr;
   double *d_send = nullptr, *d_recv = nullptr;
+  cup2d::RcclComm *rccl = nullptr;  // set by cup2d_comm_init; the callbacks above then point into comm.hip
+  bool fused_lds_opt_in = false;    // k_fused's > 64 KiB of dynamic LDS opted in on THIS context's device
   // timing: pool of event pairs, resolved lazily
   int timing = 0;          // 0 off, 1 every launch, 2 sampled (every launch outside the solver, every 8th iteration inside)
   bool prof_sample = true; // sampled mode: record the launches issued now
@@ -262,6 +266,9 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
+// comm.hip
+int comm_finalize_impl(cup2d_ctx *c);
+int comm_sum2_max1(cup2d_ctx *c);  // d_red[0..2] = {sum, sum, max} over the ranks in ONE collective (all-gather + fixed-order finish)
 static inline bool overlapped(const cup2d_ctx *c) { return c->nghost > 0 && c->exchange && c->n_inner < c->nblocks; }
 
 }  // namespace cup2d

@@ -648,14 +648,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->h_sc, sizeof init, hipMemcpyHostToDevice, c->stream));
   int gridE = (int)((n / 2 + WG - 1) / WG);
   if (gridE > c->grid) gridE = c->grid;
-  static bool lds_set = false;
-  if (!lds_set) {  // > 64 KiB of LDS is an opt-in per kernel
+  if (!c->fused_lds_opt_in) {  // > 64 KiB of LDS is an opt-in per kernel AND device: remembered per context
     const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, 0>), reinterpret_cast<const void *>(&k_fused<0, 1>),
                         reinterpret_cast<const void *>(&k_fused<0, 2>), reinterpret_cast<const void *>(&k_fused<1, 0>),
                         reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
-    lds_set = true;
+    c->fused_lds_opt_in = true;
   }
   // in-kernel finish.  1: one GPU -- one launch per sweep, the last workgroup also runs the scalar update.
   // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars

@@ -18,6 +18,8 @@
 // are dealt contiguously per XCD (workgroup w runs on XCD w % 8).
 #include <type_traits>
 
+#include <utility>
+
 #include "block.h"
 #include "krylov_common.h"
 
@@ -225,6 +227,14 @@ static int launch_smoother(cup2d_ctx *c, const double *x, const double *b, doubl
   return CUP2D_OK;
 }
 
+__global__ __launch_bounds__(WG) void k_swap_contents(double2 *__restrict__ a, double2 *__restrict__ b, size_t n2) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
+    const double2 u = a[i], v = b[i];
+    a[i] = v;
+    b[i] = u;
+  }
+}
+
 static int smoother_check(cup2d_ctx *c, const char *who) {
   if (c->amr.active || c->mat.active) {
     set_error("%s: built for the matrix-free operator of a same-level grid (no AMR tables, no installed matrix)", who);
@@ -254,15 +264,24 @@ extern "C" int cup2d_jacobi_sweeps(cup2d_ctx *c, double omega, int nsweeps, doub
     set_error("jacobi_sweeps: nsweeps >= 0 and omega > 0 expected");
     return CUP2D_ERR_ARG;
   }
+  // the sweeps ping-pong between the two slabs; the public slab pointers (cup2d_field_ptr) never change, so after an odd
+  // number of sweeps the CONTENTS are exchanged once (the new iterate belongs in PRES, the one before it in POLD)
+  double *x = c->d_field[CUP2D_PRES], *xn = c->d_field[CUP2D_POLD];
   for (int s = 0; s < nsweeps; s++) {
-    double *x = c->d_field[CUP2D_PRES], *xn = c->d_field[CUP2D_POLD];
     CUP2D_TRY(exchange_halo(c, x, 1, 1));
     {
       ProfScope ps(c, CUP2D_T_SMOOTHER);
       CUP2D_TRY(launch_smoother<0>(c, x, c->d_field[CUP2D_TMP], xn, omega));
     }
-    c->d_field[CUP2D_PRES] = xn;  // pointer swap: the new iterate is PRES, the old one is left in POLD
-    c->d_field[CUP2D_POLD] = x;
+    std::swap(x, xn);
+  }
+  if (nsweeps & 1) {
+    const size_t n2 = (size_t)c->ntotal * BC / 2;
+    int g = (int)((n2 + WG - 1) / WG);
+    if (g > c->grid) g = c->grid;
+    hipLaunchKernelGGL(k_swap_contents, dim3(g), dim3(WG), 0, c->stream, (double2 *)c->d_field[CUP2D_PRES],
+                       (double2 *)c->d_field[CUP2D_POLD], n2);
+    CUP2D_HIP_CHECK(hipGetLastError());
   }
   return nsweeps > 0 ? smoother_norm(c, linf) : CUP2D_OK;
 }

@@ -93,10 +93,11 @@ class TorchComm:
 
     MAX_STRIP = 128  # WENO halo: 3 layers x 8 cells x 2 components = 48; Krylov ghost blocks: two whole scalar blocks = 128
 
-    def __init__(self, topo, mode, device=None):
+    def __init__(self, topo, mode, device=None, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.topo, self.mode = torch, dist, topo, mode
+        self.group = group  # process group of the data path (None = the default group)
         dev = torch.device("cpu") if mode == "host" else torch.device("cuda", device)
         self.send = torch.zeros(max(1, topo.nsend) * self.MAX_STRIP, dtype=torch.float64, device=dev)
         self.recv = torch.zeros(max(1, topo.nrecv) * self.MAX_STRIP, dtype=torch.float64, device=dev)
@@ -128,9 +129,9 @@ class TorchComm:
         if ops is None:
             ops = []
             for peer, soff, roff, n in self.topo.peers:
-                ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer))
+                ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer, self.group))
             for peer, soff, roff, n in self.topo.peers:
-                ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer))
+                ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer, self.group))
             self._ops[key] = ops
         return dist.batch_isend_irecv(ops) if ops else []
 
@@ -170,41 +171,66 @@ class TorchComm:
             if view is None:
                 view = self._red_views[(offset, count)] = self.red[offset:offset + count]
             with torch.cuda.stream(self.compute_stream):
-                dist.all_reduce(view, op=rop)
+                dist.all_reduce(view, op=rop, group=self.group)
         elif self.mode == "staged":
             with torch.cuda.stream(self.compute_stream):
                 self.h_red[offset:offset + count].copy_(self.red[offset:offset + count], non_blocking=True)
             self.compute_stream.synchronize()
-            dist.all_reduce(self.h_red[offset:offset + count], op=rop)
+            dist.all_reduce(self.h_red[offset:offset + count], op=rop, group=self.group)
             with torch.cuda.stream(self.compute_stream):
                 self.red[offset:offset + count].copy_(self.h_red[offset:offset + count], non_blocking=True)
         else:
-            dist.all_reduce(self.red[offset:offset + count], op=rop)
+            dist.all_reduce(self.red[offset:offset + count], op=rop, group=self.group)
 
 
 class DistributedSimulation(Simulation):
     """One rank's patch of a px x py decomposition; same interface as Simulation.  Fields set/get
-    through .vel/.pres/... are this rank's (nby*8, nbx*8) patch."""
+    through .vel/.pres/... are this rank's (nby*8, nbx*8) patch.
 
-    def __init__(self, nbx, nby, px, py, extent=1.0, nu=1e-3, cfl=0.5, order="hilbert", device=0, mode=None):
+    comm "rccl"  (default on the "nccl" backend): the communicator inside the library (cup2d_comm_init, csrc/comm.hip) --
+                 RCCL send/recv on the library's own communication stream, all-reduce / all-gather on its compute
+                 stream; torch.distributed only carries the rendezvous token to the ranks.  No Python between a
+                 cup2d_* call and its return.
+    comm "torch": the callback interface (cup2d_set_comm) served by TorchComm -- the transport of the gloo tests
+                 (mode "staged" / "host") and a second RCCL path (mode "device")."""
+
+    def __init__(self, nbx, nby, px, py, extent=1.0, nu=1e-3, cfl=0.5, order="hilbert", device=0, mode=None, comm=None,
+                 group=None):
         import torch
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
         assert world == px * py, "world size %d != %d x %d" % (world, px, py)
         self.topo = PatchTopology(nbx, nby, px, py, rank % px, rank // px, order=order)
+        if comm is None:
+            comm = "rccl" if (mode is None and dist.get_backend() == "nccl") else "torch"
+        if comm not in ("rccl", "torch"):
+            raise ValueError("comm must be 'rccl' or 'torch'")
         if mode is None:
             mode = "device" if dist.get_backend() == "nccl" else "staged"
         h = float(extent) / max(nbx * px, nby * py) / 8  # main.cpp:6338 on the GLOBAL grid
         super().__init__(nbx, nby, nu=nu, cfl=cfl, device=device, grid=self.topo.grid, h=h)
-        self.comm = TorchComm(self.topo, mode, device)
-        self.set_stream(self.comm.compute_stream.cuda_stream)
         t = self.topo
         vp = ctypes.c_void_p
         _l.check(self.L.cup2d_halo_plan(self._ctx, t.nsend, t.send_block.ctypes.data_as(vp), t.send_face.ctypes.data_as(vp),
                                         t.nrecv, t.recv_block.ctypes.data_as(vp), t.recv_face.ctypes.data_as(vp)), "halo_plan")
+        self.comm_kind = comm
+        self.comm_errors = []
+        if comm == "rccl":
+            self.comm = None
+            token = ctypes.create_string_buffer(_l.COMM_ID_BYTES)
+            if rank == 0:
+                _l.check(self.L.cup2d_comm_unique_id(token), "comm_unique_id")
+            box = [token.raw]
+            dist.broadcast_object_list(box, src=0)  # the only thing torch.distributed moves for this simulation (default group)
+            peers = np.asarray([(p, so, ro, n) for p, so, ro, n in t.peers], dtype=np.int32).reshape(-1, 4)
+            cols = [np.ascontiguousarray(peers[:, k]) for k in range(4)]
+            _l.check(self.L.cup2d_comm_init(self._ctx, world, rank, box[0], len(t.peers), *[c.ctypes.data_as(vp) for c in cols]),
+                     "comm_init")
+            return
+        self.comm = TorchComm(self.topo, mode, device, group=group)
+        self.set_stream(self.comm.compute_stream.cuda_stream)
         red_base = self.comm.red.data_ptr()
         comm = self.comm
-        self.comm_errors = []
 
         def _exchange(user, send, recv, strip_doubles, stream):
             try:
@@ -233,3 +259,15 @@ class DistributedSimulation(Simulation):
         self._cb = (_l.EXCHANGE_FN(_exchange), _l.WAIT_FN(_wait), _l.ALLREDUCE_FN(_allreduce))  # keep alive
         _l.check(self.L.cup2d_set_comm(self._ctx, self._cb[0], self._cb[1], self._cb[2], None,
                                        vp(comm.send.data_ptr()), vp(comm.recv.data_ptr()), vp(red_base)), "set_comm")
+
+    def comm_stats(self):
+        """ranks, peers of this rank and the collectives issued so far by the in-library communicator"""
+        i, ll = ctypes.c_int, ctypes.c_longlong
+        nr, np_, ex, ar, ag = i(), i(), ll(), ll(), ll()
+        _l.check(self.L.cup2d_comm_stats(self._ctx, ctypes.byref(nr), ctypes.byref(np_), ctypes.byref(ex), ctypes.byref(ar),
+                                         ctypes.byref(ag)), "comm_stats")
+        return dict(nranks=nr.value, peers=np_.value, exchanges=ex.value, allreduces=ar.value, allgathers=ag.value)
+
+    def halo_exchange(self, field, width):
+        """sync1 of main.cpp:1971-2142 for one field: pack, exchange, unpack the ghost strips (cup2d_halo_exchange)"""
+        _l.check(self.L.cup2d_halo_exchange(self._ctx, int(field), int(width)), "halo_exchange")

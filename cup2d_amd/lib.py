@@ -33,7 +33,9 @@ SYMBOLS = [
     "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather",
     "cup2d_set_solver", "cup2d_get_last_solver", "cup2d_set_amr", "cup2d_amr_poisson_coo", "cup2d_amr_tables", "cup2d_amr_validate_states", "cup2d_amr_regrid",
     "cup2d_jacobi_sweeps", "cup2d_poisson_residual", "cup2d_block_linf",
+    "cup2d_comm_unique_id", "cup2d_comm_init", "cup2d_comm_finalize", "cup2d_comm_stats", "cup2d_halo_exchange",
 ]
+COMM_ID_BYTES = 256
 AMR_WALL, AMR_SAME, AMR_COARSER, AMR_FINER = range(4)
 SOLVER_SWEEPS, SOLVER_FUSED = 0, 1
 PRECOND_LDS, PRECOND_MFMA, PRECOND_FD = 0, 1, 2
@@ -117,6 +119,12 @@ def load_library():
     L.cup2d_halo_pack_vec.argtypes = [vp, vp, i, i, vp]
     L.cup2d_halo_unpack_vec.argtypes = [vp, vp, i, i, vp]
     L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, WAIT_FN, ALLREDUCE_FN, vp, vp, vp, vp]
+    L.cup2d_comm_unique_id.argtypes = [vp]
+    L.cup2d_comm_init.argtypes = [vp, i, i, vp, i, vp, vp, vp, vp]
+    L.cup2d_comm_finalize.argtypes = [vp]
+    LL = ctypes.POINTER(ctypes.c_longlong)
+    L.cup2d_comm_stats.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i), LL, LL, LL]
+    L.cup2d_halo_exchange.argtypes = [vp, i, i]
     L.cup2d_set_timing.argtypes = [vp, i]
     L.cup2d_get_timing.argtypes = [vp, i, ctypes.POINTER(d), ctypes.POINTER(i)]
     _LIB = L

@@ -89,7 +89,9 @@ int cup2d_download(cup2d_ctx *ctx, int field, double *const *blocks);
 /* same, one contiguous [nblocks][64*dim] host array */
 int cup2d_upload_slab(cup2d_ctx *ctx, int field, const double *slab);
 int cup2d_download_slab(cup2d_ctx *ctx, int field, double *slab);
-/* raw device pointer of a slab ([nblocks+nghost][64*dim]) for callers that keep data on the GPU */
+/* raw device pointer of a slab ([nblocks+nghost][64*dim]) for callers that keep data on the GPU.  The pointer is valid
+ * and names the same field until cup2d_destroy: no call of this library re-seats a slab (pold = pres of
+ * main.cpp:7016-7021 is a device copy, the smoother's ping-pong ends with the contents in place). */
 int cup2d_field_ptr(cup2d_ctx *ctx, int field, void **device_ptr);
 int cup2d_fill(cup2d_ctx *ctx, int field, double value);
 int cup2d_copy_field(cup2d_ctx *ctx, int dst_field, int src_field);
@@ -297,6 +299,33 @@ typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int
  * (NULL keeps the context's own). */
 int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,
                    void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
+
+/* ---- the communicator inside the library: RCCL over xGMI (one process per GPU) ----
+ * Replaces the MPI of the reference on this path: Irecv / Isend / Waitall of the synchroniser (main.cpp:2040-2047,
+ * 2133-2139; cuda.cu:365-380) by ncclRecv / ncclSend pairs of one ncclGroup on a second HIP stream, ordered behind the
+ * pack kernel by an event and awaited only where the library unpacks (the inner blocks are swept meanwhile, computeA's
+ * overlap main.cpp:3035-3057); MPI_Allreduce of max|u|, the pressure means and the solver's dot products and norms
+ * (main.cpp:6583-6592, 7138, 7162; cuda.cu:445-449, 491-493, 513-515, 533-534) by ncclAllReduce of <= 3 doubles -- or one
+ * ncclAllGather where two sums and a max are due together: three collectives per BiCGSTAB iteration, the reference has four.
+ * No host language between a cup2d_* call and its return.
+ *
+ * cup2d_comm_unique_id: one rank creates the rendezvous token (two ncclUniqueIds: exchange and reduction communicators)
+ *   and hands the bytes to every rank by whatever it has (MPI_Bcast, a file, torch.distributed's store).
+ * cup2d_comm_init: collective over all ranks, after cup2d_halo_plan.  Peer p exchanges nstrips[p] strips with rank
+ *   peer_rank[p]: entries [send_offset[p], +nstrips[p]) of the plan's send list go out, entries [recv_offset[p], ..) of its
+ *   receive list come in; both ends enumerate a link's strips in the same order.  The library owns the message buffers
+ *   and the communication stream; it installs itself where cup2d_set_comm installs callbacks.
+ * cup2d_halo_exchange: pack, exchange, unpack of the ghost strips of a field (width cell layers, 1..8) -- sync1 of
+ *   main.cpp:1971-2142 for callers that run single block operators; cup2d_step and the solver do their own, overlapped.
+ * cup2d_comm_stats: ranks, peers of this rank, and how many exchanges / all-reduces / all-gathers were issued so far. */
+#define CUP2D_COMM_ID_BYTES 256
+int cup2d_comm_unique_id(void *id_bytes /* [CUP2D_COMM_ID_BYTES] */);
+int cup2d_comm_init(cup2d_ctx *ctx, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
+                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips);
+int cup2d_comm_finalize(cup2d_ctx *ctx);
+int cup2d_comm_stats(cup2d_ctx *ctx, int *nranks, int *npeers, long long *exchanges, long long *allreduces,
+                     long long *allgathers);
+int cup2d_halo_exchange(cup2d_ctx *ctx, int field, int width);
 
 /* ---------------------------------------------------------------- instrumentation -------- */
 /* HIP-event timing per kernel family, recorded on the context stream around the launches:

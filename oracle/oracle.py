@@ -264,9 +264,10 @@ def _run_ref(mode, n, d, _threads=None, _timeout=None, _hip=False, _env=None, **
     return r.stdout.decode()
 
 
-def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
+def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None, nomatrix=False):
     """Run every hot-path block functor of the reference on the given fields.
-    Returns dict of arrays (see ref_harness.cpp 'functors')."""
+    Returns dict of arrays (see ref_harness.cpp 'functors').  nomatrix: the harness drops the Poisson triplets the
+    reference's start-up assembles (the functors never read them; at 4096^2 that is most of the run time)."""
     vel = _c(vel)
     n = vel.shape[0]
     assert vel.shape == (n, n, 2)
@@ -281,6 +282,8 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None):
         kw = dict(nu=float(nu))
         if dt is not None:
             kw["dt"] = float(dt)
+        if nomatrix:
+            kw["nomatrix"] = 1
         _run_ref("functors", n, d, **kw)
         out = {}
         for name, dim in [("advdiff_rhs", 2), ("rk2_stage1", 2), ("rk2_vel", 2), ("vorticity", 1), ("pressure_rhs", 1),

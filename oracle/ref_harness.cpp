@@ -53,6 +53,8 @@ struct HarnessHooks {
   std::function<void(LocalSpMatDnVec *, bool /*withUpdate*/, double, double, int)> on_solve;
   int forced_max_iter = -1; /* <0: reference value 1000 (cuda.cu:438) */
   bool matvec_only = false; /* solve*() returns A*x in x_ instead of solving */
+  bool skip_matrix = false; /* functor-only modes (key nomatrix=1): the triplets main.cpp:7034-7112 pushes are dropped --
+                             * the functors never look at the matrix, and at 4096^2 assembling it is most of the start-up */
   int last_iters = 0;
   int last_restarts = 0;
   double last_error = 0, last_error_init = 0;
@@ -291,16 +293,23 @@ void LocalSpMatDnVec::reserve(const int N) { /* cuda.cu:567-587 */
   bd_cooValA_.clear();
   bd_cooRowA_long_.clear();
   bd_cooColA_long_.clear();
+  if (!hooks.skip_matrix) { /* capacities as cuda.cu:573-584: without them the push_backs re-allocate 25 times each */
+    loc_cooValA_.reserve(6 * (size_t)N);
+    loc_cooRowA_long_.reserve(6 * (size_t)N);
+    loc_cooColA_long_.reserve(6 * (size_t)N);
+  }
   x_.resize(N);
   b_.resize(N);
   h2_.resize(N / BLEN_);
 }
 void LocalSpMatDnVec::cooPushBackVal(const double val, const long long row, const long long col) {
+  if (hooks.skip_matrix) return;
   loc_cooValA_.push_back(val);
   loc_cooRowA_long_.push_back(row);
   loc_cooColA_long_.push_back(col);
 }
 void LocalSpMatDnVec::cooPushBackRow(const SpRowInfo &row) { /* cuda.cu:594-610 */
+  if (hooks.skip_matrix) return;
   for (const auto &cv : row.loc_colval_)
     cooPushBackVal(cv.second, row.idx_, cv.first);
   if (!row.neirank_cols_.empty()) {
@@ -538,7 +547,7 @@ static void usage() {
           "   amr      : the reference time loop with refinement on (levelmax= rtol= ctol= steps=), analytic vortex-pair IC;\n"
           "              writes blocks.final (level, i, j, vel, pres per block) and meta.txt\n"
           "   dump     : read <dir>/vel.in; write vel.{xyz.raw,attr.raw,xdmf2} with the reference's dump() (time = dt key)\n"
-          "  keys: nu dt cfl steps reps tol reltol restarts maxiter\n");
+          "  keys: nu dt cfl steps reps tol reltol restarts maxiter nomatrix (functors/bench/dump: do not assemble the matrix)\n");
 }
 
 int main(int argc, char **argv) {
@@ -549,6 +558,7 @@ int main(int argc, char **argv) {
   double nu = 1e-3, dt = -1, cfl = 0.5, tol = 0, reltol = 0;
   int steps = 1, reps = 10, restarts = 100, maxiter = -1, dump = 1, levelmax = -1;
   double rtol_amr = 1e30, ctol_amr = 0;
+  int nomatrix = 0;
   for (int i = 4; i < argc; i++) {
     std::string kv = argv[i];
     auto eq = kv.find('=');
@@ -567,11 +577,15 @@ int main(int argc, char **argv) {
     else if (k == "levelmax") levelmax = atoi(v.c_str());
     else if (k == "rtol") rtol_amr = atof(v.c_str());
     else if (k == "ctol") ctol_amr = atof(v.c_str());
+    else if (k == "nomatrix") nomatrix = atoi(v.c_str());
     else { usage(); return 2; }
   }
   g_n = _BS_ << levelStart;
   const size_t N = (size_t)g_n * g_n;
   hooks.forced_max_iter = maxiter;
+#ifndef HARNESS_HIP_SPMAT
+  hooks.skip_matrix = nomatrix != 0 && (mode == "functors" || mode == "bench" || mode == "dump");
+#endif
 #ifdef HARNESS_HIP_SPMAT
   if (maxiter >= 0) setenv("CUP2D_SPMAT_MAX_ITER", std::to_string(maxiter).c_str(), 1);
 #endif

@@ -74,10 +74,16 @@ class AmrSimulation:
     """Device-resident fields on an adapted grid + the halo-1 block operators in their AMR form.  Fields are set and
     read as per-block arrays (nb, 64) / (nb, 64, 2)."""
 
-    def __init__(self, grid, nu=1e-3, cfl=0.5, device=0):
+    def __init__(self, grid, nu=1e-3, cfl=0.5, device=0, adapt_steps=20):
         self.L = _l.load_library()
         self.grid, self.nu, self.cfl = grid, float(nu), float(cfl)
-        self._strict = getattr(self, "_strict", None)  # arithmetic policy: survives the context rebuild of adapt()
+        self.device = int(device)
+        self.adapt_steps = int(adapt_steps)  # sim.AdaptSteps (main.cpp:6603; run.sh passes 20)
+        self.step_count = getattr(self, "step_count", 0)
+        # settings that survive the context rebuild of adapt(): arithmetic policy, solver organisation, timing
+        self._strict = getattr(self, "_strict", None)
+        self._solver = getattr(self, "_solver", None)
+        self._timing = getattr(self, "_timing", None)
         self._ctx = ctypes.c_void_p()
         vp = ctypes.c_void_p
         _l.check(self.L.cup2d_create(ctypes.byref(self._ctx), grid.nblocks, 0, grid.nblocks,
@@ -86,6 +92,28 @@ class AmrSimulation:
         _l.check(self.L.cup2d_set_amr(self._ctx, grid.h0, *[a.ctypes.data_as(vp) for a in self._tables]), "cup2d_set_amr")
         if self._strict is not None:
             self.set_math(self._strict)
+        if self._solver is not None:
+            self.set_solver(*self._solver)
+        if self._timing is not None:
+            self.set_timing(self._timing)
+
+    def set_solver(self, fused=False, finish_in_kernel=False):
+        self._solver = (bool(fused), bool(finish_in_kernel))
+        _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)), "set_solver")
+
+    def set_timing(self, on=True):
+        self._timing = int(on)
+        _l.check(self.L.cup2d_set_timing(self._ctx, int(on)), "set_timing")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def should_adapt(self):
+        """main.cpp:6603: the reference regrids on every one of the first eleven steps, then every AdaptSteps-th"""
+        return self.step_count <= 10 or self.step_count % self.adapt_steps == 0
 
     def close(self):
         if self._ctx:
@@ -151,8 +179,13 @@ class AmrSimulation:
             d = ctypes.c_double()
             _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol), int(max_restarts), int(max_iter),
                                        ctypes.byref(d), ctypes.byref(it), ctypes.byref(e)), "step")
+            if d.value > 2e-16:  # main.cpp:6596: a vanishing dt advances nothing
+                self.step_count += 1
             return dict(dt=d.value, iters=it.value, err=e.value)
         dt = float(dt)
+        if not dt > 2e-16:
+            return dict(dt=dt, iters=0, err=0.0)
+        self.step_count += 1
         _l.check(self.L.cup2d_advect_diffuse_rk2(self._ctx, self.nu, dt), "advect_diffuse_rk2")
         _l.check(self.L.cup2d_poisson_rhs(self._ctx, dt, 0), "poisson_rhs")
         _l.check(self.L.cup2d_poisson_solve(self._ctx, float(tol), float(rel_tol), int(max_restarts), int(max_iter), ctypes.byref(it),
@@ -164,7 +197,8 @@ class AmrSimulation:
         """The reference's adapt() (main.cpp:4657-5440) for this simulation: tag by max|vorticity| per block (GPU),
         validate the states, prolong / restrict every field on the host (regrid-time work, as in the reference), then
         rebuild the device context on the new grid and re-assemble the Poisson operator.  Returns True if the grid
-        changed."""
+        changed.  The caller decides WHEN (should_adapt() is the reference's rule, main.cpp:6603).  Body-free: the
+        reference also runs GradChiOnTmp on chi before tagging (main.cpp:4660), which only matters with bodies."""
         self.vorticity()
         linf = np.empty(self.grid.nblocks)
         _l.check(self.L.cup2d_block_linf(self._ctx, _l.TMP, _p(linf)), "block_linf")  # one double per block crosses PCIe
@@ -176,10 +210,10 @@ class AmrSimulation:
         names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
         fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
         blocks, data = regrid(self.grid.blocks, st, fields, level_max, self.grid.bpdx, self.grid.bpdy)
-        device = 0
+        new_grid = AmrBlockGrid(blocks, self.grid.bpdx, self.grid.bpdy, self.grid.h0 * max(self.grid.bpdx, self.grid.bpdy) * BS)
         self.close()
-        self.__init__(AmrBlockGrid(blocks, self.grid.bpdx, self.grid.bpdy, self.grid.h0 * max(self.grid.bpdx, self.grid.bpdy) * BS),
-                      nu=self.nu, cfl=self.cfl, device=device)
+        # same device, same settings (the rebuilt context gets policy / solver / timing re-applied by __init__)
+        self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, adapt_steps=self.adapt_steps)
         for k, f in names.items():
             self.set_field(f, data[k])
         self.install_poisson_matrix()

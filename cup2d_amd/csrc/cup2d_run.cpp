@@ -215,7 +215,7 @@ struct AmrRun {
 };
 
 int run_amr(int level_start, int level_max, double rtol, double ctol, int steps, double nu, double cfl, double tol, double tol_rel,
-            int max_restarts, int max_iter, const std::string &init, const std::string &state, int device, int math) {
+            int max_restarts, int max_iter, const std::string &init, const std::string &state, int device, int math, int adapt_steps) {
   AmrRun R;
   R.device = device;
   R.math = math;
@@ -254,7 +254,11 @@ int run_amr(int level_start, int level_max, double rtol, double ctol, int steps,
     double dt = 0, err = 0;
     int iters = 0;
     RUN(cup2d_compute_dt(R.ctx, nu, cfl, &dt));  // before the regrid, as main.cpp:6579-6603 orders them
-    R.adapt(rtol, ctol, level_max);
+    if (!(dt > 2e-16)) {  // main.cpp:6596 skips the body and would spin on the same state for ever: stop instead
+      std::printf("step %d: dt %.3e <= 2e-16, nothing to advance\n", step + 1, dt);
+      break;
+    }
+    if (step <= 10 || step % adapt_steps == 0) R.adapt(rtol, ctol, level_max);  // main.cpp:6603 (sim.AdaptSteps, default 20)
     const bool early = step < 10;
     RUN(cup2d_advect_diffuse_rk2(R.ctx, nu, dt));
     RUN(cup2d_poisson_rhs(R.ctx, dt, 0));
@@ -286,7 +290,7 @@ int run_amr(int level_start, int level_max, double rtol, double ctol, int steps,
 
 int main(int argc, char **argv) {
   int nx = 256, ny = 0, steps = 10, max_restarts = 0, max_iter = 1000, every = 0, device = 0, level_max = 0, level_start = 2;
-  int math = CUP2D_MATH_FAST;
+  int math = CUP2D_MATH_FAST, adapt_steps = 20;  // -AdaptSteps: main.cpp:6603, run.sh passes 20
   double nu = 1e-3, cfl = 0.5, tol = 1e-3, tol_rel = 1e-2, rtol = 2.0, ctol = 0.5;
   std::string init, prefix, state;
   for (int i = 1; i + 1 < argc; i += 2) {
@@ -307,6 +311,7 @@ int main(int argc, char **argv) {
     else if (k == "-device") device = std::atoi(v);
     else if (k == "-levelMax") level_max = std::atoi(v);
     else if (k == "-levelStart") level_start = std::atoi(v);
+    else if (k == "-AdaptSteps") adapt_steps = std::atoi(v);
     else if (k == "-Rtol") rtol = std::atof(v);
     else if (k == "-Ctol") ctol = std::atof(v);
     else if (k == "-state") state = v;
@@ -315,7 +320,9 @@ int main(int argc, char **argv) {
   }
   if (level_max > 0) {
     if (level_start < 0 || level_start >= level_max || level_max > 16) { std::fprintf(stderr, "cup2d_run: 0 <= -levelStart < -levelMax <= 16 expected\n"); return 2; }
-    return run_amr(level_start, level_max, rtol, ctol, steps, nu, cfl, tol, tol_rel, max_restarts, max_iter, init, state, device, math);
+    if (adapt_steps < 1) { std::fprintf(stderr, "cup2d_run: -AdaptSteps >= 1 expected\n"); return 2; }
+    return run_amr(level_start, level_max, rtol, ctol, steps, nu, cfl, tol, tol_rel, max_restarts, max_iter, init, state, device, math,
+                   adapt_steps);
   }
   if (ny == 0) ny = nx;
   if (nx < BS || ny < BS || nx % BS || ny % BS || steps < 0) { std::fprintf(stderr, "cup2d_run: -n / -ny must be positive multiples of 8\n"); return 2; }

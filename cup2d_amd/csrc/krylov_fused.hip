@@ -35,8 +35,19 @@ namespace cup2d {
 constexpr int TB = 16;   // blocks per tile
 constexpr int XS = 66;   // LDS stride of one block in the staging tile: the A-operand reads of a half-wave
                          // (block = lane%16, k = 4ks + lane/16) then fall on 32 distinct 8-byte banks
-constexpr int FWG = 512;         // threads per workgroup of the fused sweeps: 8 waves, ONE workgroup per CU
-constexpr int FWAVES = FWG / 64;
+// Waves per workgroup (ONE workgroup per CU).  8: two waves per SIMD, 256 registers each.  4: one wave per SIMD with the
+// whole 512-entry register file -- room for deeper load schedules without spills, and half as many tiles in flight per
+// XCD (their footprint then fits the 4 MiB L2 the ring re-reads have to hit).  CUP2D_FUSED_PREG 1: P_inv fragments in
+// registers (128 VGPRs; sensible only with 4 waves) instead of 32 KiB of LDS.
+#ifndef CUP2D_FUSED_WAVES
+#define CUP2D_FUSED_WAVES 8
+#endif
+#ifndef CUP2D_FUSED_PREG
+#define CUP2D_FUSED_PREG 0
+#endif
+constexpr int FWAVES = CUP2D_FUSED_WAVES;
+constexpr int FWG = 64 * FWAVES;  // threads per workgroup of the fused sweeps
+constexpr bool PREG = CUP2D_FUSED_PREG != 0;
 // Cache policy of the individual streams of an iteration (bit set = non-temporal access).  An iteration moves ~20
 // vectors of 134 MB (4096^2) through a 256 MB memory-side cache and 8 x 4 MiB of L2: left alone, everything evicts
 // everything.  Policy: a stream that is consumed once, or whose consumer is a whole iteration away, bypasses
@@ -106,7 +117,8 @@ struct FusedLds {
   int ring_nb[TB * 4];     // neighbour block of ring entry e ...
   int ring_dst[TB * 4];    // ... and the slot (block * 4 + side) it feeds
 };
-constexpr size_t FUSED_LDS_BYTES = PL_DOUBLES * sizeof(double) + FWAVES * sizeof(FusedLds);
+constexpr int PL_LDS_DOUBLES = PREG ? 0 : PL_DOUBLES;
+constexpr size_t FUSED_LDS_BYTES = PL_LDS_DOUBLES * sizeof(double) + FWAVES * sizeof(FusedLds);
 
 // cell (iy*8+ix) at position q of the edge on side s (W, E, S, N) of a block
 static __device__ __forceinline__ int edge_cell(int s, int q) {
@@ -118,7 +130,7 @@ static __device__ __forceinline__ int edge_cell(int s, int q) {
 // registers they cost every wave 128 VGPRs -- the first version of this kernel had nothing left to keep
 // loads in flight with (2 waves per SIMD, 234 VGPRs) and ran latency-bound at 3.3 TB/s.  Same k order and
 // operands as precond_tile, so z is bit-identical to the unfused MFMA preconditioner.
-static __device__ __forceinline__ void tile_precond(double *S, const double *PL, int lane, bool skip) {
+static __device__ __forceinline__ void tile_precond(double *S, const double *PL, const PinvFragments &PR, int lane, bool skip) {
   double xa[16];
   const int ablk = lane & 15, akk = lane >> 4;
 #pragma unroll
@@ -131,7 +143,7 @@ static __device__ __forceinline__ void tile_precond(double *S, const double *PL,
     for (int ks = 0; ks < 16; ks++)
 #pragma unroll
       for (int nt = 0; nt < 4; nt++)
-        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PREG ? PR.b[ks][nt] : PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
   }
   wave_lds_sync();  // every lane has read its operands before the tile is overwritten
 #pragma unroll
@@ -188,13 +200,18 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
   constexpr bool WLATE = MODE == 0 && CUP2D_FUSED_WLATE != 0;
   double *PL = fsm;
-  for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
-    const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
-    PL[idx] = Pinv[(4 * ks + (l >> 4)) * BC + 16 * nt + (l & 15)];
+  PinvFragments PR;
+  if constexpr (PREG) {
+    PR.load(Pinv, threadIdx.x & 63);
+  } else {
+    for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
+      const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
+      PL[idx] = Pinv[(4 * ks + (l >> 4)) * BC + 16 * nt + (l & 15)];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  FusedLds &L = reinterpret_cast<FusedLds *>(fsm + PL_DOUBLES)[wave];
+  FusedLds &L = reinterpret_cast<FusedLds *>(fsm + PL_LDS_DOUBLES)[wave];
   const int ix = lane & 7, iy = lane >> 3;
   const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
   const double beta = sc->beta;
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       } else {
         wave_lds_sync();
       }
-      tile_precond(L.S, PL, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      tile_precond(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
       if (!is_tile) {
         // entry e feeds slot dst = block*4 + side with the OPPOSITE edge of the neighbour block
         const int ne = min(TB, T.nring - j * TB);

@@ -21,6 +21,9 @@ class Simulation:
         self.h = float(h) if h is not None else float(extent) / max(g.nbx, g.nby) / 8
         self.nu, self.cfl = float(nu), float(cfl)
         self.time, self.step_count, self.dt = 0.0, 0, 0.0
+        # sim.PoissonTol / PoissonTolRel / maxPoissonRestarts (command-line options without defaults, main.cpp:6333-6335;
+        # these are the values the reference's run.sh passes): used from the eleventh step on (main.cpp:7028-7030)
+        self.poisson_tol, self.poisson_tol_rel, self.max_poisson_restarts = 1e-3, 1e-2, 0
         self._ctx = ctypes.c_void_p()
         _l.check(self.L.cup2d_create(ctypes.byref(self._ctx), g.nblocks, g.nghost, g.n_inner,
                                      g.nbr.ctypes.data_as(ctypes.c_void_p), self.h, int(device)), "cup2d_create")
@@ -216,17 +219,23 @@ class Simulation:
         return e.value
 
     def step(self, tol=None, rel_tol=None, max_restarts=None, max_iter=1000):
-        """One pass of the time-loop body.  Like main.cpp:7028-7030 the first ten steps run the
-        solver with zero tolerances unless tolerances are given explicitly."""
+        """One pass of the time-loop body.  Without explicit tolerances the reference's rule applies
+        (main.cpp:7028-7030): steps 0..9 solve with zero tolerances and up to 100 restarts, later steps with
+        poisson_tol / poisson_tol_rel / max_poisson_restarts.  Explicit arguments override it (max_restarts then
+        defaults to the reference's 0).  A vanishing dt advances nothing (main.cpp:6596)."""
         if tol is None:
-            tol, rel_tol, max_restarts = 0.0, 0.0, 100
+            early = self.step_count < 10
+            tol = 0.0 if early else self.poisson_tol
+            rel_tol = 0.0 if early else self.poisson_tol_rel
+            max_restarts = 100 if early else self.max_poisson_restarts
         dt, it, e = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
         _l.check(self.L.cup2d_step(self._ctx, self.nu, self.cfl, float(tol), float(rel_tol or 0.0),
-                                   int(100 if max_restarts is None else max_restarts), int(max_iter),
+                                   int(0 if max_restarts is None else max_restarts), int(max_iter),
                                    ctypes.byref(dt), ctypes.byref(it), ctypes.byref(e)), "step")
         self.dt = dt.value
-        self.time += self.dt
-        self.step_count += 1
+        if self.dt > 2e-16:
+            self.time += self.dt
+            self.step_count += 1
         return dict(dt=dt.value, iters=it.value, err=e.value)
 
     # ---- output ----------------------------------------------------------------------------------

@@ -251,8 +251,17 @@ def have_reference_hip():
     return os.path.exists(REF_HARNESS_HIP) and os.access(REF_HARNESS_HIP, os.X_OK)
 
 
-def _run_ref(mode, n, d, _threads=None, _timeout=None, _hip=False, _env=None, **kw):
-    cmd = [REF_HARNESS_HIP if _hip else REF_HARNESS, mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
+# the reference's main.cpp with its block-operator call sites replaced by this repository's C ABI (oracle/b2_patch.py):
+# seam B2 compiled (needs a GPU)
+REF_HARNESS_B2 = os.path.join(_HERE, "_ref", "ref_harness_b2")
+
+
+def have_reference_b2():
+    return os.path.exists(REF_HARNESS_B2) and os.access(REF_HARNESS_B2, os.X_OK)
+
+
+def _run_ref(mode, n, d, _threads=None, _timeout=None, _hip=False, _env=None, _b2=False, **kw):
+    cmd = [REF_HARNESS_B2 if _b2 else (REF_HARNESS_HIP if _hip else REF_HARNESS), mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
     env = dict(os.environ)
     if _threads:
         env.update(OMP_NUM_THREADS=str(int(_threads)), OMP_PROC_BIND="close", OMP_PLACES="cores")
@@ -389,9 +398,12 @@ def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None,
     return x, ax0, dict(iters=int(s[0]), err=s[1], err_init=s[2], restarts=int(s[3]), seconds=s[4])
 
 
-def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None, hip=False, env=None):
+def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None, hip=False, env=None,
+            b2=False):
     """The reference's own time loop (main.cpp:6576-7290) from the IC vel0 for `steps` steps.
-    hip=True: with sim.mat served by libcup2d_spmat.so (GPU) instead of the CPU restatement."""
+    hip=True: with sim.mat served by libcup2d_spmat.so (GPU) instead of the CPU restatement (seam B1).
+    b2=True: the loop of oracle/_ref/ref_harness_b2 -- every block-operator call site and the solve go through
+    include/cup2d_hip.h on the GPU (seam B2)."""
     vel0 = _c(vel0)
     n = vel0.shape[0]
     d = keep or tempfile.mkdtemp()
@@ -399,7 +411,7 @@ def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, ma
     kw = dict(nu=float(nu), cfl=float(cfl), steps=int(steps), tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
     if max_iter is not None:
         kw["maxiter"] = int(max_iter)
-    _run_ref("run", n, d, _hip=hip, _env=env, **kw)
+    _run_ref("run", n, d, _hip=hip, _env=env, _b2=b2, **kw)
     out = dict(vel=np.fromfile(os.path.join(d, "vel.final")).reshape(n, n, 2),
                pres=np.fromfile(os.path.join(d, "pres.final")).reshape(n, n), steps=[])
     meta = open(os.path.join(d, "meta.txt")).read().strip().split("\n")

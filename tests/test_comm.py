@@ -1,0 +1,130 @@
+"""The communicator inside the library (csrc/comm.hip, cup2d_comm_*).
+
+CPU  : the C ABI validates its arguments and reports a missing GPU / RCCL as CUP2D_ERR_COMM (no crash, no fallback).
+GPU  : (a) RCCL send/recv with real buffers, offsets and streams on ONE rank: the rank is its own W and E neighbour
+           (ncclSend / ncclRecv to self inside one group), i.e. a domain periodic in x -- the ghost strips must be the
+           opposite edge's cells, bit for bit, for the WENO halo (3 layers, 2 components), a scalar width-1 halo and whole
+           ghost blocks;
+       (b) a one-rank decomposition through the whole communicator path (comm stream, events, all-reduce, the
+           sum+max all-gather) gives the step the plain single-GPU context gives, bit for bit.
+The N > 1 arithmetic (ghost blocks, overlapped sweeps, reductions) is covered by tests/test_distributed.py with the
+callback transport (gloo): two ranks cannot share one GPU under RCCL.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from cup2d_amd import lib as L
+from cup2d_amd.grid import BlockGrid
+
+
+def test_comm_argument_checks_without_a_gpu():
+    lib = L.load_library()
+    vp = ctypes.c_void_p
+    assert lib.cup2d_comm_unique_id(None) == -1  # CUP2D_ERR_ARG
+    ids = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+    one = (ctypes.c_int32 * 1)(0)
+    assert lib.cup2d_comm_init(None, 1, 0, ids, 0, None, None, None, None) == -1  # null context
+    assert b"null context" in lib.cup2d_last_error()
+    assert lib.cup2d_comm_finalize(None) == -1
+    assert lib.cup2d_halo_exchange(None, L.VEL, 3) == -1
+    assert lib.cup2d_comm_stats(None, None, None, None, None, None) == -1
+    del vp, one
+
+
+def _hip():
+    h = ctypes.CDLL("libamdhip64.so")
+    h.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return h
+
+
+def _self_periodic_sim(nbx, nby):
+    """one rank that is its own W and E neighbour: ghost blocks on both x sides, each filled from the opposite edge"""
+    import cup2d_amd
+    g = BlockGrid(nbx, nby, ghost_sides=(True, True, False, False))
+    s = cup2d_amd.Simulation(nbx, nby, grid=g, h=1.0 / (8 * nbx))
+    sb, sf, rb, rf = [], [], [], []
+    for side in (0, 1):  # W strips then E strips in the send list; W ghosts then E ghosts in the receive list
+        for pos in range(nby):
+            sb.append(int(g.index_of[pos, 0 if side == 0 else nbx - 1]))
+            sf.append(side)
+            rb.append(int(g._ghost_id[(side, pos)]))
+            rf.append(1 - side)
+    arr = [np.asarray(a, dtype=np.int32) for a in (sb, sf, rb, rf)]
+    vp = ctypes.c_void_p
+    L.check(s.L.cup2d_halo_plan(s.ctx, len(sb), arr[0].ctypes.data_as(vp), arr[1].ctypes.data_as(vp), len(rb),
+                                arr[2].ctypes.data_as(vp), arr[3].ctypes.data_as(vp)), "halo_plan")
+    ids = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+    L.check(s.L.cup2d_comm_unique_id(ids), "comm_unique_id")
+    # receive i pairs with send i (RCCL matches the operations of a pair of ranks in issue order): the W ghosts
+    # (receive offset 0) take the E strips (send offset nby), the E ghosts the W strips
+    peer = np.zeros(2, dtype=np.int32)
+    soff = np.asarray([nby, 0], dtype=np.int32)
+    roff = np.asarray([0, nby], dtype=np.int32)
+    cnt = np.asarray([nby, nby], dtype=np.int32)
+    L.check(s.L.cup2d_comm_init(s.ctx, 1, 0, ids, 2, peer.ctypes.data_as(vp), soff.ctypes.data_as(vp), roff.ctypes.data_as(vp),
+                                cnt.ctypes.data_as(vp)), "comm_init")
+    return s, g
+
+
+@pytest.mark.gpu
+def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib):
+    from cup2d_amd.distributed import strip_cells
+    nbx, nby = 6, 5
+    s, g = _self_periodic_sim(nbx, nby)
+    hip = _hip()
+    rng = np.random.default_rng(3)
+    with s:
+        for field, dim, width in ((L.VEL, 2, 3), (L.PRES, 1, 1), (L.TMP, 1, 8)):
+            a = rng.uniform(-1, 1, (g.ny, g.nx, dim) if dim > 1 else (g.ny, g.nx))
+            s.set_field(field, a)
+            L.check(s.L.cup2d_halo_exchange(s.ctx, field, width), "halo_exchange")
+            s.synchronize()
+            slab = np.zeros((g.nblocks + g.nghost, 64, dim))
+            assert hip.hipMemcpy(slab.ctypes.data, s.field_ptr(field), slab.nbytes, 2) == 0
+            owned = g.to_blocks(a).reshape(g.nblocks, 64, dim)
+            assert np.array_equal(slab[:g.nblocks], owned)
+            for gi, (side, pos) in enumerate(g.ghost_coords):
+                src = owned[g.index_of[pos, nbx - 1 if side == 0 else 0]]  # periodic: the opposite edge's block
+                cells = strip_cells(1 - side, width)
+                assert np.array_equal(slab[g.nblocks + gi, cells], src[cells]), (field, side, pos)
+        st = {}
+        n, p, e, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+        L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(e), ctypes.byref(ar), ctypes.byref(ag)), "stats")
+        st = dict(nranks=n.value, peers=p.value, exchanges=e.value)
+        assert st == dict(nranks=1, peers=2, exchanges=3)
+        L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_one_rank_through_the_communicator_equals_the_plain_context(gpu_lib, oracle, fused, tmp_path):
+    """world = 1 under torch.distributed (gloo carries the token): every reduction goes through ncclAllReduce /
+    ncclAllGather on the compute stream, the solver runs its N-rank organisation (MERGE 2 + scalar kernels)."""
+    import os
+    import torch.distributed as dist
+    import cup2d_amd
+    from cup2d_amd.distributed import DistributedSimulation
+    n = 256
+    vel = oracle.taylor_green(n)
+    with cup2d_amd.Simulation(n // 8, nu=1e-3) as s:
+        s.set_solver(fused=fused, finish_in_kernel=True)
+        s.vel = vel
+        r0 = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=30)
+        v0, p0 = s.vel, s.pres
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        with DistributedSimulation(n // 8, n // 8, 1, 1, nu=1e-3, comm="rccl") as d:
+            d.set_solver(fused=fused, finish_in_kernel=True)
+            d.vel = vel
+            r1 = d.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=30)
+            st = d.comm_stats()
+            assert r1["dt"] == r0["dt"] and r1["iters"] == r0["iters"] == 30
+            assert np.array_equal(d.vel, v0) and np.array_equal(d.pres, p0)
+            assert r1["err"] == r0["err"]
+            # per iteration: AB 1 all-reduce, CD 1 all-reduce, E one all-gather (sum, sum, max)
+            assert st["nranks"] == 1 and st["peers"] == 0 and st["allgathers"] >= 30 and st["allreduces"] >= 60
+    finally:
+        dist.destroy_process_group()

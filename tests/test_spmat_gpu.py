@@ -165,3 +165,36 @@ def test_spmat_ranks_share_the_gpu(gpu_lib, ranks, env):
     assert out.returncode == 0 and "SOLVE_OK" in out.stdout, out.stdout + out.stderr
     structured = ranks == 1 and not env
     assert ("structured %d" % int(structured)) in out.stdout
+
+
+def test_b2_call_sites_compiled_into_the_reference_loop(gpu_lib, oracle):
+    """Seam B2 proven by compiling it: oracle/_ref/ref_harness_b2 is the reference's main.cpp with the call sites
+    INTEGRATION.md lists (main.cpp:4659, 6611-6642, 7003-7027, 7031-7119, 7120-7187) replaced by cup2d_* calls
+    (oracle/b2_patch.py).  Three steps from the golden initial condition must land on the golden state, which the
+    unpatched reference produced."""
+    assert oracle.have_reference_b2(), "oracle/_ref/ref_harness_b2 was not shipped (make -C oracle ref_b2)"
+    G = golden("run_n32_3steps.npz")
+    R = oracle.ref_run(G["vel0"], float(G["nu"]), steps=3, tol=1e-11, rel_tol=0.0, max_restarts=100, b2=True)
+    assert np.allclose([s["dt"] for s in R["steps"]], G["dts"], rtol=1e-12, atol=0)
+    assert np.abs(R["vel"] - G["vel"]).max() < 1e-10
+    assert np.abs(R["pres"] - G["pres"]).max() < 1e-8
+    for k in range(3):
+        assert np.abs(R["steps"][k]["b"] - G["b"][k]).max() < 1e-9
+    # STRICT arithmetic behind the seam: the first step's advected velocity and right-hand side are bit-identical
+    assert np.array_equal(R["steps"][0]["vel_adv"], G["vel_adv"][0])
+    assert np.array_equal(R["steps"][0]["b"], G["b"][0])
+
+
+def test_b2_loop_at_2048_equals_the_unpatched_reference(gpu_lib, oracle):
+    """one 2048^2 step (BASELINE.json configs[1]'s grid) of the patched loop against the unpatched harness, both solvers
+    capped at 50 iterations: advected velocity and Poisson right-hand side bit for bit, state after the step 1e-9 / 1e-8"""
+    assert oracle.have_reference_b2() and oracle.have_reference()
+    n, nu = 2048, 1e-3
+    vel0 = oracle.taylor_green(n)
+    kw = dict(steps=1, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=50)
+    A = oracle.ref_run(vel0, nu, **kw)
+    B = oracle.ref_run(vel0, nu, b2=True, **kw)
+    assert A["steps"][0]["dt"] == B["steps"][0]["dt"]
+    assert np.array_equal(A["steps"][0]["vel_adv"], B["steps"][0]["vel_adv"])
+    assert np.array_equal(A["steps"][0]["b"], B["steps"][0]["b"])
+    assert np.abs(A["vel"] - B["vel"]).max() <= 1e-9 and np.abs(A["pres"] - B["pres"]).max() <= 1e-8

@@ -82,13 +82,6 @@ constexpr unsigned POL = CUP2D_POLICY;
 #ifndef CUP2D_FUSED_DEEP
 #define CUP2D_FUSED_DEEP 2
 #endif
-// CUP2D_FUSED_WLATE 1: AB reads rhat in the stencil loop, four blocks ahead, instead of holding 16 values per lane across
-// the MFMA (220 VGPRs instead of 255, and schedule 1 then fits: 2 spills).  Measured: AB 194 -> 199 us (WLATE), 204 us
-// (WLATE + schedule 1) -- AB is bound by the L2-miss traffic its ring re-reads add, not by requests in
-// flight.  Off.
-#ifndef CUP2D_FUSED_WLATE
-#define CUP2D_FUSED_WLATE 0
-#endif
 typedef double v2d __attribute__((ext_vector_type(2)));
 template <bool NT>
 static __device__ __forceinline__ double2 ld2(const double2 *p) {
@@ -111,7 +104,7 @@ static __device__ __forceinline__ void st2(double2 *p, double2 v) {
 }  // 
 constexpr int PL_DOUBLES = 16 * 4 * 64;  // P_inv as MFMA B fragments: [k-step][n-tile][lane]
 
-struct FusedLds {
+struct alignas(16) FusedLds {
   double S[TB * XS];       // v of 16 blocks, then (same storage) z of those blocks
   double GE[TB * 4 * BS];  // z on the ghost edges of the tile's blocks: [block][W,E,S,N][position]
   int ring_nb[TB * 4];     // neighbour block of ring entry e ...
@@ -187,6 +180,12 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 // is two batches of 8 blocks.  The global loads of a batch are issued one batch ahead of their use, across
 // job boundaries, so a wave always has 8 blocks x {3|2} vectors in flight while it stages, multiplies,
 // gathers; the w operand of the dot product (rhat) is requested before the tile's MFMA.
+//
+// Every global access is 16 bytes per lane: a wave instruction moves TWO blocks (lanes 0-31 the cell pairs of one,
+// lanes 32-63 those of the next), staging writes and the stencil's reads are ds_*_b128 on the same pairs.  With 8-byte
+// accesses (one cell per lane) both sweeps sat at the rate the vector memory path sustains for 8-byte requests
+// (5.4-6.1 TB/s of L2-side traffic, ring re-reads included; SQ_WAIT_INST_ANY 44 %: issue stalled behind a full memory
+// pipeline) although HBM had room; 16-byte requests halve the instructions per byte.
 template <int MODE, int MERGE>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
@@ -195,10 +194,9 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
                                                   int dbg) {
   // blocks [first, first + count) of the nowned owned blocks; neighbour ids >= nowned are ghost blocks whose z
   // edges were computed by their owner rank (k_fused_edges) and unpacked into zg
-  extern __shared__ double fsm[];
+  extern __shared__ __attribute__((aligned(16))) double fsm[];
   if (sc->status != 0) return;
   constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
-  constexpr bool WLATE = MODE == 0 && CUP2D_FUSED_WLATE != 0;
   double *PL = fsm;
   PinvFragments PR;
   if constexpr (PREG) {
@@ -212,7 +210,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   }
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FusedLds &L = reinterpret_cast<FusedLds *>(fsm + PL_LDS_DOUBLES)[wave];
-  const int ix = lane & 7, iy = lane >> 3;
+  // pair layout of the 16-byte accesses: this lane holds cells c0 = 2 hl, c0 + 1 of block 2 i + hf
+  const int hf = lane >> 5, hl = lane & 31, c0 = 2 * hl, px = c0 & 7, py = hl >> 2;
   const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
   const double beta = sc->beta;
   const bool restart = MODE == 0 && sc->restart_flag != 0;
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
   for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
 
-  // v at this lane's cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
+  // v at one cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
   const auto form_v = [&](double a, double b, double c) -> double {
     if (MODE == 0) {
       if (restart) return c;
@@ -231,8 +230,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
     return a + c1 * b;
   };
-  struct Raw {
-    double a[8], b[8], c[8];
+  struct Raw {  // one batch = 8 blocks = 4 block pairs
+    double2 a[4], b[4], c[4];
   };
 
   // tiles of 16 blocks over the waves of the persistent grid, contiguous per XCD (workgroup w runs on XCD w % 8)
@@ -282,41 +281,43 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     wave_lds_sync();
     return T;
   };
-  // blocks of the 8 entries of batch `half` of job j of tile T -- ring entries, or for the last job blocks of
-  // the tile -- branch-free (the ring list is read even when it is not used), so that the 8 x {3|2} loads
-  // issue back to back
+  // the 4 block pairs of batch `half` of job j of tile T -- ring entries, or for the last job blocks of the tile --
+  // branch-free (the ring list is read even when it is not used), so that the 4 x {3|2} loads issue back to back
   const auto issue = [&](Raw &R, const Tile &T, int j, int half) {
     const bool tile_job = j >= T.npass;
     const int ne = max(1, min(TB, T.nring - j * TB));
-    int blk[8];
+    size_t off[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const int idx = 8 * half + e;
+    for (int p = 0; p < 4; p++) {
+      const int idx = 8 * half + 2 * p + hf;  // per half-wave
       const int rb = L.ring_nb[min(j * TB + min(idx, ne - 1), TB * 4 - 1)];
-      blk[e] = tile_job ? T.b0 + min(idx, T.nvalid - 1) : rb;
+      const int blk = tile_job ? T.b0 + min(idx, T.nvalid - 1) : rb;
+      off[p] = ((size_t)blk * BC + c0) >> 1;  // in double2 units
     }
+    const double2 *in0 = reinterpret_cast<const double2 *>(A.in0), *in1 = reinterpret_cast<const double2 *>(A.in1);
+    const double2 *in2 = reinterpret_cast<const double2 *>(A.in2);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const size_t o = (size_t)uniform(blk[e]) * BC + lane;
+    for (int p = 0; p < 4; p++) {
+      const size_t o = off[p];
       if (!tile_job && (POL & 0x20000)) {  // ring loads only
-        R.a[e] = __builtin_nontemporal_load(A.in0 + o);
-        R.b[e] = __builtin_nontemporal_load(A.in1 + o);
-        if (MODE == 0) R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+        R.a[p] = ld2<true>(in0 + o);
+        R.b[p] = ld2<true>(in1 + o);
+        if (MODE == 0) R.c[p] = ld2<true>(in2 + o);
       } else if (MODE == 0 && (POL & 0x4000)) {
-        R.a[e] = __builtin_nontemporal_load(A.in0 + o);
-        R.b[e] = __builtin_nontemporal_load(A.in1 + o);
-        R.c[e] = __builtin_nontemporal_load(A.in2 + o);
+        R.a[p] = ld2<true>(in0 + o);
+        R.b[p] = ld2<true>(in1 + o);
+        R.c[p] = ld2<true>(in2 + o);
       } else if (MODE == 1 && (POL & 0x18000)) {
-        R.a[e] = (POL & 0x8000) ? __builtin_nontemporal_load(A.in0 + o) : A.in0[o];
-        R.b[e] = (POL & 0x10000) ? __builtin_nontemporal_load(A.in1 + o) : A.in1[o];
+        R.a[p] = ld2<(POL & 0x8000) != 0>(in0 + o);
+        R.b[p] = ld2<(POL & 0x10000) != 0>(in1 + o);
       } else if (MODE == 0 && tile_job && (POL & 0x3000)) {
-        R.a[e] = (POL & 0x1000) ? __builtin_nontemporal_load(A.in0 + o) : A.in0[o];
-        R.b[e] = (POL & 0x2000) ? __builtin_nontemporal_load(A.in1 + o) : A.in1[o];
-        R.c[e] = A.in2[o];
+        R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
+        R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
+        R.c[p] = in2[o];
       } else {
-        R.a[e] = A.in0[o];
-        R.b[e] = A.in1[o];
-        if (MODE == 0) R.c[e] = A.in2[o];
+        R.a[p] = in0[o];
+        R.b[p] = in1[o];
+        if (MODE == 0) R.c[p] = in2[o];
       }
     }
   };
@@ -336,23 +337,23 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = 0.0;
     }
-    // dot-product operand of the tile's cells: s itself (CD); rhat (AB; r on a restart) -- with WLATE not held in
-    // registers across the MFMA but read in the stencil loop, four blocks ahead
-    double W[WLATE ? 1 : TB];
+    // dot-product operand of the tile's cells in pair layout: s itself (CD); rhat (AB; r on a restart)
+    double2 W[TB / 2];
     const auto stage = [&](const Raw &R, bool is_tile, int half) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int idx = 8 * half + e;
-        const double v = form_v(R.a[e], R.b[e], MODE == 0 ? R.c[e] : 0.0);
-        L.S[idx * XS + lane] = v;
+      for (int p = 0; p < 4; p++) {
+        const int idx = 8 * half + 2 * p + hf;
+        double2 v;
+        v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
+        v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
+        *reinterpret_cast<double2 *>(L.S + idx * XS + c0) = v;
         if (is_tile) {
-          if (MODE == 1) W[idx] = v;
-          if (MODE == 0 && restart && !WLATE) W[idx] = R.c[e];
+          if (MODE == 1) W[4 * half + p] = v;
+          if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
           if (idx < nvalid) {
-            const size_t o = (size_t)(b0 + idx) * BC + lane;
-            if (POL & (MODE == 0 ? 0x001 : 0x004)) __builtin_nontemporal_store(v, A.vout + o);
-            else A.vout[o] = v;
-            if (MODE == 0 && restart) A.w[o] = R.c[e];  // rhat = r
+            const size_t o = ((size_t)(b0 + idx) * BC + c0) >> 1;
+            st2<(POL & (MODE == 0 ? 0x001 : 0x004)) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
+            if (MODE == 0 && restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
           }
         }
       }
@@ -366,11 +367,11 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       if (!is_tile) {
         issue(Ra, T, j + 1, 0);
         if (DEEP) issue(Rb, T, j + 1, 1);
-      } else if (MODE == 0 && !restart && !WLATE) {
+      } else if (MODE == 0 && !restart) {
 #pragma unroll
-        for (int i = 0; i < TB; i++) {
-          const double *pw = A.w + (size_t)(b0 + min(i, nvalid - 1)) * BC + lane;
-          W[i] = (POL & 0x800) ? __builtin_nontemporal_load(pw) : *pw;
+        for (int i = 0; i < TB / 2; i++) {
+          const double2 *pw = reinterpret_cast<const double2 *>(A.w) + (((size_t)(b0 + min(2 * i + hf, nvalid - 1)) * BC + c0) >> 1);
+          W[i] = ld2<(POL & 0x800) != 0>(pw);
         }
       }
       if (!DEEP) stage(Rb, is_tile, 1);
@@ -413,41 +414,29 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       }
     }
     wave_lds_sync();
-    // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products ----
-    constexpr int LA = 4;
-    double wq[LA];
-    const double *wsrc = nullptr;
-    const auto wload = [&](int i) -> double {
-      const double *pw = wsrc + (size_t)min(i, nvalid - 1) * BC;
-      return (POL & 0x800) ? __builtin_nontemporal_load(pw) : *pw;
-    };
-    if constexpr (WLATE) {
-      wsrc = (restart ? A.in2 : A.w) + (size_t)b0 * BC + lane;  // restart: rhat = r (cuda.cu:461-476)
+    // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products: two cells per
+    //      lane, eight block pairs ----
 #pragma unroll
-      for (int k = 0; k < LA; k++) wq[k] = wload(k);
-    }
-#pragma unroll
-    for (int i = 0; i < TB; i++) {
-      double wv;
-      if constexpr (WLATE) {
-        wv = wq[i % LA];
-        if (i + LA < TB) wq[i % LA] = wload(i + LA);
-      } else {
-        wv = W[i];
-      }
-      if (i < nvalid) {
-        const double *zb = L.S + i * XS + lane;
-        const double *ge = L.GE + i * 4 * BS;
-        const double l0 = zb[0];
-        const double l1 = *(ix > 0 ? zb - 1 : ge + 0 * BS + iy);
-        const double l2 = *(ix < BS - 1 ? zb + 1 : ge + 1 * BS + iy);
-        const double l3 = *(iy > 0 ? zb - BS : ge + 2 * BS + ix);
-        const double l4 = *(iy < BS - 1 ? zb + BS : ge + 3 * BS + ix);
-        const double yv = l1 + l2 + l3 + l4 - 4 * l0;
-        if (POL & (MODE == 0 ? 0x002 : 0x008)) __builtin_nontemporal_store(yv, A.yout + (size_t)(b0 + i) * BC + lane);
-        else A.yout[(size_t)(b0 + i) * BC + lane] = yv;
-        acc[0] = __builtin_fma(yv, wv, acc[0]);
-        if constexpr (NDOT == 2) acc[1] = __builtin_fma(yv, yv, acc[1]);
+    for (int i = 0; i < TB / 2; i++) {
+      const int blk = 2 * i + hf;
+      if (blk < nvalid) {
+        const double *zb = L.S + blk * XS + c0;
+        const double *ge = L.GE + blk * 4 * BS;
+        const double2 zc = *reinterpret_cast<const double2 *>(zb);
+        const double lw = *(px > 0 ? zb - 1 : ge + 0 * BS + py);           // west of cell c0
+        const double le = *(px < BS - 2 ? zb + 2 : ge + 1 * BS + py);      // east of cell c0 + 1
+        const double2 ls = *reinterpret_cast<const double2 *>(py > 0 ? zb - BS : ge + 2 * BS + px);
+        const double2 ln = *reinterpret_cast<const double2 *>(py < BS - 1 ? zb + BS : ge + 3 * BS + px);
+        double2 yv;
+        yv.x = lw + zc.y + ls.x + ln.x - 4 * zc.x;
+        yv.y = zc.x + le + ls.y + ln.y - 4 * zc.y;
+        st2<(POL & (MODE == 0 ? 0x002 : 0x008)) != 0>(reinterpret_cast<double2 *>(A.yout) + (((size_t)(b0 + blk) * BC + c0) >> 1), yv);
+        acc[0] = __builtin_fma(yv.x, W[i].x, acc[0]);
+        acc[0] = __builtin_fma(yv.y, W[i].y, acc[0]);
+        if constexpr (NDOT == 2) {
+          acc[1] = __builtin_fma(yv.x, yv.x, acc[1]);
+          acc[1] = __builtin_fma(yv.y, yv.y, acc[1]);
+        }
       }
     }
     wave_lds_sync();  // the next tile overwrites S and GE

@@ -104,9 +104,12 @@ static __device__ __forceinline__ void st2(double2 *p, double2 v) {
 }  // 
 constexpr int PL_DOUBLES = 16 * 4 * 64;  // P_inv as MFMA B fragments: [k-step][n-tile][lane]
 
+constexpr int GS = 10;   // doubles per (block, side) slot of GE: 8 used; with stride 8 the 64 lanes that each fill one slot hit
+                         // 4 banks (8-way conflicts, 7 M conflict cycles per launch); 10 is even (the stencil reads pairs with
+                         // ds_read_b128) and leaves 2-way
 struct alignas(16) FusedLds {
   double S[TB * XS];       // v of 16 blocks, then (same storage) z of those blocks
-  double GE[TB * 4 * BS];  // z on the ghost edges of the tile's blocks: [block][W,E,S,N][position]
+  double GE[TB * 4 * GS];  // z on the ghost edges of the tile's blocks: [block][W,E,S,N][position], slot stride GS
   int ring_nb[TB * 4];     // neighbour block of ring entry e ...
   int ring_dst[TB * 4];    // ... and the slot (block * 4 + side) it feeds
 };
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     const int b0 = T.b0, nvalid = T.nvalid;
     if (dbg & 1) {
 #pragma unroll
-      for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = 0.0;
+      for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = 0.0;
     }
     // dot-product operand of the tile's cells in pair layout: s itself (CD); rhat (AB; r on a restart)
     double2 W[TB / 2];
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
           if (e < ne) {
             const int dst = L.ring_dst[j * TB + e];
-            L.GE[dst * BS + q] = L.S[e * XS + edge_cell((dst & 3) ^ 1, q)];
+            L.GE[dst * GS + q] = L.S[e * XS + edge_cell((dst & 3) ^ 1, q)];
           }
         }
         wave_lds_sync();
@@ -406,11 +409,11 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       if (T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
         const double *g = zg + (size_t)T.nb * BC;
 #pragma unroll
-        for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = g[edge_cell(ss ^ 1, q)];
+        for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = g[edge_cell(ss ^ 1, q)];
       } else {
         const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
 #pragma unroll
-        for (int q = 0; q < BS; q++) L.GE[lane * BS + q] = L.S[sblk * XS + edge_cell(sside, q)];
+        for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + edge_cell(sside, q)];
       }
     }
     wave_lds_sync();
@@ -421,12 +424,12 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       const int blk = 2 * i + hf;
       if (blk < nvalid) {
         const double *zb = L.S + blk * XS + c0;
-        const double *ge = L.GE + blk * 4 * BS;
+        const double *ge = L.GE + blk * 4 * GS;
         const double2 zc = *reinterpret_cast<const double2 *>(zb);
-        const double lw = *(px > 0 ? zb - 1 : ge + 0 * BS + py);           // west of cell c0
-        const double le = *(px < BS - 2 ? zb + 2 : ge + 1 * BS + py);      // east of cell c0 + 1
-        const double2 ls = *reinterpret_cast<const double2 *>(py > 0 ? zb - BS : ge + 2 * BS + px);
-        const double2 ln = *reinterpret_cast<const double2 *>(py < BS - 1 ? zb + BS : ge + 3 * BS + px);
+        const double lw = *(px > 0 ? zb - 1 : ge + 0 * GS + py);           // west of cell c0
+        const double le = *(px < BS - 2 ? zb + 2 : ge + 1 * GS + py);      // east of cell c0 + 1
+        const double2 ls = *reinterpret_cast<const double2 *>(py > 0 ? zb - BS : ge + 2 * GS + px);
+        const double2 ln = *reinterpret_cast<const double2 *>(py < BS - 1 ? zb + BS : ge + 3 * GS + px);
         double2 yv;
         yv.x = lw + zc.y + ls.x + ln.x - 4 * zc.x;
         yv.y = zc.x + le + ls.y + ln.y - 4 * zc.y;

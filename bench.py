@@ -207,6 +207,11 @@ def main():
     import torch
     from cup2d_amd import lib as L
 
+    # one node: rendezvous sockets (gloo, RCCL's bootstrap) on loopback -- resolving the container's hostname can take
+    # minutes to fail; HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC between the ranks' processes
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

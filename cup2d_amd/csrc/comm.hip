@@ -16,12 +16,14 @@
 // librccl.so.1 is opened on first use (dlopen), not linked: a process that never decomposes its grid never loads it.
 // The callback interface of cup2d_set_comm stays for callers that bring their own transport (the gloo tests).
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
-#include "ctx.h"
+#include "krylov_common.h"
 
 namespace cup2d {
 
@@ -44,7 +46,19 @@ static RcclApi *rccl_api() {
   static bool tried = false;
   if (tried) return api.handle ? &api : nullptr;
   tried = true;
-  const char *names[] = {getenv("CUP2D_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // a librccl the process has mapped already (PyTorch ships its own, without a soname) is reused: a second copy would be
+  // another half gigabyte to page in and a second set of device code objects
+  std::string loaded;
+  dl_iterate_phdr(
+      [](struct dl_phdr_info *info, size_t, void *out) -> int {
+        if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) {
+          *static_cast<std::string *>(out) = info->dlpi_name;
+          return 1;
+        }
+        return 0;
+      },
+      &loaded);
+  const char *names[] = {getenv("CUP2D_RCCL_LIB"), loaded.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
   for (const char *n : names)
     if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
@@ -138,23 +152,32 @@ static int rccl_allreduce(void *user, double *buf, int count, int op, void *stre
   return 0;
 }
 
-// {sum, sum, max} of every rank side by side, then one wave adds / maximises them in rank order: a sum and a max in ONE
-// collective, and a summation order that does not depend on the algorithm RCCL picks
-__global__ void k_gather_finish(const double *__restrict__ g, int nranks, double *__restrict__ red) {
+// The solver's reductions with the in-library communicator: {sum, sum, max} of every rank side by side (ONE all-gather of
+// three doubles per rank), then ONE single-wave kernel that adds / maximises them in rank order -- a summation order that
+// does not depend on the algorithm RCCL picks, and a sum and a max in one collective -- and runs the scalar update of the
+// stage on the result (krylov_common.h scalars_update; stage < 0: only the reduced values, into red).
+__global__ void k_gather_scalars(const double *__restrict__ g, int nranks, int nsum, int with_max, double *__restrict__ red,
+                                 KrylovScalars *sc, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double a = 0, b = 0, m = 0;
+  if (stage > 0 && sc->status != 0) return;  // the solve is over: the sweeps before this were no-ops
+  double v[3] = {0.0, 0.0, 0.0};
   for (int r = 0; r < nranks; r++) {
-    a += g[3 * r];
-    b += g[3 * r + 1];
-    m = fmax(m, g[3 * r + 2]);
+    if (nsum > 0) v[0] += g[3 * r];
+    if (nsum > 1) v[1] += g[3 * r + 1];
+    if (with_max) v[2] = fmax(v[2], g[3 * r + 2]);
   }
-  red[0] = a; red[1] = b; red[2] = m;
+  red[0] = v[0]; red[1] = v[1]; red[2] = v[2];
+  if (stage >= 0) {
+    scalars_update(sc, v, stage);
+    if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
-int comm_sum2_max1(cup2d_ctx *c) {
+int comm_reduce_scalars(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status) {
   RcclComm *rc = c->rccl;
   rc->n_allgather++;
   CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, 3, ncclDouble, rc->red, c->stream));
-  hipLaunchKernelGGL(k_gather_finish, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, c->d_red);
+  hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, nsum, with_max, c->d_red, c->d_sc,
+                     stage, host_status);
   CUP2D_HIP_CB(hipGetLastError());
   return 0;
 }

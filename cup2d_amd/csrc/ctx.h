@@ -268,7 +268,9 @@ int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
 // comm.hip
 int comm_finalize_impl(cup2d_ctx *c);
-int comm_sum2_max1(cup2d_ctx *c);  // d_red[0..2] = {sum, sum, max} over the ranks in ONE collective (all-gather + fixed-order finish)
+// d_red[0 .. nsum) summed and d_red[2] maximised over the ranks in ONE all-gather, finished in rank order by the kernel that
+// also runs the scalar update of `stage` (-1: none)
+int comm_reduce_scalars(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status);
 static inline bool overlapped(const cup2d_ctx *c) { return c->nghost > 0 && c->exchange && c->n_inner < c->nblocks; }
 
 }  // namespace cup2d

@@ -697,42 +697,39 @@ __global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int
   if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// the rank-local values in d_red[0 .. nsum) (sums) and d_red[2] (max) reduced over the ranks (cuda.cu:445-449, 491-493,
-// 513-515, 533-534).  The reference issues one MPI_Allreduce per quantity; here two sums share one all-reduce, and where
-// a max is due with them the in-library communicator moves all three in ONE all-gather (comm.hip) -- three collectives
-// per BiCGSTAB iteration instead of four.  Callback communicators (cup2d_set_comm) get one all-reduce per operator.
-static int allreduce_sums_max(cup2d_ctx *c, int nsum, int with_max) {
-  if (c->rccl && c->comm_user == (void *)c->rccl && nsum == 2 && with_max) {
-    if (comm_sum2_max1(c) != 0) return CUP2D_ERR_COMM;
+// The rank-local values in d_red[0 .. nsum) (sums) and d_red[2] (max) reduced over the ranks, then the scalar update of
+// `stage` (cuda.cu:445-449, 491-493, 513-515, 533-534; the reference issues one MPI_Allreduce per quantity, four per
+// iteration).  In-library communicator (comm.hip): ONE all-gather and ONE single-wave kernel per reduction point -- three
+// collectives per BiCGSTAB iteration.  Callback communicators (cup2d_set_comm): an all-reduce per operator, then k_scalars.
+static int reduce_over_ranks_and_update(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status) {
+  if (c->rccl && c->comm_user == (void *)c->rccl) {
+    if (comm_reduce_scalars(c, nsum, with_max, stage, host_status) != 0) return CUP2D_ERR_COMM;
     return CUP2D_OK;
   }
-  if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
-  if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+  if (c->allreduce) {
+    if (nsum > 0 && c->allreduce(c->comm_user, c->d_red, nsum, 0, c->stream) != 0) return CUP2D_ERR_COMM;
+    if (with_max && c->allreduce(c->comm_user, c->d_red + 2, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
+  }
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage, host_status);
+  CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
 
 int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status) {
   ProfScope prof(c, CUP2D_T_SCALARS);
-  const bool split = c->allreduce != nullptr;  // N GPUs: local sums -> all-reduce -> scalar update
+  const bool split = c->allreduce != nullptr;  // N GPUs: local sums -> reduction over the ranks -> scalar update
   hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(WG), 0, c->stream, c->d_partials, G, nsum, with_max, c->d_red,
                      c->d_sc, guarded ? 1 : 0, split ? -1 : stage, host_status);
   CUP2D_HIP_CHECK(hipGetLastError());
-  if (split) {
-    CUP2D_TRY(allreduce_sums_max(c, nsum, with_max));
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage, host_status);
-    CUP2D_HIP_CHECK(hipGetLastError());
-  }
+  if (split) CUP2D_TRY(reduce_over_ranks_and_update(c, nsum, with_max, stage, host_status));
   return CUP2D_OK;
 }
 
 // after a sweep whose last workgroup already summed this rank's partials into d_red (krylov_fused.hip, MERGE 2):
-// all-reduce over the ranks, then the scalar update
+// reduction over the ranks, then the scalar update
 int finish_local(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status) {
   ProfScope prof(c, CUP2D_T_SCALARS);
-  if (c->allreduce) CUP2D_TRY(allreduce_sums_max(c, nsum, with_max));
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), 0, c->stream, c->d_sc, c->d_red, stage, host_status);
-  CUP2D_HIP_CHECK(hipGetLastError());
-  return CUP2D_OK;
+  return reduce_over_ranks_and_update(c, nsum, with_max, stage, host_status);
 }
 
 // b = TMP, x0 = PRES, result -> PRES

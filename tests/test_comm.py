@@ -71,6 +71,8 @@ def _self_periodic_sim(nbx, nby):
 @pytest.mark.gpu
 def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib):
     from cup2d_amd.distributed import strip_cells
+    import os
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap socket on loopback
     nbx, nby = 6, 5
     s, g = _self_periodic_sim(nbx, nby)
     hip = _hip()
@@ -113,8 +115,10 @@ def test_one_rank_through_the_communicator_equals_the_plain_context(gpu_lib, ora
         s.vel = vel
         r0 = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=30)
         v0, p0 = s.vel, s.pres
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "rdv"), rank=0, world_size=1)
+    # loopback everywhere: gloo and RCCL's bootstrap otherwise resolve the box's hostname, which can take minutes to fail
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + int(fused)), RANK="0", WORLD_SIZE="1",
+                      GLOO_SOCKET_IFNAME="lo", NCCL_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         with DistributedSimulation(n // 8, n // 8, 1, 1, nu=1e-3, comm="rccl") as d:
             d.set_solver(fused=fused, finish_in_kernel=True)
@@ -124,7 +128,7 @@ def test_one_rank_through_the_communicator_equals_the_plain_context(gpu_lib, ora
             assert r1["dt"] == r0["dt"] and r1["iters"] == r0["iters"] == 30
             assert np.array_equal(d.vel, v0) and np.array_equal(d.pres, p0)
             assert r1["err"] == r0["err"]
-            # per iteration: AB 1 all-reduce, CD 1 all-reduce, E one all-gather (sum, sum, max)
-            assert st["nranks"] == 1 and st["peers"] == 0 and st["allgathers"] >= 30 and st["allreduces"] >= 60
+            # per iteration three reduction points (after AB, CD, E), each ONE all-gather + one scalar kernel
+            assert st["nranks"] == 1 and st["peers"] == 0 and st["allgathers"] >= 90
     finally:
         dist.destroy_process_group()

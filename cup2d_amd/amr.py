@@ -7,6 +7,7 @@ import ctypes
 import numpy as np
 
 from . import lib as _l
+from .simulation import BodyOps
 
 BS = 8
 
@@ -70,7 +71,7 @@ class AmrBlockGrid:
         return ox[:, None] + (ix[None, :] + 0.5) * h[:, None], oy[:, None] + (iy[None, :] + 0.5) * h[:, None]
 
 
-class AmrSimulation:
+class AmrSimulation(BodyOps):
     """Device-resident fields on an adapted grid + the halo-1 block operators in their AMR form.  Fields are set and
     read as per-block arrays (nb, 64) / (nb, 64, 2)."""
 

@@ -209,6 +209,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)comm_finalize_impl(c);
+  bodies_release(c);
   (void)hipFree(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
   (void)hipFree(c->d_vscratch);

@@ -90,6 +90,7 @@ struct SellMatrix {
 enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
 
 struct RcclComm;  // comm.hip: the in-library RCCL communicator (cup2d_comm_init)
+struct Bodies;    // penalize.hip: host-supplied bodies (cup2d_body_set)
 
 // Block-AMR topology (amr.hip): per block its level and, per side W,E,S,N, what lies across it
 struct AmrTopo {
@@ -153,6 +154,7 @@ struct cup2d_ctx {
   void *comm_user = nullptr;
   double *d_send = nullptr, *d_recv = nullptr;
   cup2d::RcclComm *rccl = nullptr;  // set by cup2d_comm_init; the callbacks above then point into comm.hip
+  cup2d::Bodies *bodies = nullptr;  // cup2d_body_set
   bool fused_lds_opt_in = false;    // k_fused's > 64 KiB of dynamic LDS opted in on THIS context's device
   // timing: pool of event pairs, resolved lazily
   int timing = 0;          // 0 off, 1 every launch, 2 sampled (every launch outside the solver, every 8th iteration inside)
@@ -266,6 +268,7 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
+void bodies_release(cup2d_ctx *c);  // penalize.hip
 // comm.hip
 int comm_finalize_impl(cup2d_ctx *c);
 // d_red[0 .. nsum) summed and d_red[2] maximised over the ranks in ONE all-gather, finished in rank order by the kernel that

@@ -11,7 +11,38 @@ from . import lib as _l
 from .grid import BlockGrid
 
 
-class Simulation:
+class BodyOps:
+    """Penalisation with host-supplied bodies (main.cpp:6643-7006; include/cup2d_hip.h cup2d_body_*): shared by the
+    uniform and the block-AMR host mirrors (the kernels take a block's cell size from the context)."""
+
+    def body_set(self, body, blocks, origin, chi, udef, centre):
+        """blocks: ascending block indices the shape touches; origin (n, 2) = Info::origin; chi (n, 64); udef (n, 64, 2)"""
+        vp = ctypes.c_void_p
+        b = np.ascontiguousarray(blocks, dtype=np.int32)
+        o = np.ascontiguousarray(origin, dtype=np.float64).reshape(len(b), 2)
+        c = np.ascontiguousarray(chi, dtype=np.float64).reshape(len(b), 64)
+        u = np.ascontiguousarray(udef, dtype=np.float64).reshape(len(b), 128)
+        _l.check(self.L.cup2d_body_set(self._ctx, int(body), len(b), b.ctypes.data_as(vp), o.ctypes.data_as(vp), c.ctypes.data_as(vp),
+                                       u.ctypes.data_as(vp), float(centre[0]), float(centre[1])), "body_set")
+
+    def body_clear(self):
+        _l.check(self.L.cup2d_body_clear(self._ctx), "body_clear")
+
+    def body_momentum(self, body, lam, dt):
+        """main.cpp:6643-6702: returns ((u, v, omega), the seven moments PM, PJ, PX, PY, UM, VM, AM)"""
+        uvw, q = np.zeros(3), np.zeros(7)
+        vp = ctypes.c_void_p
+        _l.check(self.L.cup2d_body_momentum(self._ctx, int(body), float(lam), float(dt), uvw.ctypes.data_as(vp), q.ctypes.data_as(vp)),
+                 "body_momentum")
+        return uvw, q
+
+    def penalize(self, lam, dt, uvw):
+        """main.cpp:6944-7006: velocity blend + tmpV = u_def of the dominating bodies; uvw (nbodies, 3)"""
+        a = np.ascontiguousarray(uvw, dtype=np.float64).reshape(-1, 3)
+        _l.check(self.L.cup2d_penalize(self._ctx, float(lam), float(dt), a.ctypes.data_as(ctypes.c_void_p)), "penalize")
+
+
+class Simulation(BodyOps):
     def __init__(self, nbx, nby=None, extent=1.0, nu=1e-3, cfl=0.5, order="hilbert", device=0, grid=None, h=None):
         """Uniform grid of nbx x nby blocks of 8x8 cells.  h = extent / max(nbx, nby) / 8 as
         main.cpp:6338 (sim.h0 at the level of the blocks)."""

@@ -300,6 +300,26 @@ typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int
 int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,
                    void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
 
+/* ---- penalisation with host-supplied bodies (main.cpp:6643-7006) ----
+ * A body is what the reference keeps per shape: for every block the shape touches an Obstacle with the shape's own
+ * indicator chi[8][8] and deformation velocity udef[8][8][2] (main.cpp:3283-3286; produced on the host by the shape
+ * model, which stays with the caller), and the shape's centre of mass.  CUP2D_CHI holds the field chi (var.chi).
+ * cup2d_body_set: body number `body` (0, 1, ...): blocks[nblk] = indices of the touched blocks, ascending (the order of the
+ *   reference's block loop), origin[nblk][2] = Info::origin of each, chi[nblk][64], udef[nblk][64][2], centre of mass.
+ * cup2d_body_momentum: main.cpp:6643-6702 -- the seven penalisation moments PM, PJ, PX, PY, UM, VM, AM of the body over
+ *   CUP2D_VEL (the integrands on the GPU, added up on the host in the reference's order; all-reduced over the ranks) and
+ *   the 3 x 3 LU solve for uvw = (u, v, omega); integrals (may be NULL) receives the seven sums.
+ * cup2d_penalize: main.cpp:6944-7006 with the bodies' velocities uvw[nbodies][3] (the caller may have passed them
+ *   through its collision model, main.cpp:6703-6943): CUP2D_VEL blended towards the body velocity where a body's chi
+ *   dominates, then CUP2D_TMPV = sum of the dominating bodies' udef (the u_def of cup2d_pressure_rhs).  Without bodies
+ *   it only clears CUP2D_TMPV.  Bit-identical to the reference's single-threaded loops; works on adapted grids
+ *   (cell size per block from cup2d_set_amr). */
+int cup2d_body_set(cup2d_ctx *ctx, int body, int nblk, const int32_t *blocks, const double *origin, const double *chi,
+                   const double *udef, double cx, double cy);
+int cup2d_body_clear(cup2d_ctx *ctx);
+int cup2d_body_momentum(cup2d_ctx *ctx, int body, double lambda, double dt, double *uvw /* [3] */, double *integrals /* [7] */);
+int cup2d_penalize(cup2d_ctx *ctx, double lambda, double dt, const double *uvw);
+
 /* ---- the communicator inside the library: RCCL over xGMI (one process per GPU) ----
  * Replaces the MPI of the reference on this path: Irecv / Isend / Waitall of the synchroniser (main.cpp:2040-2047,
  * 2133-2139; cuda.cu:365-380) by ncclRecv / ncclSend pairs of one ncclGroup on a second HIP stream, ordered behind the

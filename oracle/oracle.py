@@ -399,11 +399,13 @@ def ref_solve(b, x0=None, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None,
 
 
 def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=None, keep=None, hip=False, env=None,
-            b2=False):
+            b2=False, shapes=None, threads=None):
     """The reference's own time loop (main.cpp:6576-7290) from the IC vel0 for `steps` steps.
     hip=True: with sim.mat served by libcup2d_spmat.so (GPU) instead of the CPU restatement (seam B1).
-    b2=True: the loop of oracle/_ref/ref_harness_b2 -- every block-operator call site and the solve go through
-    include/cup2d_hip.h on the GPU (seam B2)."""
+    b2=True / b2="rk2,penal,...": the loop of oracle/_ref/ref_harness_b2 -- all (or the named) block-operator call sites
+    go through include/cup2d_hip.h on the GPU (seam B2), the others run the reference's own lines; b2="none" is the
+    reference loop in that binary.  shapes: the reference's -shapes descriptor (a fish), e.g.
+    "angle=0 L=0.4 xpos=0.5 ypos=0.5".  threads: OpenMP threads of the reference's loops (1 = fixed summation order)."""
     vel0 = _c(vel0)
     n = vel0.shape[0]
     d = keep or tempfile.mkdtemp()
@@ -411,7 +413,11 @@ def ref_run(vel0, nu, steps, cfl=0.5, tol=0.0, rel_tol=0.0, max_restarts=100, ma
     kw = dict(nu=float(nu), cfl=float(cfl), steps=int(steps), tol=float(tol), reltol=float(rel_tol), restarts=int(max_restarts))
     if max_iter is not None:
         kw["maxiter"] = int(max_iter)
-    _run_ref("run", n, d, _hip=hip, _env=env, _b2=b2, **kw)
+    if shapes:
+        kw["shapes"] = str(shapes)
+    if b2 and b2 is not True:
+        env = dict(env or {}, CUP2D_B2_SITES=str(b2))
+    _run_ref("run", n, d, _threads=threads, _hip=hip, _env=env, _b2=bool(b2), **kw)
     out = dict(vel=np.fromfile(os.path.join(d, "vel.final")).reshape(n, n, 2),
                pres=np.fromfile(os.path.join(d, "pres.final")).reshape(n, n), steps=[])
     meta = open(os.path.join(d, "meta.txt")).read().strip().split("\n")

@@ -35,13 +35,15 @@ static int harness_finalize_and_leave() {
   throw EscapeFromMain();
 }
 #ifdef HARNESS_B2
-/* oracle/_ref/ref_harness_b2: the copy of main.cpp that oracle/b2_patch.py wrote (-Ioracle/_ref/b2 comes first) calls
- * these at the block-operator call sites instead of computeA / computeB and the cuda.h solve: seam B2 compiled and run */
-static void b2_site_vorticity();
-static void b2_site_advect_diffuse_rk2();
-static void b2_site_poisson_rhs();
-static void b2_site_solve(double max_error, double max_rel_error, int max_restarts);
-static void b2_site_project();
+/* oracle/_ref/ref_harness_b2: the copy of main.cpp that oracle/b2_patch.py wrote (-Ioracle/_ref/b2 comes first) asks
+ * these at every block-operator call site: true = served through the C ABI on the GPU, false = the reference's own lines
+ * run (site switched off with CUP2D_B2_SITES): seam B2 compiled and run, site by site */
+static bool b2_site_vorticity();
+static bool b2_site_advect_diffuse_rk2();
+static bool b2_site_penalize();
+static bool b2_site_poisson_rhs();
+static bool b2_site_solve(double max_error, double max_rel_error, int max_restarts);
+static bool b2_site_project();
 #endif
 #define MPI_Finalize harness_finalize_and_leave
 #define main cup2d_reference_main
@@ -437,9 +439,27 @@ static int g_n = 0; /* cells per side */
 struct B2State {
   cup2d_ctx *ctx = nullptr;
   size_t nb = 0;
-  int calls[5] = {0, 0, 0, 0, 0};
+  int calls[6] = {0, 0, 0, 0, 0, 0};
+  unsigned sites = ~0u; /* bit per site: vort, rk2, penal, rhs, solve, project (CUP2D_B2_SITES) */
+  bool parsed = false;
 };
 static B2State b2;
+enum { B2_VORT = 0, B2_RK2 = 1, B2_PENAL = 2, B2_RHS = 3, B2_SOLVE = 4, B2_PROJECT = 5 };
+static bool b2_on(int site) {
+  if (!b2.parsed) {
+    b2.parsed = true;
+    if (const char *e = getenv("CUP2D_B2_SITES")) {
+      const char *names[6] = {"vort", "rk2", "penal", "rhs", "solve", "project"};
+      const std::string v = std::string(",") + e + ",";
+      if (v != ",all,") {
+        b2.sites = 0;
+        for (int k = 0; k < 6; k++)
+          if (v.find(std::string(",") + names[k] + ",") != std::string::npos) b2.sites |= 1u << k;
+      }
+    }
+  }
+  return (b2.sites >> site) & 1u;
+}
 #define B2RUN(expr)                                                                                   \
   do {                                                                                                \
     int _s = (expr);                                                                                  \
@@ -480,22 +500,64 @@ static void b2_get(int field, Grid *g) {
   for (size_t k = 0; k < p.size(); k++) p[k] = g->infos[k].block;
   B2RUN(cup2d_download(b2.ctx, field, p.data()));
 }
-static void b2_site_vorticity() { /* main.cpp:4659 */
+static bool b2_site_vorticity() { /* main.cpp:4659 */
+  if (!b2_on(B2_VORT)) return false;
   b2_sync_grid();
-  b2.calls[0]++;
+  b2.calls[B2_VORT]++;
   b2_put(CUP2D_VEL, var.vel);
   B2RUN(cup2d_vorticity(b2.ctx, CUP2D_BLOCKS_ALL));
   b2_get(CUP2D_TMP, var.tmp);
+  return true;
 }
-static void b2_site_advect_diffuse_rk2() { /* main.cpp:6611-6642 */
+static bool b2_site_advect_diffuse_rk2() { /* main.cpp:6611-6642 */
+  if (!b2_on(B2_RK2)) return false;
   b2_sync_grid();
-  b2.calls[1]++;
+  b2.calls[B2_RK2]++;
   b2_put(CUP2D_VEL, var.vel);
   B2RUN(cup2d_advect_diffuse_rk2(b2.ctx, sim.nu, sim.dt));
   b2_get(CUP2D_VEL, var.vel);
+  return true;
 }
-static void b2_site_poisson_rhs() { /* main.cpp:7003-7027 */
-  b2.calls[2]++;
+static bool b2_site_penalize() { /* main.cpp:6643-7006 */
+  if (!b2_on(B2_PENAL)) return false;
+  if (sim.shapes.size() > 1) return false; /* collisions between shapes (main.cpp:6703-6943) stay the reference's */
+  b2_sync_grid();
+  b2.calls[B2_PENAL]++;
+  std::vector<Info> &I = var.vel->infos;
+  b2_put(CUP2D_VEL, var.vel);
+  b2_put(CUP2D_CHI, var.chi);
+  B2RUN(cup2d_body_clear(b2.ctx));
+  std::vector<double> uvw;
+  for (size_t s = 0; s < sim.shapes.size(); s++) {
+    auto *shape = sim.shapes[s];
+    std::vector<int32_t> blocks;
+    std::vector<double> origin, chi, udef;
+    for (size_t i = 0; i < I.size(); i++) {
+      Obstacle *o = shape->obstacleBlocks[I[i].id];
+      if (o == nullptr) continue;
+      blocks.push_back((int32_t)i);
+      origin.push_back(I[i].origin[0]);
+      origin.push_back(I[i].origin[1]);
+      chi.insert(chi.end(), &o->chi[0][0], &o->chi[0][0] + _BS_ * _BS_);
+      udef.insert(udef.end(), &o->udef[0][0][0], &o->udef[0][0][0] + 2 * _BS_ * _BS_);
+    }
+    B2RUN(cup2d_body_set(b2.ctx, (int)s, (int)blocks.size(), blocks.data(), origin.data(), chi.data(), udef.data(),
+                         shape->centerOfMass[0], shape->centerOfMass[1]));
+    double x[3];
+    B2RUN(cup2d_body_momentum(b2.ctx, (int)s, sim.lambda, sim.dt, x, nullptr));
+    shape->u = x[0]; shape->v = x[1]; shape->omega = x[2];
+    uvw.insert(uvw.end(), x, x + 3);
+  }
+  sim.bCollisionID.clear(); /* main.cpp:6706 */
+  B2RUN(cup2d_penalize(b2.ctx, sim.lambda, sim.dt, uvw.data()));
+  b2_get(CUP2D_VEL, var.vel);
+  b2_get(CUP2D_TMPV, var.tmpV);
+  return true;
+}
+static bool b2_site_poisson_rhs() { /* main.cpp:7007-7027 */
+  if (!b2_on(B2_RHS)) return false;
+  b2_sync_grid();
+  b2.calls[B2_RHS]++;
   b2_put(CUP2D_VEL, var.vel); /* the host may have penalised it in between (main.cpp:6643-6979) */
   b2_put(CUP2D_TMPV, var.tmpV);
   b2_put(CUP2D_CHI, var.chi);
@@ -504,9 +566,14 @@ static void b2_site_poisson_rhs() { /* main.cpp:7003-7027 */
   b2_get(CUP2D_TMP, var.tmp);
   b2_get(CUP2D_POLD, var.pold);
   b2_get(CUP2D_PRES, var.pres);
+  return true;
 }
-static void b2_site_solve(double max_error, double max_rel_error, int max_restarts) { /* main.cpp:7031-7119 */
-  b2.calls[3]++;
+static bool b2_solved_on_device = false;
+static bool b2_site_solve(double max_error, double max_rel_error, int max_restarts) { /* main.cpp:7031-7119 */
+  b2_solved_on_device = false;
+  if (!b2_on(B2_SOLVE)) return false;
+  b2_sync_grid();
+  b2.calls[B2_SOLVE]++;
   if (hooks.on_solve) hooks.on_solve(sim.mat, false, max_error, max_rel_error, max_restarts);
   b2_put(CUP2D_TMP, var.tmp);
   b2_put(CUP2D_PRES, var.pres);
@@ -515,14 +582,30 @@ static void b2_site_solve(double max_error, double max_rel_error, int max_restar
   B2RUN(cup2d_poisson_solve(b2.ctx, max_error, max_rel_error, max_restarts, hooks.forced_max_iter >= 0 ? hooks.forced_max_iter : 1000,
                             &iters, &restarts, &err, &err0));
   hooks.last_iters = iters; hooks.last_restarts = restarts; hooks.last_error = err; hooks.last_error_init = err0;
+  b2_solved_on_device = true;
+  return true;
 }
-static void b2_site_project() { /* main.cpp:7120-7187; x stays on the device in PRES */
-  b2.calls[4]++;
+static bool b2_site_project() { /* main.cpp:7120-7187; x of a device solve is still on the device in PRES */
+  if (!b2_on(B2_PROJECT)) {
+    if (b2_solved_on_device) { /* the reference's projection reads the solution from sim.mat->get_x() */
+      std::vector<double> slab(b2.nb * _BS_ * _BS_);
+      B2RUN(cup2d_download_slab(b2.ctx, CUP2D_PRES, slab.data()));
+      sim.mat->get_x() = slab;
+    }
+    return false;
+  }
+  b2_sync_grid();
+  b2.calls[B2_PROJECT]++;
+  if (!b2_solved_on_device) { /* x of the reference's solve -> PRES */
+    const std::vector<double> &x = sim.mat->get_x();
+    B2RUN(cup2d_upload_slab(b2.ctx, CUP2D_PRES, x.data()));
+  }
   b2_put(CUP2D_VEL, var.vel);
   b2_put(CUP2D_POLD, var.pold);
   B2RUN(cup2d_project(b2.ctx, sim.dt));
   b2_get(CUP2D_PRES, var.pres);
   b2_get(CUP2D_VEL, var.vel);
+  return true;
 }
 #endif
 
@@ -590,6 +673,7 @@ static void global_to_blockvec(const std::vector<double> &glob, std::vector<doub
             glob[(size_t)(infos[i].index[1] * _BS_ + iy) * g_n + infos[i].index[0] * _BS_ + ix];
 }
 
+static std::string g_shapes; /* key shapes=...: the reference's own -shapes descriptor (fish), e.g. "angle=0 L=0.2 xpos=0.5 ypos=0.5" */
 static int run_reference_main(int levelStart, double nu, double cfl, double tend,
                               double ptol, double ptolrel, int prestarts, int levelMax = -1, int adaptSteps = 1000000) {
   /* uniform n x n recipe: one base block, all blocks at
@@ -602,7 +686,7 @@ static int run_reference_main(int levelStart, double nu, double cfl, double tend
       "-nu", std::to_string(nu), "-poissonTol", std::to_string(ptol),
       "-poissonTolRel", std::to_string(ptolrel),
       "-maxPoissonRestarts", std::to_string(prestarts), "-maxPoissonIterations", "1000",
-      "-tdump", "0", "-shapes", ""};
+      "-tdump", "0", "-shapes", g_shapes};
   /* std::to_string(double) keeps 6 decimals: pass exact values via %.17g */
   auto put = [&](const char *key, double v) {
     char buf[64];
@@ -686,6 +770,7 @@ int main(int argc, char **argv) {
     else if (k == "rtol") rtol_amr = atof(v.c_str());
     else if (k == "ctol") ctol_amr = atof(v.c_str());
     else if (k == "nomatrix") nomatrix = atoi(v.c_str());
+    else if (k == "shapes") g_shapes = v;
     else { usage(); return 2; }
   }
   g_n = _BS_ << levelStart;
@@ -951,11 +1036,14 @@ int main(int argc, char **argv) {
         snprintf(tag, sizeof tag, ".%d", solve_count);
         dump_grid(dir + "/vel_adv" + tag, var.vel, 2);
 #ifdef HARNESS_B2
-        dump_grid(dir + "/b" + tag, var.tmp, 1); /* the right-hand side the GPU computed, back on the host */
-#else
-        auto bg = blockvec_to_global(M->get_b());
-        write_file(dir + "/b" + tag, bg.data(), bg.size());
+        if (b2_on(B2_SOLVE)) {
+          dump_grid(dir + "/b" + tag, var.tmp, 1); /* the right-hand side as the host holds it ahead of a device solve */
+        } else
 #endif
+        {
+          auto bg = blockvec_to_global(M->get_b());
+          write_file(dir + "/b" + tag, bg.data(), bg.size());
+        }
         dump_grid(dir + "/pold" + tag, var.pold, 1);
         fprintf(meta, "step %d dt %.17g time %.17g tol %.17g reltol %.17g restarts %d prev_iters %d prev_err %.17g\n",
                 solve_count, sim.dt, sim.time, e, re, mr, hooks.last_iters, hooks.last_error);
@@ -972,8 +1060,8 @@ int main(int argc, char **argv) {
     fprintf(meta, "final iters %d err %.17g err_init %.17g restarts %d time %.17g steps %d\n", hooks.last_iters,
             hooks.last_error, hooks.last_error_init, hooks.last_restarts, sim.time, sim.step);
 #ifdef HARNESS_B2
-    fprintf(stderr, "ref_harness_b2: C-ABI call sites served: vorticity %d, advect_diffuse_rk2 %d, poisson_rhs %d, solve %d, project %d\n",
-            b2.calls[0], b2.calls[1], b2.calls[2], b2.calls[3], b2.calls[4]);
+    fprintf(stderr, "ref_harness_b2: C-ABI call sites served: vorticity %d, advect_diffuse_rk2 %d, penalize %d, poisson_rhs %d, solve %d, project %d\n",
+            b2.calls[0], b2.calls[1], b2.calls[2], b2.calls[3], b2.calls[4], b2.calls[5]);
 #endif
     fclose(meta);
     if (dump) {

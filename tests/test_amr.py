@@ -470,3 +470,80 @@ def test_amr_unsupported_entry_points_say_so(gpu_lib):
         it = ctypes.c_int()
         assert s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 10, 10, ctypes.byref(it), None, None, None) == -4
         assert s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER) == -1  # CUP2D_ERR_ARG: adapted grids take all blocks
+
+
+def _penalize_numpy(vel, CHI, blocks_idx, origin, h, chi, udef, centre, lam, dt):
+    """main.cpp:6643-7006 for one body, statement by statement in numpy (same operation order, no contraction):
+    returns (uvw, moments, vel after the blend, tmpV)"""
+    lamdt = lam * dt
+    iy, ix = np.divmod(np.arange(64), 8)
+    q = np.zeros(7)
+    terms = []
+    for k, b in enumerate(blocks_idx):  # the reference's order: block, iy, ix
+        X = chi[k]
+        V, U = vel[b], udef[k]
+        ud0, ud1 = V[:, 0] - U[:, 0], V[:, 1] - U[:, 1]
+        Xl = np.where(X >= 0.5, lamdt, 0.0)
+        F = h[b] * h[b] * Xl / (1 + Xl)
+        p0 = origin[k, 0] + h[b] * (ix + 0.5) - centre[0]
+        p1 = origin[k, 1] + h[b] * (iy + 0.5) - centre[1]
+        t = np.stack([F, F * (p0 * p0 + p1 * p1), F * p0, F * p1, F * ud0, F * ud1, F * (p0 * ud1 - p1 * ud0)], axis=1)
+        t[X <= 0] = 0.0
+        terms.append(t)
+    for t in terms:
+        for j in range(64):
+            q += t[j]
+    PM, PJ, PX, PY = q[:4]
+    A = np.array([[PM, 0, -PY], [0, PM, PX], [-PY, PX, PJ]])
+    uvw = np.linalg.solve(A, q[4:])  # the solve itself is pinned by the bit-exact loop test (tests/test_spmat_gpu.py)
+    return q, terms
+
+
+@pytest.mark.gpu
+def test_penalisation_kernels_on_an_adapted_grid_gpu(gpu_lib, oracle):
+    """cup2d_body_momentum / cup2d_penalize on a three-level grid (cell size per block from the AMR tables): moments and
+    fields equal the numpy statement of main.cpp:6643-7006 bit for bit; the 3 x 3 solve to round-off"""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    name, F = next(_grid_cases(oracle))  # the golden three-level grid
+    g = AmrBlockGrid(F["blocks"])
+    nb = g.nblocks
+    rng = np.random.default_rng(11)
+    h = g.h0 / (1 << g.blocks[:, 0])
+    org = np.stack([g.blocks[:, 1] * 8 * h, g.blocks[:, 2] * 8 * h], axis=1)
+    touched = np.sort(rng.choice(nb, size=nb // 3, replace=False))
+    chi = rng.uniform(-0.2, 1.0, (len(touched), 64))      # <= 0, (0, 0.5), >= 0.5 all occur
+    udef = 0.3 * rng.uniform(-1, 1, (len(touched), 64, 2))
+    CHI = rng.uniform(0, 1, (nb, 64))                      # the field chi: sometimes above, sometimes below the body's
+    vel = rng.uniform(-1, 1, (nb, 64, 2))
+    centre, lam, dt = (0.47, 0.52), 1e7, 1e-3
+    q_ref, _ = _penalize_numpy(vel, CHI, touched, org[touched], h, chi, udef, centre, lam, dt)
+    with AmrSimulation(g) as s:
+        s.set_field(L.VEL, vel)
+        s.set_field(L.CHI, CHI)
+        s.body_set(0, touched, org[touched], chi, udef, centre)
+        uvw, q = s.body_momentum(0, lam, dt)
+        assert np.array_equal(q, q_ref), name
+        A = np.array([[q[0], 0, -q[3]], [0, q[0], q[2]], [-q[3], q[2], q[1]]])
+        assert np.allclose(A @ uvw, q[4:], rtol=1e-12, atol=1e-14 * np.abs(q[4:]).max())
+        s.penalize(lam, dt, uvw)
+        # main.cpp:6944-6978 / 6979-7006, elementwise
+        iy, ix = np.divmod(np.arange(64), 8)
+        v_ref, t_ref = vel.copy(), np.zeros_like(vel)
+        for k, b in enumerate(touched):
+            X = chi[k]
+            p0 = org[b, 0] + h[b] * (ix + 0.5) - centre[0]
+            p1 = org[b, 1] + h[b] * (iy + 0.5) - centre[1]
+            alpha = np.where(X > 0.5, 1 / (1 + lam * dt), 1.0)
+            US = uvw[0] - uvw[2] * p1 + udef[k, :, 0]
+            VS = uvw[1] + uvw[2] * p0 + udef[k, :, 1]
+            on = ~(CHI[b] > X) & ~(X <= 0)
+            v_ref[b, on, 0] = (alpha * vel[b, :, 0] + (1 - alpha) * US)[on]
+            v_ref[b, on, 1] = (alpha * vel[b, :, 1] + (1 - alpha) * VS)[on]
+            dom = ~(X < CHI[b])
+            t_ref[b, dom] += udef[k, dom]
+        assert np.array_equal(s.get_field(L.VEL), v_ref), name
+        assert np.array_equal(s.get_field(L.TMPV), t_ref), name
+        s.body_clear()
+        s.penalize(lam, dt, np.zeros((0, 3)))
+        assert not s.get_field(L.TMPV).any()

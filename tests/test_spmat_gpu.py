@@ -198,3 +198,41 @@ def test_b2_loop_at_2048_equals_the_unpatched_reference(gpu_lib, oracle):
     assert np.array_equal(A["steps"][0]["vel_adv"], B["steps"][0]["vel_adv"])
     assert np.array_equal(A["steps"][0]["b"], B["steps"][0]["b"])
     assert np.abs(A["vel"] - B["vel"]).max() <= 1e-9 and np.abs(A["pres"] - B["pres"]).max() <= 1e-8
+
+
+FISH = "angle=0 L=0.4 xpos=0.5 ypos=0.5"  # the reference's own shape model (main.cpp:6378-6444) supplies chi and u_def
+
+
+def test_penalisation_site_is_bit_identical_to_the_reference(gpu_lib, oracle):
+    """SURVEY.md 8f item 3 (main.cpp:6643-7006): the reference's loop with one fish, three steps at 256^2, once entirely
+    the reference's code (all sites of ref_harness_b2 off) and once with ONLY the penalisation site served by
+    cup2d_body_set / cup2d_body_momentum / cup2d_penalize.  One OpenMP thread fixes the reference's summation order; the
+    moments are added up in that order, so the body velocities, the blended velocity field and everything downstream are
+    equal bit for bit."""
+    assert oracle.have_reference_b2()
+    vel0 = 0.1 * oracle.taylor_green(256)
+    kw = dict(steps=3, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=40, shapes=FISH, threads=1)
+    A = oracle.ref_run(vel0, 1e-3, b2="none", **kw)
+    B = oracle.ref_run(vel0, 1e-3, b2="penal", **kw)
+    assert np.abs(A["vel"] - vel0).max() > 1e-2  # the fish is there
+    for k in range(3):
+        assert A["steps"][k]["dt"] == B["steps"][k]["dt"]
+        assert np.array_equal(A["steps"][k]["vel_adv"], B["steps"][k]["vel_adv"])  # velocity after the blend
+        assert np.array_equal(A["steps"][k]["b"], B["steps"][k]["b"])              # rhs with the chi / u_def terms
+    assert np.array_equal(A["vel"], B["vel"]) and np.array_equal(A["pres"], B["pres"])
+
+
+def test_all_sites_with_a_body_follow_the_reference(gpu_lib, oracle):
+    """every call site on the GPU (RK2, penalisation, Poisson rhs with chi / u_def, solve, projection) with the fish in the
+    flow: the state after three steps is the reference's to the solve tolerance"""
+    assert oracle.have_reference_b2()
+    vel0 = 0.1 * oracle.taylor_green(256)
+    kw = dict(steps=3, tol=1e-11, rel_tol=0.0, max_restarts=100, shapes=FISH, threads=1)
+    A = oracle.ref_run(vel0, 1e-3, b2="none", **kw)
+    B = oracle.ref_run(vel0, 1e-3, b2=True, **kw)
+    # with a body the very first pass of the loop already solves a non-trivial system (u_def drives a pressure), so the two
+    # solvers' iterates differ at the solve tolerance times the conditioning of the 256^2 operator from step one on
+    dv, dp = np.abs(A["vel"] - B["vel"]).max(), np.abs(A["pres"] - B["pres"]).max()
+    print("all sites with a body: max|dvel| %.2e max|dpres| %.2e, dt %s vs %s" % (dv, dp, [s["dt"] for s in A["steps"]], [s["dt"] for s in B["steps"]]))
+    assert np.allclose([s["dt"] for s in A["steps"]], [s["dt"] for s in B["steps"]], rtol=1e-6, atol=0)
+    assert dv < 1e-6 and dp < 5e-5

@@ -336,7 +336,8 @@ def main():
     #   sweep_E       reads x, z, z2, r, t, rhat 48 + writes x, r 16 = 64
     #   smoother      weighted-Jacobi sweep (not part of the step): reads x, b 16 + writes x' 8 = 24
     #   fused solver (krylov_fused.hip): sweep_A = A+B in one launch: reads p, nu, r, rhat 32 + writes p', nu' 16 = 48
-    #   sweep_C = C+D: reads r, nu 16 + writes s, t 16 = 32     sweep_E: reads y, p, s, t, rhat 40 + writes y, r 16 = 56
+    #   sweep_C = C+D: reads r, nu 16 + writes t 8 = 24 (s = r - alpha nu is not stored)
+    #   sweep_E: reads y, p, r, nu, t, rhat 48 + writes y, r 16 = 64 (forms s again)
     ALGO_BYTES = {"advect_stage": 40.0, "poisson_rhs": 32.0, "sweep_A": 40.0, "sweep_B": 24.0, "sweep_C": 32.0,
                   "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0, "smoother": 24.0}
     mk = "true" if args.finish == "kernel" and dist is None else "false"
@@ -346,7 +347,7 @@ def main():
                  "init_residual": "k_init_residual", "smoother": "k_smoother<0, false, 1>"}
     sweeps = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E")
     if fused:
-        ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 32.0, "sweep_E": 56.0})
+        ALGO_BYTES.update({"sweep_A": 48.0, "sweep_C": 24.0, "sweep_E": 64.0})
         del ALGO_BYTES["sweep_B"], ALGO_BYTES["sweep_D"]
         # fused kernels: MERGE 1 = the last workgroup finishes the reduction and updates the scalars (one GPU),
         # 2 = it sums the rank's partials, all-reduce + scalar kernel follow (N GPUs), 0 = finish launch

@@ -19,8 +19,8 @@
 // x = x0 + P_inv y once at the end (P_inv is linear, z = P_inv p, z2 = P_inv s) -- so sweep E reads p
 // instead of z and z2.  Per iteration and cell:
 //   AB  reads p, nu, r, rhat (32) writes p', nu' (16)           = 48 B   (+ ring re-reads, served by L2)
-//   CD  reads r, nu' (16)         writes s, t (16)              = 32 B
-//   E   reads y, p', s, t, rhat (40) writes y, r (16)           = 56 B        total 136 B (five sweeps: 184 B)
+//   CD  reads r, nu' (16)         writes t (8)                  = 24 B   (s = r - alpha nu' is not stored)
+//   E   reads y, p', r, nu', t, rhat (48) writes y, r (16)      = 64 B        total 136 B (five sweeps: 184 B)
 // p and nu are double-buffered (a ring recomputation must see the OLD p, nu of a block another wave may
 // already have advanced) and s gets its own vector for the same reason.
 #include <stdlib.h>
@@ -353,10 +353,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         if (is_tile) {
           if (MODE == 1) W[4 * half + p] = v;
           if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
-          if (idx < nvalid) {
+          if (MODE == 0 && idx < nvalid) {  // CD does not store s: its only reader, sweep E, forms it again from r and nu'
             const size_t o = ((size_t)(b0 + idx) * BC + c0) >> 1;
-            st2<(POL & (MODE == 0 ? 0x001 : 0x004)) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
-            if (MODE == 0 && restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
+            st2<(POL & 0x001) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
+            if (restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
           }
         }
       }
@@ -517,22 +517,28 @@ __global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double
 // with x = x0 + P_inv y).  y lives in three buffers: y' goes to the one that holds neither y nor the best
 // iterate so far, so the reference's copy of the best iterate (cuda.cu:535-538) is a change of index
 // (krylov_common.h y_out_buffer) and the sweep moves a flat 56 B/cell.
+// s = r - alpha nu' (cuda.cu:499-502) is formed here again from r and nu' -- the same two operands and operation CD used,
+// bit for bit -- instead of being stored by CD and read back: a stored double costs the L2 one 64-byte write request per 8
+// cells plus the read, the recomputation one more 128-byte read request per 16 (the sweeps are bound by L2 requests).
 template <int MERGE>
 __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, double2 *y2, const double2 *__restrict__ p,
-                                                 double2 *__restrict__ r, const double2 *__restrict__ s,
+                                                 double2 *__restrict__ r, const double2 *__restrict__ nu,
                                                  const double2 *__restrict__ t, const double2 *__restrict__ rhat,
                                                  KrylovScalars *sc, double *partials, size_t n2, double *red,
                                                  unsigned *ticket, int *host_status) {
   if (sc->status != 0) return;
-  const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega;
+  const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega, malpha = -sc->alpha;
   const int cur = sc->ycur, out = y_out_buffer(cur, sc->ybest);
   const double2 *__restrict__ yin = cur == 0 ? y0 : (cur == 1 ? y1 : y2);
   double2 *__restrict__ yout = out == 0 ? y0 : (out == 1 ? y1 : y2);
   double sm[2] = {0.0, 0.0}, m[1] = {0.0};
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
     double2 yv = ld2<(POL & 0x040) != 0>(yin + i);
-    const double2 pv = ld2<(POL & 0x080) != 0>(p + i), sv = ld2<(POL & 0x100) != 0>(s + i);
+    const double2 pv = ld2<(POL & 0x080) != 0>(p + i), ro = r[i], nv = ld2<(POL & 0x100) != 0>(nu + i);
     const double2 tv = ld2<(POL & 0x200) != 0>(t + i), hv = ld2<(POL & 0x400) != 0>(rhat + i);
+    double2 sv;
+    sv.x = ro.x + malpha * nv.x;
+    sv.y = ro.y + malpha * nv.y;
     yv.x = yv.x + alpha * pv.x;
     yv.y = yv.y + alpha * pv.y;
     yv.x = yv.x + omega * sv.x;
@@ -727,7 +733,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       ProfScope prof(c, CUP2D_T_SWEEP_E);
       const auto launchE = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
-                           (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)c->d_s, (const double2 *)c->d_t,
+                           (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)nu_out, (const double2 *)c->d_t,
                            (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
                            &c->h_status[slot]);
       };

@@ -418,6 +418,43 @@ static AmrDev amr_dev(const cup2d_ctx *c) {
   T.faces = c->amr.d_faces; T.h0 = c->amr.h0;
   return T;
 }
+// ---- N ranks: ghost copies ------------------------------------------------------------------------------------------
+// whole ghost blocks of a field the next kernel reads (the halo plan lists whole blocks; width 8 = the block)
+static int amr_refresh(cup2d_ctx *c, const double *field, int dim) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  return exchange_halo(c, const_cast<double *>(field), dim, BS);
+}
+// the face arrays (BlockCase::d, REC doubles per block) of the blocks in the send list -> the peers' ghost slots: the
+// coarse side of a coarse-fine face adds the fine side's fluxes, and the fine blocks may live on another rank
+// (main.cpp:1819-1825 exchanges exactly these)
+__global__ __launch_bounds__(WG) void k_amr_faces_pack(const double *__restrict__ faces, double *__restrict__ buf,
+                                                       const int32_t *__restrict__ blocks, int n, int rec, int pack) {
+  const size_t total = (size_t)n * rec;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const int k = (int)(i / rec), q = (int)(i - (size_t)k * rec);
+    double *f = const_cast<double *>(faces) + (size_t)blocks[k] * rec + q;
+    if (pack) buf[i] = *f;
+    else *f = buf[i];
+  }
+}
+static int amr_exchange_faces(cup2d_ctx *c, double *faces, int rec) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  const HaloPlan &P = c->plan;
+  if (P.nsend > 0) {
+    int g = (int)(((size_t)P.nsend * rec + WG - 1) / WG);
+    hipLaunchKernelGGL(k_amr_faces_pack, dim3(g > c->grid ? c->grid : g), dim3(WG), 0, c->stream, faces, c->d_send, P.d_send_block, P.nsend, rec, 1);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  if (c->exchange(c->comm_user, c->d_send, c->d_recv, rec, c->stream) != 0) { set_error("exchange callback failed"); return CUP2D_ERR_COMM; }
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) { set_error("wait callback failed"); return CUP2D_ERR_COMM; }
+  if (P.nrecv > 0) {
+    int g = (int)(((size_t)P.nrecv * rec + WG - 1) / WG);
+    hipLaunchKernelGGL(k_amr_faces_pack, dim3(g > c->grid ? c->grid : g), dim3(WG), 0, c->stream, faces, c->d_recv, P.d_recv_block, P.nrecv, rec, 0);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  return CUP2D_OK;
+}
+
 static int amr_grid(const cup2d_ctx *c) {
   int g = (c->nblocks + WPG - 1) / WPG;
   return g > c->grid ? c->grid : (g < 1 ? 1 : g);
@@ -425,8 +462,10 @@ static int amr_grid(const cup2d_ctx *c) {
 
 int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract) {
   const AmrDev T = amr_dev(c);
+  CUP2D_TRY(amr_refresh(c, x, 1));
   if (subtract) {
     hipLaunchKernelGGL(k_amr_scalar<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
+    CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces, 4 * BS));
     hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, y, T, c->nblocks);
   } else {
     hipLaunchKernelGGL(k_amr_scalar<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
@@ -435,11 +474,13 @@ int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract) {
   return CUP2D_OK;
 }
 int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt) {
+  CUP2D_TRY(amr_refresh(c, pres, 1));
   hipLaunchKernelGGL(k_amr_scalar<2>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, pres, tmpV, amr_dev(c), c->nblocks, dt);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
 int amr_vorticity(cup2d_ctx *c, const double *vel, double *out) {
+  CUP2D_TRY(amr_refresh(c, vel, 2));
   hipLaunchKernelGGL(k_amr_vector<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, nullptr, nullptr, out,
                      amr_dev(c), c->nblocks, 0.0);
   CUP2D_HIP_CHECK(hipGetLastError());
@@ -447,8 +488,11 @@ int amr_vorticity(cup2d_ctx *c, const double *vel, double *out) {
 }
 int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt) {
   const AmrDev T = amr_dev(c);
+  CUP2D_TRY(amr_refresh(c, vel, 2));
+  CUP2D_TRY(amr_refresh(c, udef, 2));
   hipLaunchKernelGGL(k_amr_vector<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (const double2 *)udef,
                      chi, out, T, c->nblocks, dt);
+  CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces, 4 * BS));
   hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, out, T, c->nblocks);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
@@ -510,13 +554,16 @@ __global__ __launch_bounds__(WG) void k_amr_wsum_final(const double *__restrict_
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) red[0] = sm[0][0] / sm[1][0];  // avg = avg / avg1, main.cpp:7142
+  if (threadIdx.x == 0) {  // quantities[0], quantities[1] of main.cpp:7136-7141: summed over the ranks before the division
+    red[0] = sm[0][0];
+    red[1] = sm[1][0];
+  }
 }
 // MODE 0: p += -avg (main.cpp:7143-7148)   MODE 1: p += pold - avg (main.cpp:7166-7172)
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_amr_shift(double *__restrict__ p, const double *__restrict__ pold,
                                                   const double *__restrict__ red, size_t n) {
-  const double avg = red[0];
+  const double avg = red[0] / red[1];  // avg = avg / avg1, main.cpp:7142
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
     if (MODE == 0) p[i] += -avg;
     else p[i] += pold[i] - avg;
@@ -557,6 +604,7 @@ int amr_project(cup2d_ctx *c, double dt) {
     const int g = amr_grid(c);
     hipLaunchKernelGGL(k_amr_wsum, dim3(g), dim3(WG), 0, c->stream, pres, T, c->nblocks, c->d_partials);
     hipLaunchKernelGGL(k_amr_wsum_final, dim3(1), dim3(WG), 0, c->stream, c->d_partials, g, c->d_red);
+    if (c->allreduce && c->allreduce(c->comm_user, c->d_red, 2, 0, c->stream) != 0) { set_error("allreduce callback failed"); return CUP2D_ERR_COMM; }
     if (pass == 0) hipLaunchKernelGGL(k_amr_shift<0>, dim3(gs), dim3(WG), 0, c->stream, pres, pold, c->d_red, n);
     else hipLaunchKernelGGL(k_amr_shift<1>, dim3(gs), dim3(WG), 0, c->stream, pres, pold, c->d_red, n);
   }
@@ -570,12 +618,14 @@ int amr_project(cup2d_ctx *c, double dt) {
 // tmpV = KernelAdvectDiffuse(vel) with the flux correction (main.cpp:6611-6617 / 6627-6633)
 int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt) {
   const AmrDev T = amr_dev(c);
+  CUP2D_TRY(amr_refresh(c, vel, 2));
   if (c->math == CUP2D_MATH_STRICT)
     hipLaunchKernelGGL(k_amr_advect<WenoStrict>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV,
                        T, c->amr.d_faces2, c->nblocks, nu, dt);
   else
     hipLaunchKernelGGL(k_amr_advect<WenoFast>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV, T,
                        c->amr.d_faces2, c->nblocks, nu, dt);
+  CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces2, 4 * BS * 2));
   hipLaunchKernelGGL(k_amr_fillcases2, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)tmpV, T, c->amr.d_faces2, c->nblocks);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;

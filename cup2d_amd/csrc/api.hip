@@ -337,8 +337,10 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
                   const int32_t *half) {
   CUP2D_CHECK_CTX(c);
   if (!(h0 > 0) || !level || !kind || !nbr2 || !half) { set_error("set_amr: bad argument"); return CUP2D_ERR_ARG; }
-  if (c->nghost != 0) { set_error("set_amr: ghost blocks (multi-GPU) are not supported on adapted grids yet"); return CUP2D_ERR_UNSUPPORTED; }
-  const int nb = c->nblocks;
+  // with ghost blocks (N ranks) the tables cover owned + ghost blocks: a ghost block's entries are read where a kernel
+  // looks across a COARSER neighbour's tangential side (halo-3 tile, amr.hip); sides of ghost blocks whose neighbour this
+  // rank does not hold are passed as CUP2D_AMR_WALL and never read
+  const int nb = c->ntotal;
   for (int b = 0; b < nb; b++) {
     if (level[b] < 0 || level[b] > 30) { set_error("set_amr: level[%d] = %d", b, level[b]); return CUP2D_ERR_ARG; }
     for (int s = 0; s < 4; s++) {
@@ -370,8 +372,14 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   A.h0 = h0;
   int lmax = 0;
   for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;
-  A.h_min = h0 / (double)(1 << lmax);
+  A.h_min = h0 / (double)(1 << lmax);  // N ranks: the finest level of the WHOLE grid, cup2d_amr_set_finest_level
   A.active = true;
+  return CUP2D_OK;
+}
+int cup2d_amr_set_finest_level(cup2d_ctx *c, int level_finest) {
+  CUP2D_CHECK_CTX(c);
+  if (!c->amr.active || level_finest < 0 || level_finest > 30) { set_error("amr_set_finest_level: cup2d_set_amr first; 0 <= level <= 30"); return CUP2D_ERR_ARG; }
+  c->amr.h_min = c->amr.h0 / (double)(1 << level_finest);
   return CUP2D_OK;
 }
 #define AMR_UNSUPPORTED(c)                                                                      \

@@ -99,7 +99,7 @@ struct RcclComm {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   int nranks = 1, rank = 0;
-  std::vector<int> peer, soff, roff, cnt;   // per peer: rank, first strip in the send / receive list, strips
+  std::vector<int> peer, soff, roff, cnt, rcnt;   // per peer: rank, first strip in the send / receive list, strips sent / received
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
   long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
 };
@@ -131,9 +131,11 @@ static int rccl_exchange(void *user, double *send, double *recv, int strip_doubl
   const size_t sd = (size_t)strip_doubles;
   CUP2D_NCCL(rc, rc->api->GroupStart());
   for (size_t i = 0; i < rc->peer.size(); i++)  // receives first, as main.cpp:2040-2047 posts them
-    CUP2D_NCCL(rc, rc->api->Recv(recv + rc->roff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+    if (rc->rcnt[i] > 0)
+      CUP2D_NCCL(rc, rc->api->Recv(recv + rc->roff[i] * sd, rc->rcnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
   for (size_t i = 0; i < rc->peer.size(); i++)
-    CUP2D_NCCL(rc, rc->api->Send(send + rc->soff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+    if (rc->cnt[i] > 0)
+      CUP2D_NCCL(rc, rc->api->Send(send + rc->soff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
   CUP2D_NCCL(rc, rc->api->GroupEnd());
   CUP2D_HIP_CB(hipEventRecord(rc->ev_arrived, rc->comm_stream));
   return 0;
@@ -225,18 +227,19 @@ int cup2d_comm_unique_id(void *id_bytes) {
 }
 
 int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
-                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips) {
+                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips, const int32_t *nstrips_recv) {
   CUP2D_CHECK_CTX(c);
   if (nranks < 1 || rank < 0 || rank >= nranks || !id_bytes || npeers < 0 ||
       (npeers && (!peer_rank || !send_offset || !recv_offset || !nstrips))) {
     set_error("comm_init: bad argument");
     return CUP2D_ERR_ARG;
   }
+  if (!nstrips_recv) nstrips_recv = nstrips;  // same-level faces: as many strips come in as go out
   for (int i = 0; i < npeers; i++)
-    if (peer_rank[i] < 0 || peer_rank[i] >= nranks || nstrips[i] < 0 || send_offset[i] < 0 || recv_offset[i] < 0 ||
-        send_offset[i] + nstrips[i] > c->plan.nsend || recv_offset[i] + nstrips[i] > c->plan.nrecv) {
-      set_error("comm_init: peer %d (rank %d, strips %d at %d / %d) does not fit the halo plan (%d sent, %d received): "
-                "call cup2d_halo_plan first", i, peer_rank[i], nstrips[i], send_offset[i], recv_offset[i], c->plan.nsend, c->plan.nrecv);
+    if (peer_rank[i] < 0 || peer_rank[i] >= nranks || nstrips[i] < 0 || nstrips_recv[i] < 0 || send_offset[i] < 0 || recv_offset[i] < 0 ||
+        send_offset[i] + nstrips[i] > c->plan.nsend || recv_offset[i] + nstrips_recv[i] > c->plan.nrecv) {
+      set_error("comm_init: peer %d (rank %d, strips %d at %d out, %d at %d in) does not fit the halo plan (%d sent, %d received): "
+                "call cup2d_halo_plan first", i, peer_rank[i], nstrips[i], send_offset[i], nstrips_recv[i], recv_offset[i], c->plan.nsend, c->plan.nrecv);
       return CUP2D_ERR_ARG;
     }
   if (c->rccl) CUP2D_TRY(comm_finalize_impl(c));
@@ -248,9 +251,9 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
   rc->nranks = nranks;
   rc->rank = rank;
   for (int i = 0; i < npeers; i++) {
-    if (nstrips[i] == 0) continue;
+    if (nstrips[i] == 0 && nstrips_recv[i] == 0) continue;
     rc->peer.push_back(peer_rank[i]); rc->soff.push_back(send_offset[i]);
-    rc->roff.push_back(recv_offset[i]); rc->cnt.push_back(nstrips[i]);
+    rc->roff.push_back(recv_offset[i]); rc->cnt.push_back(nstrips[i]); rc->rcnt.push_back(nstrips_recv[i]);
   }
   // widest message: whole blocks of two Krylov vectors = 128 doubles per strip (the WENO halo is 3 x 8 x 2 = 48)
   const size_t strip = 2 * BC;

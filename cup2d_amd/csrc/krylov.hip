@@ -659,7 +659,10 @@ int matrix_exchange(cup2d_ctx *c, double *vec) {
     hipLaunchKernelGGL(k_gather, dim3(grid), dim3(WG), 0, c->stream, vec, M.d_gather, c->d_send, M.ngather);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
-  if (c->exchange(c->comm_user, c->d_send, vec + (size_t)c->nblocks * BC, 1, c->stream) != 0) {
+  // the gather list is the halo plan's send blocks, whole (adapted grids on N ranks): the message unit is a block, the
+  // transports count strips of the plan; otherwise single entries (cuda.h's send_pack_idx_ protocol)
+  const bool whole_blocks = c->plan.nsend > 0 && M.ngather == c->plan.nsend * BC && M.halo == c->plan.nrecv * BC;
+  if (c->exchange(c->comm_user, c->d_send, vec + (size_t)c->nblocks * BC, whole_blocks ? BC : 1, c->stream) != 0) {
     set_error("exchange callback failed");
     return CUP2D_ERR_COMM;
   }

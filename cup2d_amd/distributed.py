@@ -128,10 +128,14 @@ class TorchComm:
         ops = self._ops.get(key)
         if ops is None:
             ops = []
-            for peer, soff, roff, n in self.topo.peers:
-                ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer, self.group))
-            for peer, soff, roff, n in self.topo.peers:
-                ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer, self.group))
+            for pr in self.topo.peers:  # (peer, send offset, receive offset, strips out[, strips in])
+                peer, roff, n = pr[0], pr[2], pr[4] if len(pr) > 4 else pr[3]
+                if n:
+                    ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer, self.group))
+            for pr in self.topo.peers:
+                peer, soff, n = pr[0], pr[1], pr[3]
+                if n:
+                    ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer, self.group))
             self._ops[key] = ops
         return dist.batch_isend_irecv(ops) if ops else []
 
@@ -222,9 +226,9 @@ class DistributedSimulation(Simulation):
                 _l.check(self.L.cup2d_comm_unique_id(token), "comm_unique_id")
             box = [token.raw]
             dist.broadcast_object_list(box, src=0)  # the only thing torch.distributed moves for this simulation (default group)
-            peers = np.asarray([(p, so, ro, n) for p, so, ro, n in t.peers], dtype=np.int32).reshape(-1, 4)
+            peers = np.asarray([tuple(p)[:4] for p in t.peers], dtype=np.int32).reshape(-1, 4)
             cols = [np.ascontiguousarray(peers[:, k]) for k in range(4)]
-            _l.check(self.L.cup2d_comm_init(self._ctx, world, rank, box[0], len(t.peers), *[c.ctypes.data_as(vp) for c in cols]),
+            _l.check(self.L.cup2d_comm_init(self._ctx, world, rank, box[0], len(t.peers), *[c.ctypes.data_as(vp) for c in cols], None),
                      "comm_init")
             return
         self.comm = TorchComm(self.topo, mode, device, group=group)

@@ -211,6 +211,19 @@ int cup2d_set_gather(cup2d_ctx *ctx, int nsend, const int32_t *idx);
 typedef enum { CUP2D_AMR_WALL = 0, CUP2D_AMR_SAME = 1, CUP2D_AMR_COARSER = 2, CUP2D_AMR_FINER = 3 } cup2d_amr_kind;
 int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
                   const int32_t *half);
+/* Adapted grids on N ranks (BASELINE.json configs[4]; the reference: contiguous Hilbert ranges per rank main.cpp:6494-6504,
+ * remote blocks through the synchroniser 1971-2142, 2582-2684, flux faces 1819-1825).  A rank's context holds its owned
+ * blocks plus GHOST blocks (nghost of cup2d_create) = copies of every remote block its kernels read: the face neighbours
+ * of its blocks and, across a coarser neighbour, that neighbour's tangential neighbours (two rings).  The tables of
+ * cup2d_set_amr then cover owned + ghost blocks (level[nblocks + nghost], ...; sides of a ghost block whose neighbour the
+ * rank does not hold: CUP2D_AMR_WALL).  With a halo plan that lists whole blocks (cup2d_halo_plan: owned blocks to send,
+ * ghost blocks to receive, face 0) and a communicator (cup2d_comm_init / cup2d_set_comm), every block operator first
+ * refreshes the ghost copies of the field it reads (whole blocks), the flux-correction face arrays of fine blocks travel
+ * to the rank that owns the coarse side, reductions go over the ranks, and cup2d_poisson_solve takes an assembled operator
+ * whose columns >= 64 * nblocks address the ghost blocks' cells in ghost order (cup2d_set_matrix_coo with
+ * halo = 64 * nghost; cup2d_set_gather listing the 64 cells of every sent block in plan order).
+ * cup2d_amr_set_finest_level: the finest level present on ANY rank (dt uses the finest cell size, main.cpp:6580-6583). */
+int cup2d_amr_set_finest_level(cup2d_ctx *ctx, int level_finest);
 
 /* The Poisson matrix the reference assembles on an adapted grid (the serial host loop main.cpp:7034-7112 with
  * Solver::makeFlux / interpolate / D1 / D2, main.cpp:5915-5997), from the topology tables of cup2d_set_amr.  Host-side,
@@ -331,8 +344,8 @@ int cup2d_penalize(cup2d_ctx *ctx, double lambda, double dt, const double *uvw);
  *
  * cup2d_comm_unique_id: one rank creates the rendezvous token (two ncclUniqueIds: exchange and reduction communicators)
  *   and hands the bytes to every rank by whatever it has (MPI_Bcast, a file, torch.distributed's store).
- * cup2d_comm_init: collective over all ranks, after cup2d_halo_plan.  Peer p exchanges nstrips[p] strips with rank
- *   peer_rank[p]: entries [send_offset[p], +nstrips[p]) of the plan's send list go out, entries [recv_offset[p], ..) of its
+ * cup2d_comm_init: collective over all ranks, after cup2d_halo_plan.  Peer p = rank peer_rank[p]: entries
+ *   [send_offset[p], +nstrips[p]) of the plan's send list go out to it, entries [recv_offset[p], +nstrips_recv[p]) of its
  *   receive list come in; both ends enumerate a link's strips in the same order.  The library owns the message buffers
  *   and the communication stream; it installs itself where cup2d_set_comm installs callbacks.
  * cup2d_halo_exchange: pack, exchange, unpack of the ghost strips of a field (width cell layers, 1..8) -- sync1 of
@@ -341,7 +354,8 @@ int cup2d_penalize(cup2d_ctx *ctx, double lambda, double dt, const double *uvw);
 #define CUP2D_COMM_ID_BYTES 256
 int cup2d_comm_unique_id(void *id_bytes /* [CUP2D_COMM_ID_BYTES] */);
 int cup2d_comm_init(cup2d_ctx *ctx, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
-                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips);
+                    const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips,
+                    const int32_t *nstrips_recv /* NULL: as many come in as go out (same-level faces); adapted grids differ */);
 int cup2d_comm_finalize(cup2d_ctx *ctx);
 int cup2d_comm_stats(cup2d_ctx *ctx, int *nranks, int *npeers, long long *exchanges, long long *allreduces,
                      long long *allgathers);

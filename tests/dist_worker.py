@@ -175,12 +175,91 @@ def run_gpu(rank, world, px, py, nbx, nby):
     sim.close()
 
 
+def run_amr_gpu(rank, world):
+    """BASELINE.json configs[4] on N ranks sharing the one GPU (gloo, host-staged): the three-level golden grid split into
+    contiguous Hilbert ranges; every block operator on a rank's owned blocks (ghost blocks refreshed whole, flux-correction
+    faces exchanged) equals the reference's own functors bit for bit -- the same golden vectors the single-GPU test uses --
+    a time step lands on the single-context step, and a regrid across the ranks reproduces the single-context regrid."""
+    import torch.distributed as dist
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    from cup2d_amd.amr_dist import DistributedAmrSimulation
+    F = dict(np.load(os.path.join(ROOT, "tests", "golden", "amr_functors.npz")))
+    G = AmrBlockGrid(F["blocks"])
+    dt = float(F["dt"])
+    with DistributedAmrSimulation(G, nu=float(F["nu"]), device=0) as s:
+        lo, hi = s.part.lo, s.part.hi
+        own = slice(lo, hi)
+        s.set_math(True)
+        s.set_field(L.POLD, F["pold"][own])
+        s.set_field(L.TMP, F["tmp_in"][own])
+        s.laplacian_sub()  # ghosts of pold + the fine faces of remote blocks
+        assert np.array_equal(s.get_field(L.TMP), F["tmp_out"][own]), "laplacian_sub rank %d" % rank
+        s.set_field(L.VEL, F["vel"][own])
+        s.vorticity()
+        assert np.array_equal(s.get_field(L.TMP), F["vort"][own]), "vorticity rank %d" % rank
+        s.set_field(L.TMPV, F["udef"][own])
+        s.set_field(L.CHI, F["chi"][own])
+        s.pressure_rhs(dt)
+        assert np.array_equal(s.get_field(L.TMP), F["prhs"][own]), "pressure_rhs rank %d" % rank
+        s.set_field(L.PRES, F["pres"][own])
+        s.pressure_correction(dt)
+        assert np.array_equal(s.get_field(L.TMPV), F["pcorr"][own]), "pressure_correction rank %d" % rank
+        s.set_field(L.VEL, F["vel"][own])
+        s.advect_diffuse_rhs(dt)  # halo-3 tile: two rings of ghost blocks, dim-2 face exchange
+        assert np.array_equal(s.get_field(L.TMPV), F["advdiff"][own]), "advect_diffuse rank %d" % rank
+        # ---- a whole step against the single-context path on the same grid ----
+        with AmrSimulation(G, nu=float(F["nu"])) as ref:
+            ref.set_math(True)
+            ref.set_field(L.VEL, F["vel"])
+            ref.install_poisson_matrix()
+            s.set_field(L.VEL, F["vel"][own])
+            s.set_field(L.PRES, np.zeros((hi - lo, 64)))
+            s.set_field(L.POLD, np.zeros((hi - lo, 64)))
+            s.set_field(L.CHI, np.zeros((hi - lo, 64)))
+            s.set_field(L.TMPV, np.zeros((hi - lo, 64, 2)))
+            ref.set_field(L.VEL, F["vel"])
+            for f in (L.PRES, L.POLD, L.CHI):
+                ref.set_field(f, np.zeros((G.nblocks, 64)))
+            ref.set_field(L.TMPV, np.zeros((G.nblocks, 64, 2)))
+            rr = ref.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=400)
+            vref, pref = ref.get_field(L.VEL), ref.get_field(L.PRES)
+            s.install_poisson_matrix()
+            r = s.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=400)
+            assert r["dt"] == rr["dt"], (r, rr)
+            dv, dp = np.abs(s.get_field(L.VEL) - vref[own]).max(), np.abs(s.get_field(L.PRES) - pref[own]).max()
+            assert dv < 1e-8 and dp < 1e-7, (rank, dv, dp, r, rr)
+            # ---- regrid across the ranks = the single-context regrid (same leaves, bit-identical fields) ----
+            ref.set_field(L.VEL, F["vel"])
+            s.set_field(L.VEL, F["vel"][own])
+            changed_ref = ref.adapt(1.0, 0.2, 5)
+            blocks_ref, vel_ref = ref.grid.blocks.copy(), ref.get_field(L.VEL)
+        changed = s.adapt(1.0, 0.2, 5)
+        assert changed == changed_ref
+        assert np.array_equal(s.global_grid.blocks, blocks_ref)
+        assert np.array_equal(s.get_field(L.VEL), vel_ref[s.part.lo:s.part.hi])
+        # the re-partitioned grid is balanced to one block and still steps
+        counts = [None] * world
+        dist.all_gather_object(counts, s.part.nowned)
+        assert max(counts) - min(counts) <= 1 and sum(counts) == len(blocks_ref)
+        r2 = s.step(tol=1e-9, rel_tol=0.0, max_restarts=100, max_iter=400)
+        assert np.isfinite(r2["err"]) and r2["err"] <= 1e-9
+        assert not s.comm_errors, s.comm_errors
+    dist.barrier()
+
+
 def main():
     import torch.distributed as dist
     mode = sys.argv[1]
     px, py, nbx, nby = (int(a) for a in sys.argv[2:6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "amr":
+        run_amr_gpu(rank, world)
+        if rank == 0:
+            print("DIST_OK mode=amr world=%d" % world)
+        dist.destroy_process_group()
+        return
     assert world == px * py
     (run_cpu if mode == "cpu" else run_gpu)(rank, world, px, py, nbx, nby)
     if rank == 0:

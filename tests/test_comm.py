@@ -25,7 +25,7 @@ def test_comm_argument_checks_without_a_gpu():
     assert lib.cup2d_comm_unique_id(None) == -1  # CUP2D_ERR_ARG
     ids = ctypes.create_string_buffer(L.COMM_ID_BYTES)
     one = (ctypes.c_int32 * 1)(0)
-    assert lib.cup2d_comm_init(None, 1, 0, ids, 0, None, None, None, None) == -1  # null context
+    assert lib.cup2d_comm_init(None, 1, 0, ids, 0, None, None, None, None, None) == -1  # null context
     assert b"null context" in lib.cup2d_last_error()
     assert lib.cup2d_comm_finalize(None) == -1
     assert lib.cup2d_halo_exchange(None, L.VEL, 3) == -1
@@ -64,7 +64,7 @@ def _self_periodic_sim(nbx, nby):
     roff = np.asarray([0, nby], dtype=np.int32)
     cnt = np.asarray([nby, nby], dtype=np.int32)
     L.check(s.L.cup2d_comm_init(s.ctx, 1, 0, ids, 2, peer.ctypes.data_as(vp), soff.ctypes.data_as(vp), roff.ctypes.data_as(vp),
-                                cnt.ctypes.data_as(vp)), "comm_init")
+                                cnt.ctypes.data_as(vp), None), "comm_init")
     return s, g
 
 

@@ -38,3 +38,42 @@ def test_cartesian_dims():
 @pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 8, 16), (2, 1, 2, 16, 8), (4, 2, 2, 8, 8)])
 def test_decomposed_step_matches_global_oracle_gpu(world, px, py, nbx, nby):
     launch("gpu", world, px, py, nbx, nby, 29711 + world + px, timeout=900)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_amr_partition_plans_are_consistent(nranks):
+    """host planning of an adapted grid on N ranks (cup2d_amd/amr_dist.py): contiguous balanced Hilbert ranges, ghost sets
+    that cover every table entry the kernels read and every matrix column, send lists that are the peers' receive lists"""
+    import numpy as np
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid
+    from cup2d_amd.amr_dist import AmrPartition
+    G = AmrBlockGrid(np.load(os.path.join(ROOT, "tests", "golden", "amr_functors.npz"))["blocks"])
+    coo = G.poisson_coo()
+    parts = [AmrPartition(G, nranks, r, coo=coo) for r in range(nranks)]
+    assert sum(P.nowned for P in parts) == G.nblocks and max(P.nowned for P in parts) - min(P.nowned for P in parts) <= 1
+    nnz = 0
+    for P in parts:
+        for (p, so, ro, ns, nr) in P.peers:
+            Q = parts[p]
+            q = [x for x in Q.peers if x[0] == P.rank][0]
+            assert (ns, nr) == (q[4], q[3])
+            assert np.array_equal(P.local_ids[P.send_block[so:so + ns]], Q.local_ids[Q.recv_block[q[2]:q[2] + q[4]]])
+        k = P.kind[:P.nowned]
+        assert np.array_equal(k, G.kind[P.lo:P.hi])  # nothing of an owned block's topology is lost
+        assert np.array_equal(P.local_ids[P.nbr2[:P.nowned][k != L.AMR_WALL][:, 0]], G.nbr2[P.lo:P.hi][k != L.AMR_WALL][:, 0])
+        # across a coarser neighbour the halo-3 tile reads that neighbour's tangential sides: present for ghosts too
+        for b in range(P.nowned):
+            for s in range(4):
+                if k[b, s] == L.AMR_COARSER:
+                    n0 = P.nbr2[b, s, 0]
+                    assert np.array_equal(P.kind[n0], G.kind[P.local_ids[n0]]), "coarse neighbour's table"
+        assert P.col.max() < 64 * (P.nowned + P.nghost) and P.row.max() < 64 * P.nowned
+        nnz += len(P.val)
+    assert nnz == len(coo[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world):
+    launch("amr", world, 0, 0, 0, 0, 29811 + world, timeout=900)

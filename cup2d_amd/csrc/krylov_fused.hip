@@ -217,6 +217,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   const int hf = lane >> 5, hl = lane & 31, c0 = 2 * hl, px = c0 & 7, py = hl >> 2;
   const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
   const double beta = sc->beta;
+  // restart: p' = rhat = r (cuda.cu:461-476).  The first iteration of a solve has p = nu = 0 (cuda.cu:436-437), so
+  // p' = beta (0 - omega 0) + r = r as well: the two vectors are not read as zeros, they are not looked at -- the solve
+  // does not fill them
+  const bool fresh = MODE == 0 && sc->iter == 0;
   const bool restart = MODE == 0 && sc->restart_flag != 0;
   constexpr int NDOT = MODE == 0 ? 1 : 2;
   double acc[NDOT];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   // v at one cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
   const auto form_v = [&](double a, double b, double c) -> double {
     if (MODE == 0) {
-      if (restart) return c;
+      if (restart || fresh) return c;
       double v = a + c1 * b;
       v = v * beta;
       return v + c;
@@ -691,9 +695,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     CUP2D_TRY(launch_init_residual(c, x, b, &GP));
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
-  // p, nu start at zero (cuda.cu:436-437); so does the accumulated correction
-  CUP2D_TRY(launch_zero(c, c->d_p, gb ? (size_t)c->ntotal * BC : n));
-  CUP2D_TRY(launch_zero(c, c->d_nu, gb ? (size_t)c->ntotal * BC : n));
+  // p, nu start at zero (cuda.cu:436-437): the first AB sweep knows (k_fused: fresh) and does not use them; the
+  // accumulated correction starts at zero and its first buffer may remain the best iterate
   CUP2D_TRY(launch_zero(c, c->d_y, n));
   if (gb) CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
 

@@ -665,7 +665,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   init.max_restarts = max_restarts; init.max_iter = max_iter;
   *c->h_sc = init;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->h_sc, sizeof init, hipMemcpyHostToDevice, c->stream));
+  // sweep E: two workgroups per CU.  Its last workgroup finishes the reduction (arrive_last), and every workgroup pays an
+  // agent-scope ticket for that: 2048 workgroups cost the sweep 8 us more than 512 (measured 161.5 / 161.7 / 152.9 / 152.9 us
+  // at 2048 / 1024 / 512 / 256 workgroups, 4096^2)
   int gridE = (int)((n / 2 + WG - 1) / WG);
+  static const int capE = [] { const char *e = getenv("CUP2D_GRID_E"); return e ? atoi(e) : 0; }();
+  const int cap = capE > 0 ? capE : 2 * (c->num_cus > 0 ? c->num_cus : 256);
+  if (gridE > cap) gridE = cap;
   if (gridE > c->grid) gridE = c->grid;
   if (!c->fused_lds_opt_in) {  // > 64 KiB of LDS is an opt-in per kernel AND device: remembered per context
     const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, 0>), reinterpret_cast<const void *>(&k_fused<0, 1>),

@@ -46,19 +46,33 @@ static RcclApi *rccl_api() {
   static bool tried = false;
   if (tried) return api.handle ? &api : nullptr;
   tried = true;
-  // a librccl the process has mapped already (PyTorch ships its own, without a soname) is reused: a second copy would be
-  // another half gigabyte to page in and a second set of device code objects
-  std::string loaded;
-  dl_iterate_phdr(
-      [](struct dl_phdr_info *info, size_t, void *out) -> int {
-        if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) {
-          *static_cast<std::string *>(out) = info->dlpi_name;
-          return 1;
-        }
-        return 0;
-      },
-      &loaded);
-  const char *names[] = {getenv("CUP2D_RCCL_LIB"), loaded.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // The RCCL that is opened must sit on the SAME HIP runtime this library is linked to (the streams, events and
+  // buffers handed to it are that runtime's): the librccl next to it.  A process may have mapped another pair already --
+  // PyTorch ships libamdhip64.so / librccl.so of its own, without sonames, so the loader treats them as different
+  // libraries -- and RCCL on that other runtime would see none of this library's streams.
+  std::string sib1, sib2;
+  {
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t cut = dir.rfind('/');
+      if (cut != std::string::npos) {
+        dir.resize(cut + 1);
+        sib1 = dir + "librccl.so.1";
+        sib2 = dir + "librccl.so";
+      }
+    }
+  }
+  // RCCL itself looks the HSA runtime up BY NAME (dlopen("libhsa-runtime64.so"), rocmwrap.cc) to ask it about dmabuf
+  // support; in a process that has PyTorch imported but not yet on the GPU that name is PyTorch's own, uninitialised,
+  // copy and the query fails with HSA_STATUS_ERROR_NOT_INITIALIZED.  hsa_init() is reference-counted: bring that copy up.
+  if (void *hsa = dlopen("libhsa-runtime64.so", RTLD_NOW | RTLD_NOLOAD)) {
+    auto get = reinterpret_cast<int (*)(int, void *)>(dlsym(hsa, "hsa_system_get_info"));
+    auto init = reinterpret_cast<int (*)()>(dlsym(hsa, "hsa_init"));
+    unsigned short major = 0;
+    if (get && init && get(0 /* HSA_SYSTEM_INFO_VERSION_MAJOR */, &major) == 0x100B /* not initialised */) init();
+  }
+  const char *names[] = {getenv("CUP2D_RCCL_LIB"), sib1.c_str(), sib2.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
   for (const char *n : names)
     if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;

@@ -96,3 +96,19 @@ def test_cpp_host_driver_fails_loudly_without_gpu():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "-n", "16", "-steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and b"cup2d_create" in r.stderr and b"step 1" not in r.stdout
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` starts its own ranks; on a node with fewer GPUs it says so and exits 2 (no hang, no
+    partial launch).  Here: no GPU at all."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("a node with two GPUs launches the ranks for real")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=300)
+    assert r.returncode == 2 and b"GPU(s) are visible" in r.stderr and not r.stdout.strip()

@@ -132,3 +132,37 @@ def test_one_rank_through_the_communicator_equals_the_plain_context(gpu_lib, ora
             assert st["nranks"] == 1 and st["peers"] == 0 and st["allgathers"] >= 90
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_one_rank_amr_through_the_communicator_equals_the_plain_context(gpu_lib, oracle, tmp_path):
+    """an adapted grid on 'one of one' ranks with the in-library communicator: no ghost blocks, but every reduction of the
+    AMR step (max|u|, the volume-weighted pressure means, the solver's sums and norms on the assembled operator) goes through
+    RCCL -- the step equals the plain context's bit for bit"""
+    import os
+    import torch.distributed as dist
+    from conftest import golden
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    from cup2d_amd.amr_dist import DistributedAmrSimulation
+    F = golden("amr_functors.npz")
+    G = AmrBlockGrid(F["blocks"])
+    with AmrSimulation(G, nu=float(F["nu"])) as ref:
+        ref.set_math(True)
+        ref.set_field(L.VEL, F["vel"])
+        ref.install_poisson_matrix()
+        r0 = ref.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=300)
+        v0, p0 = ref.get_field(L.VEL), ref.get_field(L.PRES)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", GLOO_SOCKET_IFNAME="lo",
+                      NCCL_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with DistributedAmrSimulation(G, nu=float(F["nu"]), comm="rccl") as s:
+            assert s.part.nghost == 0 and s.part.nowned == G.nblocks
+            s.set_math(True)
+            s.set_field(L.VEL, F["vel"])
+            s.install_poisson_matrix()
+            r1 = s.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=300)
+            assert r1["dt"] == r0["dt"] and r1["iters"] == r0["iters"] and r1["err"] == r0["err"]
+            assert np.array_equal(s.get_field(L.VEL), v0) and np.array_equal(s.get_field(L.PRES), p0)
+    finally:
+        dist.destroy_process_group()

@@ -102,6 +102,25 @@ class AmrSimulation(BodyOps):
         self._solver = (bool(fused), bool(finish_in_kernel))
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)), "set_solver")
 
+    def last_solver(self):
+        """'fused' or 'sweeps': what the last poisson_solve ran (the hybrid assembled operator takes the tile-fused sweeps)"""
+        k = ctypes.c_int()
+        _l.check(self.L.cup2d_get_last_solver(self._ctx, ctypes.byref(k)), "get_last_solver")
+        return "fused" if k.value == _l.SOLVER_FUSED else "sweeps"
+
+    def poisson_solve(self, tol=1e-9, rel_tol=0.0, max_restarts=100, max_iter=1000):
+        """b = TMP, x0 = PRES -> PRES on the installed operator (cuda.cu:403-548)"""
+        it, rs, e, e0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _l.check(self.L.cup2d_poisson_solve(self._ctx, tol, rel_tol, max_restarts, max_iter, ctypes.byref(it), ctypes.byref(rs),
+                                            ctypes.byref(e), ctypes.byref(e0)), "poisson_solve")
+        return dict(iters=it.value, restarts=rs.value, err=e.value, err_init=e0.value)
+
+    def matrix_stats(self):
+        """how the installed operator is applied (include/cup2d_hip.h cup2d_matrix_stats)"""
+        a, b, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        _l.check(self.L.cup2d_matrix_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(e)), "matrix_stats")
+        return dict(plain_blocks=a.value, general_tile_blocks=b.value, stored_entries=e.value)
+
     def set_timing(self, on=True):
         self._timing = int(on)
         _l.check(self.L.cup2d_set_timing(self._ctx, int(on)), "set_timing")

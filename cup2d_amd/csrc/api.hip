@@ -620,7 +620,7 @@ int cup2d_clear_matrix(cup2d_ctx *c) {
   CUP2D_CHECK_CTX(c);
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
-  (void)hipFree(c->mat.d_reg);
+  (void)hipFree(c->mat.d_reg); (void)hipFree(c->mat.d_fnbr); (void)hipFree(c->mat.d_zmask); (void)hipFree(c->mat.d_tile0); (void)hipFree(c->mat.d_gen);
   c->mat = SellMatrix();
   return CUP2D_OK;
 }
@@ -743,7 +743,78 @@ int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *r
   M.nregular = nregular;
   M.entries = entries;
   M.halo = halo;
+  if (hybrid) {
+    // tables of the tile-fused sweeps (ctx.h SellMatrix): the tiling, which tiles are all plain, whose z the rows of the
+    // other tiles read
+    const int nbk = c->nblocks;
+    std::vector<int> plain_run((size_t)nbk + 1, 0);  // number of consecutive plain slices from s on
+    for (int s = nbk - 1; s >= 0; s--) plain_run[s] = stored(s) ? 0 : plain_run[s + 1] + 1;
+    const auto good = [&](int s) {  // 16 plain slices from s on with <= 16 neighbour slots outside the set
+      if (plain_run[s] < FUSED_TILE) return false;
+      int ring = 0;
+      for (int b = s; b < s + FUSED_TILE; b++)
+        for (int side = 0; side < 4; side++) {
+          const int32_t nb_ = reg[(size_t)4 * b + side];
+          ring += nb_ >= 0 && (nb_ < s || nb_ >= s + FUSED_TILE);
+        }
+      return ring <= FUSED_TILE;
+    };
+    std::vector<int32_t> tile0;
+    for (int s = 0; s < nbk;) {
+      tile0.push_back(s);
+      if (good(s)) { s += FUSED_TILE; continue; }
+      int e = s + 1;  // a chunk: up to the next good start, at most 16
+      while (e < nbk && e - s < FUSED_TILE && !good(e)) e++;
+      s = e;
+    }
+    tile0.push_back(nbk);
+    const int ntiles = (int)tile0.size() - 1;
+    std::vector<int32_t> fnbr(reg), gen;
+    M.h_zmask.assign((size_t)ntiles, 0);
+    M.h_slot.assign((size_t)nbk, 0);
+    for (int t = 0; t < ntiles; t++)
+      for (int s = tile0[t]; s < tile0[t + 1]; s++) M.h_slot[s] = t * FUSED_TILE + (s - tile0[t]);
+    const auto flag = [&](long long b) {
+      if (b >= 0 && b < nbk) M.h_zmask[(size_t)(M.h_slot[b] / FUSED_TILE)] |= 1 << (M.h_slot[b] % FUSED_TILE);
+    };
+    for (int t = 0; t < ntiles; t++) {
+      const int b0 = tile0[t], b1 = tile0[t + 1];
+      bool general = false;
+      for (int s = b0; s < b1; s++) general = general || stored(s);
+      if (!general) continue;
+      for (int s = b0; s < b1; s++) {
+        gen.push_back(s);
+        flag(s);
+        if (stored(s)) {
+          for (long long e = ptr[s]; e < ptr[s + 1]; e++) flag(ecol[e] >> 6);
+        } else {
+          for (int side = 0; side < 4; side++) flag(reg[(size_t)4 * s + side]);
+        }
+        for (int side = 0; side < 4; side++) fnbr[(size_t)4 * s + side] = FUSED_GENERAL;
+      }
+    }
+    M.ntiles = ntiles;
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_fnbr, fnbr.data(), fnbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_zmask, M.h_zmask.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_zmask, M.h_zmask.data(), M.h_zmask.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    M.ngen = (int)gen.size();
+    if (M.ngen) {
+      CUP2D_HIP_CHECK(hipMalloc(&M.d_gen, gen.size() * sizeof(int32_t)));
+      CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
   M.active = true;
+  return CUP2D_OK;
+}
+int cup2d_matrix_stats(cup2d_ctx *c, int *plain_blocks, int *general_tile_blocks, long long *stored_entries) {
+  CUP2D_CHECK_CTX(c);
+  if (!c->mat.active) { set_error("matrix_stats: no operator installed"); return CUP2D_ERR_ARG; }
+  if (plain_blocks) *plain_blocks = c->mat.nregular;
+  if (general_tile_blocks) *general_tile_blocks = c->mat.d_fnbr ? c->mat.ngen : c->nblocks;
+  if (stored_entries) *stored_entries = (long long)c->mat.entries;
   return CUP2D_OK;
 }
 int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
@@ -758,6 +829,13 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
   if (nsend) {
     CUP2D_HIP_CHECK(hipMalloc(&c->mat.d_gather, nsend * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(c->mat.d_gather, idx, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (c->mat.d_zmask) {  // the fused sweeps store z where it is read from memory: the gathered entries are
+    for (int i = 0; i < nsend; i++) {
+      const int32_t slot = c->mat.h_slot[(size_t)(idx[i] >> 6)];
+      c->mat.h_zmask[(size_t)(slot / FUSED_TILE)] |= 1 << (slot % FUSED_TILE);
+    }
+    CUP2D_HIP_CHECK(hipMemcpy(c->mat.d_zmask, c->mat.h_zmask.data(), c->mat.h_zmask.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   return CUP2D_OK;
 }

@@ -85,7 +85,22 @@ struct SellMatrix {
   int nregular = 0;
   int ngather = 0;             // send_buff_pack (cuda.cu:338-343): d_send[i] = vec[gather[i]]
   int32_t *d_gather = nullptr;
+  // The tile-fused sweeps on the hybrid form (krylov_fused.hip).  The slices are cut into TILES of <= 16 consecutive
+  // slices (tile t = slices [tile0[t], tile0[t+1])): 16 plain slices whose neighbours outside the set number <= 16 (an
+  // aligned 4x4 patch of a Hilbert-ordered level) are a tile wherever they start, what lies between such runs is cut
+  // into chunks.  A tile of plain slices is FUSED -- its z never leaves the chip --, one that holds a stored slice is
+  // GENERAL: the sweep forms v and z = P_inv v of its blocks, stores both, and a second launch (k_hyb_rows) applies the
+  // rows of the general tiles from z in memory.
+  int ntiles = 0;
+  int32_t *d_tile0 = nullptr;  // [ntiles + 1]
+  int32_t *d_fnbr = nullptr;   // [4 nblocks] k_fused's neighbour table: reg of a plain block, FUSED_GENERAL in a general tile
+  int32_t *d_zmask = nullptr;  // [ntiles] bit b: z of block b of the tile is read from memory by someone (stored to d_z)
+  int32_t *d_gen = nullptr;    // [ngen] the blocks of the general tiles
+  int ngen = 0;
+  std::vector<int32_t> h_zmask, h_slot;  // slot[b] = 16 tile + position; cup2d_set_gather adds the blocks other ranks read
 };
+constexpr int32_t FUSED_GENERAL = -3;
+constexpr int FUSED_TILE = 16;  // blocks per tile of the fused sweeps = N of v_mfma_f64_16x16x4_f64
 
 enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
 

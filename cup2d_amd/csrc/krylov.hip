@@ -538,26 +538,6 @@ __global__ __launch_bounds__(WG) void k_init_residual(const double *__restrict__
   workgroup_reduce_store<1, true>(m, partials, 2, poff);
 }
 
-// r = rhat = b - A x over all owned blocks on the neighbour table (the fused solver's entry): inner blocks
-// while the face strips of x are in flight, halo blocks after unpack (main.cpp:3035-3057).  *GP = number of
-// per-workgroup partials written.
-int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP) {
-  const int nb = c->nblocks;
-  const int n_in = overlapped(c) ? c->n_inner : nb, n_ha = nb - n_in;
-  const int G_in = n_in > 0 ? grid_for(c, n_in) : 0, G_ha = n_ha > 0 ? grid_for(c, n_ha) : 0;
-  CUP2D_TRY(exchange_begin(c, x, 1, 1));
-  if (n_in > 0)
-    hipLaunchKernelGGL(k_init_residual, dim3(G_in), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
-                       c->d_partials, 0, n_in, 0);
-  CUP2D_TRY(exchange_end(c, x, 1, 1));
-  if (n_ha > 0)
-    hipLaunchKernelGGL(k_init_residual, dim3(G_ha), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
-                       c->d_partials, n_in, n_ha, G_in);
-  CUP2D_HIP_CHECK(hipGetLastError());
-  *GP = G_in + G_ha;
-  return CUP2D_OK;
-}
-
 // ---- general sparse operator (sliced ELL, ctx.h SellMatrix) --------------------------------------
 // The same sweeps with y = A x taken from the assembled matrix instead of the 5-point stencil: what
 // the reference does with cusparseSpMV on its COO arrays (cuda.cu:344-402).  One wave per slice (= per
@@ -582,35 +562,7 @@ __global__ __launch_bounds__(WG) void k_sell(const double *__restrict__ x, doubl
   for (int g = gr.begin; g < gr.end; g += gr.stride) {
     const int s = g * WPG + wave;
     if (s < count) {
-      const long long base = sptr[s];
-      const int width = (int)((sptr[s + 1] - base) >> 6);
-      const int32_t *cp = col + base + lane;
-      const double *vp = val + base + lane;
-      double a = 0.0;
-      int k = 0;
-      const int4 rg = reg4[s];  // wave-uniform
-      if (rg.x != SELL_STORED) {
-        // a slice of plain same-level rows (ctx.h SellMatrix::d_reg): the 5-point sum straight from x, ghost = own
-        // cell at a wall (the row has no entry there and one neighbour less on the diagonal: the same number)
-        const int ix = lane & 7, iy = lane >> 3;
-        const double *own = x + (size_t)s * BC;
-        const double l0 = own[lane];
-        const double l1 = ix > 0 ? own[lane - 1] : rg.x >= 0 ? x[(size_t)rg.x * BC + iy * BS + (BS - 1)] : l0;
-        const double l2 = ix < BS - 1 ? own[lane + 1] : rg.y >= 0 ? x[(size_t)rg.y * BC + iy * BS] : l0;
-        const double l3 = iy > 0 ? own[lane - BS] : rg.z >= 0 ? x[(size_t)rg.z * BC + (BS - 1) * BS + ix] : l0;
-        const double l4 = iy < BS - 1 ? own[lane + BS] : rg.w >= 0 ? x[(size_t)rg.w * BC + ix] : l0;
-        a = l1 + l2 + l3 + l4 - 4 * l0;
-      }
-      for (; k + 4 <= width; k += 4) {  // four independent gathers in flight
-        const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
-        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        a = __builtin_fma(v0, x0, a);
-        a = __builtin_fma(v1, x1, a);
-        a = __builtin_fma(v2, x2, a);
-        a = __builtin_fma(v3, x3, a);
-      }
-      for (; k < width; k++) a = __builtin_fma(vp[k * 64], x[cp[k * 64]], a);
+      const double a = sell_row(x, s, lane, sptr, col, val, reg4);
       const size_t o = (size_t)s * BC + lane;
       if (MODE == 3) {
         const double rv = w[o] - a;
@@ -679,6 +631,36 @@ int launch_matvec(cup2d_ctx *c, double *x, double *y) {
   hipLaunchKernelGGL(k_sell<0>, dim3(grid_for(c, c->nblocks)), dim3(WG), 0, c->stream, x, y, nullptr, nullptr, M.d_ptr,
                      M.d_col, M.d_val, M.d_reg, nullptr, nullptr, c->nblocks, 0);
   CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
+// r = rhat = b - A x over all owned blocks on the neighbour table (the fused solver's entry): inner blocks
+// while the face strips of x are in flight, halo blocks after unpack (main.cpp:3035-3057).  *GP = number of
+// per-workgroup partials written.
+int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP) {
+  const int nb = c->nblocks;
+  if (c->mat.active) {  // assembled operator: halo entries of x, then one sweep over all slices
+    const SellMatrix &M = c->mat;
+    const int G = grid_for(c, nb);
+    CUP2D_TRY(matrix_exchange(c, x));
+    hipLaunchKernelGGL(k_sell<3>, dim3(G), dim3(WG), 0, c->stream, x, c->d_r, b, c->d_rhat, M.d_ptr, M.d_col, M.d_val, M.d_reg,
+                       c->d_sc, c->d_partials, nb, 0);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    *GP = G;
+    return CUP2D_OK;
+  }
+  const int n_in = overlapped(c) ? c->n_inner : nb, n_ha = nb - n_in;
+  const int G_in = n_in > 0 ? grid_for(c, n_in) : 0, G_ha = n_ha > 0 ? grid_for(c, n_ha) : 0;
+  CUP2D_TRY(exchange_begin(c, x, 1, 1));
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_init_residual, dim3(G_in), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                       c->d_partials, 0, n_in, 0);
+  CUP2D_TRY(exchange_end(c, x, 1, 1));
+  if (n_ha > 0)
+    hipLaunchKernelGGL(k_init_residual, dim3(G_ha), dim3(WG), 0, c->stream, x, b, c->d_r, c->d_rhat, c->d_nbr,
+                       c->d_partials, n_in, n_ha, G_in);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  *GP = G_in + G_ha;
   return CUP2D_OK;
 }
 

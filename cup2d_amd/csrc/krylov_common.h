@@ -69,6 +69,43 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
   }
 }
 
+// One row of the hybrid sliced-ELL operator (ctx.h SellMatrix): slice s (= block; wave-uniform), lane = row.  Shared by
+// k_sell (krylov.hip) and k_hyb_rows (krylov_fused.hip).
+static __device__ __forceinline__ double sell_row(const double *__restrict__ x, int s, int lane,
+                                                  const long long *__restrict__ sptr, const int32_t *__restrict__ col,
+                                                  const double *__restrict__ val, const int4 *__restrict__ reg4) {
+  const long long base = sptr[s];
+  const int width = (int)((sptr[s + 1] - base) >> 6);
+  const int32_t *cp = col + base + lane;
+  const double *vp = val + base + lane;
+  double a = 0.0;
+  int k = 0;
+  const int4 rg = reg4[s];  // wave-uniform
+  if (rg.x != SELL_STORED) {
+    // a slice of plain same-level rows (ctx.h SellMatrix::d_reg): the 5-point sum straight from x, ghost = own
+    // cell at a wall (the row has no entry there and one neighbour less on the diagonal: the same number)
+    const int ix = lane & 7, iy = lane >> 3;
+    const double *own = x + (size_t)s * BC;
+    const double l0 = own[lane];
+    const double l1 = ix > 0 ? own[lane - 1] : rg.x >= 0 ? x[(size_t)rg.x * BC + iy * BS + (BS - 1)] : l0;
+    const double l2 = ix < BS - 1 ? own[lane + 1] : rg.y >= 0 ? x[(size_t)rg.y * BC + iy * BS] : l0;
+    const double l3 = iy > 0 ? own[lane - BS] : rg.z >= 0 ? x[(size_t)rg.z * BC + (BS - 1) * BS + ix] : l0;
+    const double l4 = iy < BS - 1 ? own[lane + BS] : rg.w >= 0 ? x[(size_t)rg.w * BC + ix] : l0;
+    a = l1 + l2 + l3 + l4 - 4 * l0;
+  }
+  for (; k + 4 <= width; k += 4) {  // four independent gathers in flight
+    const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
+    const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+    const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+    a = __builtin_fma(v0, x0, a);
+    a = __builtin_fma(v1, x1, a);
+    a = __builtin_fma(v2, x2, a);
+    a = __builtin_fma(v3, x3, a);
+  }
+  for (; k < width; k++) a = __builtin_fma(vp[k * 64], x[cp[k * 64]], a);
+  return a;
+}
+
 // Finish of a fused reduction by ONE workgroup: sums the per-workgroup partials of slots [0,nsum) and
 // takes the max of slot 2, in a fixed order (thread t takes partials t, t+256, ...; then a binary tree),
 // so the result does not depend on which workgroup runs it.  fused_stage >= 0: also runs the scalar

@@ -32,7 +32,7 @@
 
 namespace cup2d {
 
-constexpr int TB = 16;   // blocks per tile
+constexpr int TB = FUSED_TILE;   // blocks per tile
 constexpr int XS = 66;   // LDS stride of one block in the staging tile: the A-operand reads of a half-wave
                          // (block = lane%16, k = 4ks + lane/16) then fall on 32 distinct 8-byte banks
 // Waves per workgroup (ONE workgroup per CU).  8: two waves per SIMD, 256 registers each.  4: one wave per SIMD with the
@@ -189,12 +189,16 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 // accesses (one cell per lane) both sweeps sat at the rate the vector memory path sustains for 8-byte requests
 // (5.4-6.1 TB/s of L2-side traffic, ring re-reads included; SQ_WAIT_INST_ANY 44 %: issue stalled behind a full memory
 // pipeline) although HBM had room; 16-byte requests halve the instructions per byte.
-template <int MODE, int MERGE>
+// HYB: the hybrid assembled operator (ctx.h SellMatrix): nbr = its d_fnbr.  A tile whose slots read FUSED_GENERAL holds a
+// slice with stored rows: the wave forms v and z = P_inv v of its blocks and stores them (v as always, z to zg), the rows
+// themselves are applied by k_hyb_rows from z in memory; a fused tile also stores the z of the blocks zmask names (the
+// ones those rows read).  Ring entries work as ever: the neighbour of a plain block is a block with p, nu, r in memory.
+template <int MODE, int MERGE, bool HYB = false>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                   int first, int count, int poff, int nowned,
-                                                  const double *__restrict__ zg, double *red, unsigned *ticket,
-                                                  int dbg) {
+                                                  double *__restrict__ zg, double *red, unsigned *ticket,
+                                                  int dbg, const int32_t *__restrict__ zmask, const int32_t *__restrict__ tile0) {
   // blocks [first, first + count) of the nowned owned blocks; neighbour ids >= nowned are ghost blocks whose z
   // edges were computed by their owner rank (k_fused_edges) and unpacked into zg
   extern __shared__ __attribute__((aligned(16))) double fsm[];
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   };
 
   // tiles of 16 blocks over the waves of the persistent grid, contiguous per XCD (workgroup w runs on XCD w % 8)
-  const int ntiles = (count + TB - 1) / TB;
+  const int ntiles = HYB ? count : (count + TB - 1) / TB;  // HYB: count = number of tiles of the table tile0
   int t_begin, t_end, t_stride;
   {
     const int G = gridDim.x, w = blockIdx.x;
@@ -261,25 +265,32 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
   const int last = first + count;
   const auto load_nb = [&](int t) -> int {
+    if constexpr (HYB) {
+      if (t >= t_end) return CUP2D_WALL;
+      const int b0 = uniform(tile0[t]), nv = uniform(tile0[t + 1]) - b0;
+      return si < nv ? nbr[4 * (b0 + si) + ss] : CUP2D_WALL;
+    }
     const int b = first + t * TB + si;
     return (t < t_end && b < last) ? nbr[4 * b + ss] : CUP2D_WALL;
   };
   // state of a tile: its blocks, this lane's neighbour slot, the ring list (in LDS) it was classified into
   struct Tile {
-    int b0, nvalid, nb, nring, npass;
-    bool is_ring;
+    int b0, nvalid, nb, nring, npass, zm;
+    bool is_ring, gen;
   };
   // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the list
   // of the previous tile: call only when that one is dead)
   const auto classify = [&](int t, int nb) -> Tile {
     Tile T;
-    T.b0 = first + t * TB;
-    T.nvalid = min(TB, last - T.b0);
+    T.b0 = HYB ? uniform(tile0[t]) : first + t * TB;
+    T.nvalid = HYB ? uniform(tile0[t + 1]) - T.b0 : min(TB, last - T.b0);
     T.nb = nb;
     T.is_ring = si < T.nvalid && nb >= 0 && nb < nowned && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (dbg & 1) ? 0 : __popcll(rmask);  // dbg 1: timing experiment without the ring -- WRONG results
     T.npass = (T.nring + TB - 1) / TB;
+    T.gen = HYB && __ballot(si < T.nvalid && nb == FUSED_GENERAL) != 0ull;
+    T.zm = HYB ? uniform(zmask[t]) : 0;
     if (T.is_ring) {
       const int slot = __popcll(rmask & ((1ull << lane) - 1ull));
       L.ring_nb[slot] = nb;
@@ -393,6 +404,16 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         wave_lds_sync();
       }
       tile_precond(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      if constexpr (HYB) {
+        if (is_tile && T.zm != 0) {  // z of the blocks somebody reads from memory
+#pragma unroll
+          for (int i = 0; i < TB / 2; i++) {
+            const int blk = 2 * i + hf;
+            if (blk < nvalid && ((T.zm >> blk) & 1))
+              reinterpret_cast<double2 *>(zg)[((size_t)(b0 + blk) * BC + c0) >> 1] = *reinterpret_cast<const double2 *>(L.S + blk * XS + c0);
+          }
+        }
+      }
       if (!is_tile) {
         // entry e feeds slot dst = block*4 + side with the OPPOSITE edge of the neighbour block
         const int ne = min(TB, T.nring - j * TB);
@@ -409,8 +430,13 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
+    if (HYB && T.gen) {  // rows with stored entries in this tile: k_hyb_rows applies them
+      wave_lds_sync();
+      T = N;
+      continue;
+    }
     if (si < nvalid && !T.is_ring) {
-      if (T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
+      if (!HYB && T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
         const double *g = zg + (size_t)T.nb * BC;
 #pragma unroll
         for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = g[edge_cell(ss ^ 1, q)];
@@ -516,6 +542,41 @@ __global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double
   }
 }
 
+// ---- the rows of the general tiles of the hybrid operator (k_fused HYB) -----------------------------
+// y = A z for the listed blocks, z from memory (k_fused stored it for exactly the blocks these rows read; the halo entries
+// of other ranks arrive in between), with the dot products of the sweep:  MODE 0: y = nu', w = rhat;  MODE 1: y = t,
+// w = s = r - alpha nu' formed again.  One wave per block, lane = row (krylov_common.h sell_row).  The partials go behind
+// the poff partials of k_fused; MERGE as there: the last workgroup finishes the reduction of BOTH launches.
+constexpr int RWAVES = 16, RWG = RWAVES * 64;  // one wave per block; wide workgroups: few tickets (arrive_last), many waves
+template <int MODE, int MERGE>
+__global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, double *__restrict__ y,
+                                                 const double *__restrict__ w0, const double *__restrict__ w1,
+                                                 const long long *__restrict__ sptr, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ reg,
+                                                 const int32_t *__restrict__ list, int nlist, KrylovScalars *sc,
+                                                 double *partials, int poff, double *red, unsigned *ticket) {
+  if (sc->status != 0) return;
+  constexpr int NDOT = MODE == 0 ? 1 : 2;
+  const int4 *reg4 = (const int4 *)reg;
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const double c1 = -sc->alpha;
+  double acc[NDOT];
+#pragma unroll
+  for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
+  for (int e = blockIdx.x * RWAVES + wave; e < nlist; e += gridDim.x * RWAVES) {
+    const int s = uniform(list[e]);
+    const double a = sell_row(z, s, lane, sptr, col, val, reg4);
+    const size_t o = (size_t)s * BC + lane;
+    y[o] = a;
+    const double w = MODE == 0 ? w0[o] : w0[o] + c1 * w1[o];
+    acc[0] = __builtin_fma(a, w, acc[0]);
+    if constexpr (NDOT == 2) acc[1] = __builtin_fma(a, a, acc[1]);
+  }
+  fused_reduce_store<RWAVES, NDOT, MERGE != 0>(acc, partials + poff);
+  if (MERGE && arrive_last(ticket))
+    finish_reduce<true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr);
+}
+
 // ---- sweep E in the preconditioned space ---------------------------------------------------------
 // y' = y + alpha p + omega s ; r = s - omega t ; partial(rhat.r, r.r), max|r|   (cuda.cu:498, 520-525, 440-442
 // with x = x0 + P_inv y).  y lives in three buffers: y' goes to the one that holds neither y nor the best
@@ -564,11 +625,16 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, doubl
     finish_reduce<true>(partials, gridDim.x, 2, 1, red, sc, MERGE == 1 ? 3 : -1, MERGE == 1 ? host_status : nullptr);
 }
 
-bool fused_supported(const cup2d_ctx *c) { return !c->mat.active && (c->nghost == 0 || c->exchange != nullptr); }
+// the same-level stencil on one or N ranks, or the assembled operator in its hybrid form (one or N ranks: the halo
+// columns of its rows are z entries, exchanged between the two launches of a sweep)
+bool fused_supported(const cup2d_ctx *c) {
+  if (c->mat.active) return c->mat.d_fnbr != nullptr && (c->mat.halo == 0 || c->exchange != nullptr);
+  return c->nghost == 0 || c->exchange != nullptr;
+}
 
 static int ensure_fused_buffers(cup2d_ctx *c) {
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
-  double **v[] = {&c->d_p2, &c->d_nu2, &c->d_s, &c->d_y, &c->d_yopt};
+  double **v[] = {&c->d_p2, &c->d_nu2, &c->d_s, &c->d_y, &c->d_yopt, &c->d_z};
   for (double **p : v)
     if (!*p) {
       CUP2D_HIP_CHECK(hipMalloc(p, bytes));
@@ -598,6 +664,42 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 template <int MODE>
 static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks) {
   const int nb = c->nblocks;
+  if (c->mat.active) {
+    // hybrid assembled operator: the fused tiles in one launch; then the halo entries of z, then the rows of the general
+    // tiles, whose last workgroup finishes the reduction of both launches
+    const SellMatrix &M = c->mat;
+    int g = (M.ntiles + FWAVES - 1) / FWAVES;
+    const int cus = c->num_cus > 0 ? c->num_cus : 256;
+    if (g > cus) g = cus;
+    if (g >= 8) g -= g % 8;
+    if (g < 1) g = 1;
+    const int m1 = M.ngen > 0 ? 0 : merge;
+    const auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, M.d_fnbr, c->d_sc, c->d_partials,
+                         0, M.ntiles, 0, c->ntotal, c->d_z, c->d_red, c->d_ticket, dbg, M.d_zmask, M.d_tile0);
+    };
+    if (m1 == 1) go(k_fused<MODE, 1, true>);
+    else if (m1 == 2) go(k_fused<MODE, 2, true>);
+    else go(k_fused<MODE, 0, true>);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    *GP = g;
+    if (M.ngen == 0) return CUP2D_OK;
+    CUP2D_TRY(matrix_exchange(c, c->d_z));
+    int g2 = (M.ngen + RWAVES - 1) / RWAVES;
+    static const int rows_per_cu = [] { const char *e = getenv("CUP2D_ROWS_WG_PER_CU"); return e ? atoi(e) : 1; }();
+    if (g2 > rows_per_cu * cus) g2 = rows_per_cu * cus;
+    const double *w0 = MODE == 0 ? a.w : a.in0, *w1 = MODE == 0 ? nullptr : a.in1;
+    const auto rows = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col,
+                         M.d_val, M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket);
+    };
+    if (merge == 1) rows(k_hyb_rows<MODE, 1>);
+    else if (merge == 2) rows(k_hyb_rows<MODE, 2>);
+    else rows(k_hyb_rows<MODE, 0>);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    *GP = g + g2;
+    return CUP2D_OK;
+  }
   if (ghost_blocks) {
     // N ranks, ghost-block form: the ghost copies of the sweep's input vectors are complete (solve_fused_impl
     // exchanges whole boundary blocks behind the reductions), so a ghost block is a ring entry like any other
@@ -605,7 +707,7 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
     const int g = fused_grid(c, nb);
     const auto go = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials,
-                         0, nb, 0, c->ntotal, c->d_z, c->d_red, c->d_ticket, dbg);
+                         0, nb, 0, c->ntotal, c->d_z, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
     };
     if (merge == 1) go(k_fused<MODE, 1>);
     else if (merge == 2) go(k_fused<MODE, 2>);
@@ -632,13 +734,13 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
   const auto launch = [&](int first, int count, int poff, int g, int mg) {
     if (mg == 1)
       hipLaunchKernelGGL((k_fused<MODE, 1>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
     else if (mg == 2)
       hipLaunchKernelGGL((k_fused<MODE, 2>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
     else
       hipLaunchKernelGGL((k_fused<MODE, 0>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg);
+                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
   };
   if (n_in > 0) launch(0, n_in, 0, G_in, n_ha > 0 && merge == 2 ? 0 : merge);
   if (ghosts) CUP2D_TRY(exchange_end(c, zg, 1, 1));
@@ -676,7 +778,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   if (!c->fused_lds_opt_in) {  // > 64 KiB of LDS is an opt-in per kernel AND device: remembered per context
     const void *ks[] = {reinterpret_cast<const void *>(&k_fused<0, 0>), reinterpret_cast<const void *>(&k_fused<0, 1>),
                         reinterpret_cast<const void *>(&k_fused<0, 2>), reinterpret_cast<const void *>(&k_fused<1, 0>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>)};
+                        reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>),
+                        reinterpret_cast<const void *>(&k_fused<0, 0, true>), reinterpret_cast<const void *>(&k_fused<0, 1, true>),
+                        reinterpret_cast<const void *>(&k_fused<0, 2, true>), reinterpret_cast<const void *>(&k_fused<1, 0, true>),
+                        reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -684,6 +789,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // in-kernel finish.  1: one GPU -- one launch per sweep, the last workgroup also runs the scalar update.
   // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars
   const int merge = !c->finish_in_kernel ? 0 : (c->allreduce || (c->nghost > 0 && c->exchange)) ? 2 : 1;
+  // (restart in the hybrid form: rhat = r is written by k_fused for every block before k_hyb_rows reads it)
   // N ranks: how a sweep learns z on the other side of a rank boundary.
   //   blocks (default)  whole boundary blocks of nu', p', r are exchanged as they are produced -- nu' and p' in one
   //                     message behind the reduction of AB, r behind the reduction of E -- and the sweeps recompute the
@@ -692,7 +798,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   //   edges             per sweep: z of the send-list blocks (k_fused_edges), a width-1 exchange overlapped with the
   //                     inner tiles, then a second launch for the tiles that touch ghost blocks
   static const bool ghost_edges = [] { const char *e = getenv("CUP2D_FUSED_GHOST"); return e && !strcmp(e, "edges"); }();
-  const bool gb = c->nghost > 0 && c->exchange && !ghost_edges;
+  const bool gb = c->nghost > 0 && c->exchange && !ghost_edges && !c->mat.active;
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
 
   int GP = 0;

@@ -192,6 +192,12 @@ int cup2d_clear_matrix(cup2d_ctx *ctx);
  * device_send_buffer[i] = vec[idx[i]], i < nsend, is handed to the exchange callback with
  * strip_doubles = 1 and device_recv = &vec[64*nblocks].  Call after cup2d_set_matrix_coo. */
 int cup2d_set_gather(cup2d_ctx *ctx, int nsend, const int32_t *idx);
+/* How the installed operator is applied (any pointer may be NULL).  plain_blocks: blocks whose 64 rows are exactly the
+ * same-level 5-point rows -- applied matrix-free from the four neighbour ids, no stored entries; stored_entries: the
+ * sliced-ELL entries kept for the other blocks (coarse-fine rows, halo columns); general_tile_blocks: blocks that sit in
+ * a tile of 16 consecutive blocks holding at least one such block -- the tile-fused sweeps (CUP2D_SOLVER_FUSED) keep
+ * z = P_inv v of every other tile on the chip and apply the rows of these from memory in a second launch per sweep. */
+int cup2d_matrix_stats(cup2d_ctx *ctx, int *plain_blocks, int *general_tile_blocks, long long *stored_entries);
 
 /* ---------------------------------------------------------------- block-AMR --------------- */
 /* Adapted grids (BASELINE.json configs[4]; the reference's Info::level / tree, main.cpp:504-517, 2197-2198).

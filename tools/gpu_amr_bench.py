@@ -36,16 +36,22 @@ with A.AmrSimulation(g) as s:
     t0 = time.perf_counter()
     s.install_poisson_matrix()
     print("operator assembly + sliced-ELL upload %.2f s" % (time.perf_counter() - t0), flush=True)
+    print("operator:", s.matrix_stats(), flush=True)
+    if os.environ.get("SWEEPS"):
+        s.set_solver(fused=False, finish_in_kernel=False)
     for _ in range(2):
         r = s.step(max_iter=50)
-    L.check(s.L.cup2d_set_timing(s._ctx, 1))
+    nst = 5
     t0 = time.perf_counter()
-    nst = 3
     for _ in range(nst):
         r = s.step(max_iter=50)
     L.check(s.L.cup2d_synchronize(s._ctx)) if hasattr(s.L, "cup2d_synchronize") else None
     el = (time.perf_counter() - t0) / nst
-    print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e" % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"]), flush=True)
+    print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e  [%s solver]"
+          % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"], s.last_solver()), flush=True)
+    L.check(s.L.cup2d_set_timing(s._ctx, 1))  # per-launch events: the breakdown below, not the figure above
+    for _ in range(3):
+        r = s.step(max_iter=50)
     import ctypes
     for i, name in enumerate(L.TIMER_NAMES):
         ms, calls = ctypes.c_double(), ctypes.c_int()

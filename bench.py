@@ -106,6 +106,37 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+class Watchdog:
+    """A rank that makes no progress for `limit` seconds (a peer died, a collective never completes) ends itself with a
+    message instead of holding the GPU until the caller's timeout: torch.distributed.run then stops the other ranks."""
+
+    def __init__(self, limit):
+        import threading
+        self.limit, self.last, self.what = limit, time.monotonic(), "start"
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def beat(self, what):
+        self.last, self.what = time.monotonic(), what
+
+    def _watch(self):
+        while True:
+            time.sleep(2.0)
+            idle = time.monotonic() - self.last
+            if idle > self.limit:
+                sys.stderr.write("bench.py: rank %s made no progress for %.0f s after '%s' -- giving up\n"
+                                 % (os.environ.get("RANK", "0"), idle, self.what))
+                sys.stderr.flush()
+                os._exit(4)
+
+
+WATCHDOG = None
+
+
+def beat(what):
+    if WATCHDOG is not None:
+        WATCHDOG.beat(what)
+
+
 class Runner:
     """one layout on this rank: the simulation, its timed region and its timers"""
 
@@ -149,7 +180,9 @@ class Runner:
             torch.cuda.synchronize()
 
     def one_step(self):
-        return self.sim.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=self.args.iters)
+        r = self.sim.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=self.args.iters)
+        beat("step")
+        return r
 
     def timed_steps(self, steps, timing_mode):
         import torch
@@ -204,8 +237,11 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    global WATCHDOG
+    WATCHDOG = Watchdog(float(os.environ.get("CUP2D_BENCH_WATCHDOG_S", "300")))
     import torch
     from cup2d_amd import lib as L
+    beat("import")
 
     # one node: rendezvous sockets (gloo, RCCL's bootstrap) on loopback -- resolving the container's hostname can take
     # minutes to fail; HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf IPC between the ranks' processes
@@ -243,6 +279,7 @@ def main():
 
     nx, ny = geometry(args.layout)
     run = Runner(args, nx, ny, px, py, rank, world, local_rank, dist, ctl)
+    beat("setup")
     sim = run.sim
     fused = args.solver == "fused"
     for _ in range(args.warmup):
@@ -254,6 +291,7 @@ def main():
     # computed from those samples.  The same K steps are repeated afterwards without any events and
     # reported as ms_per_step_no_kernel_timers.
     elapsed, iters = run.timed_steps(args.steps, 0 if args.no_kernel_timers else 2)
+    beat("timed region")
     cells_rank = nx * ny
     cells = cells_rank * world
     value = cells * args.steps / elapsed / 1e6
@@ -309,6 +347,7 @@ def main():
 
     # ---- the other layout (N > 1): same command, second timed region -------------------------------------------
     second = None
+    beat("first layout")
     if world > 1 and not args.no_second_layout:
         other = "configs3" if args.layout == "weak" else "weak"
         run.close()
@@ -422,6 +461,7 @@ def main():
                   "mcell_iterations_per_s": round(cells_rank / t_it / 1e6, 1)}
 
     cpu = None
+    beat("gpu part")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import oracle as O
@@ -433,6 +473,7 @@ def main():
                 sweep = {}
                 for thr in cand:
                     try:
+                        beat("cpu baseline, %d threads" % thr)
                         r = O.ref_step_time(args.cpu_n, steps=2, max_iter=args.iters, threads=thr, timeout=120)
                         sweep[thr] = (round(args.cpu_n ** 2 / r["median_step_s"] / 1e6, 4), r)
                     except Exception as e:

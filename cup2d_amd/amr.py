@@ -181,9 +181,14 @@ class AmrSimulation(BodyOps):
     def apply_A(self, dst, src):
         _l.check(self.L.cup2d_apply_A(self._ctx, dst, src), "apply_A")
 
-    def install_poisson_matrix(self):
-        """assemble the coarse-fine Poisson rows on the host (AmrBlockGrid.poisson_coo) and hand them to the library:
-        what the reference does after every regrid (main.cpp:7034-7113)"""
+    def install_poisson_matrix(self, via_triplets=False):
+        """the coarse-fine Poisson operator of this grid, what the reference assembles after every regrid
+        (main.cpp:7034-7113): built by the library from the tables of cup2d_set_amr (cup2d_amr_install_poisson: rows only
+        where a block has a coarse-fine side); via_triplets: the COO route (AmrBlockGrid.poisson_coo -> cup2d_set_matrix_coo),
+        the same operator bit for bit"""
+        if not via_triplets:
+            _l.check(self.L.cup2d_amr_install_poisson(self._ctx), "amr_install_poisson")
+            return
         r, c, v = self.grid.poisson_coo()
         vp = ctypes.c_void_p
         _l.check(self.L.cup2d_set_matrix_coo(self._ctx, 0, len(v), r.ctypes.data_as(vp), c.ctypes.data_as(vp), v.ctypes.data_as(vp)),

@@ -36,13 +36,14 @@ def partition_bounds(nblocks, nranks):
 class AmrPartition:
     def __init__(self, G, nranks, rank, coo=None):
         """G: the GLOBAL AmrBlockGrid (every rank holds the leaf list, 12 bytes per block).  coo: the global Poisson triplets
-        (G.poisson_coo()), computed here when not given."""
+        (G.poisson_coo()) when the caller wants this rank's rows as triplets (row, col, val: the route through
+        cup2d_set_matrix_coo, and the tests); without them the library assembles the rows from the local tables
+        (cup2d_amr_install_poisson) -- a row's columns lie in the block itself and its face neighbours, all in the first
+        ghost ring."""
         self.G, self.nranks, self.rank = G, int(nranks), int(rank)
         nb = G.nblocks
         self.bounds = partition_bounds(nb, nranks)
         self.owner = np.searchsorted(self.bounds, np.arange(nb), side="right") - 1
-        if coo is None:
-            coo = G.poisson_coo()
         self.coo = coo
         self._ghosts = [self._ghost_ids(r) for r in range(nranks)]  # every rank's ghost list (global ids, ascending)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
@@ -88,13 +89,15 @@ class AmrPartition:
         assert np.array_equal(self.recv_block, self.nowned + np.arange(self.nghost)), "ghosts are numbered in receive order"
         self.nsend, self.nrecv = len(send), len(recv)
         # ---- this rank's rows of the Poisson matrix; ghost cells are halo columns 64 * nowned + 64 * g + cell ----
-        r, c, v = coo
-        m = (r >= 64 * lo) & (r < 64 * hi)
-        cb = self.local_of[c[m] // 64]
-        assert (cb >= 0).all(), "ghost closure does not cover the matrix columns"
-        self.row = (r[m] - 64 * lo).astype(np.int32)
-        self.col = (cb * 64 + c[m] % 64).astype(np.int32)
-        self.val = np.ascontiguousarray(v[m])
+        self.row = self.col = self.val = None
+        if coo is not None:
+            r, c, v = coo
+            m = (r >= 64 * lo) & (r < 64 * hi)
+            cb = self.local_of[c[m] // 64]
+            assert (cb >= 0).all(), "ghost closure does not cover the matrix columns"
+            self.row = (r[m] - 64 * lo).astype(np.int32)
+            self.col = (cb * 64 + c[m] % 64).astype(np.int32)
+            self.val = np.ascontiguousarray(v[m])
         self.gather = (self.send_block.astype(np.int64)[:, None] * 64 + np.arange(64)[None, :]).ravel().astype(np.int32)
 
     def _neighbours(self, ids):
@@ -110,10 +113,12 @@ class AmrPartition:
         owned = np.arange(lo, hi)
         ring1 = self._neighbours(owned)
         ring2 = self._neighbours(np.union1d(owned, ring1)) if len(ring1) else ring1
-        rr, cc, _ = self.coo
-        m = (rr >= 64 * lo) & (rr < 64 * hi)
-        cols = np.unique(cc[m] // 64)
-        g = np.union1d(np.union1d(ring1, ring2), cols)
+        g = np.union1d(ring1, ring2)
+        if self.coo is not None:  # (a row's columns: the block and its face neighbours -- nothing beyond ring 1)
+            rr, cc, _ = self.coo
+            m = (rr >= 64 * lo) & (rr < 64 * hi)
+            cols = np.unique(cc[m] // 64)
+            assert np.isin(cols, np.union1d(owned, ring1)).all(), "a matrix column outside the first ghost ring"
         return g[(g < lo) | (g >= hi)].astype(np.int64)
 
 
@@ -218,8 +223,11 @@ class DistributedAmrSimulation(AmrSimulation):
         """this rank's rows of the operator of main.cpp:7034-7113, ghost cells as halo columns, whole sent blocks as the
         gather list (cuda.h's send_pack_idx_ with a block as the unit)"""
         P, vp = self.part, ctypes.c_void_p
-        _l.check(self.L.cup2d_set_matrix_coo(self._ctx, 64 * P.nghost, len(P.val), P.row.ctypes.data_as(vp), P.col.ctypes.data_as(vp),
-                                             P.val.ctypes.data_as(vp)), "set_matrix_coo")
+        if P.val is not None:
+            _l.check(self.L.cup2d_set_matrix_coo(self._ctx, 64 * P.nghost, len(P.val), P.row.ctypes.data_as(vp),
+                                                 P.col.ctypes.data_as(vp), P.val.ctypes.data_as(vp)), "set_matrix_coo")
+        else:  # assembled by the library from the local tables: rows only where a side is coarse-fine or a ghost block
+            _l.check(self.L.cup2d_amr_install_poisson(self._ctx), "amr_install_poisson")
         _l.check(self.L.cup2d_set_gather(self._ctx, len(P.gather), P.gather.ctypes.data_as(vp)), "set_gather")
 
     # ---- regridding across the ranks -------------------------------------------------------------------------------------

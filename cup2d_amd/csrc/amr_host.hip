@@ -59,6 +59,60 @@ void interpolate(Row &r, int bc, int s, int ixc, int iyc, long long fine_close, 
 
 }  // namespace
 
+namespace {
+
+// one row of main.cpp:7034-7112: cell (ix, iy) of block b
+void build_row(Row &r, int b, int ix, int iy, const int32_t *kind, const int32_t *nbr2, const int32_t *half) {
+  const long long me = cell(b, ix, iy);
+  if (ix > 0 && ix < BS - 1 && iy > 0 && iy < BS - 1) {  // main.cpp:7075-7087
+    r.add(cell(b, ix, iy - 1), 1.);
+    r.add(cell(b, ix - 1, iy), 1.);
+    r.add(me, -4.);
+    r.add(cell(b, ix + 1, iy), 1.);
+    r.add(cell(b, ix, iy + 1), 1.);
+    return;
+  }
+  const bool inblock[4] = {ix > 0, ix < BS - 1, iy > 0, iy < BS - 1};
+  const long long inner[4] = {cell(b, ix - 1, iy), cell(b, ix + 1, iy), cell(b, ix, iy - 1), cell(b, ix, iy + 1)};
+  for (int s = 0; s < 4; s++) {
+    if (inblock[s]) {
+      r.add(inner[s], 1.);
+      r.add(me, -1.);
+      continue;
+    }
+    const int k = kind[4 * b + s];
+    if (k == CUP2D_AMR_WALL) continue;
+    const int n0 = nbr2[(4 * b + s) * 2], n1 = nbr2[(4 * b + s) * 2 + 1];
+    if (k == CUP2D_AMR_SAME) {  // makeFlux, same level
+      r.add(s == 0 ? cell(n0, 7, iy) : s == 1 ? cell(n0, 0, iy) : s == 2 ? cell(n0, ix, 7) : cell(n0, ix, 0), 1.);
+      r.add(me, -1.);
+    } else if (k == CUP2D_AMR_COARSER) {
+      const int h = half[4 * b + s];
+      const int ixc = s == 0 ? 7 : s == 1 ? 0 : ix / 2 + 4 * h;
+      const int iyc = s == 2 ? 7 : s == 3 ? 0 : iy / 2 + 4 * h;
+      const long long inward = s == 0 ? cell(b, ix + 1, iy) : s == 1 ? cell(b, ix - 1, iy) : s == 2 ? cell(b, ix, iy + 1)
+                                                                                            : cell(b, ix, iy - 1);
+      const int t = s < 2 ? iy : ix;
+      interpolate(r, n0, s, ixc, iyc, me, inward, 1., t % 2 == 0 ? -1. : 1.);
+      r.add(me, -1.);
+    } else {  // the two finer cells across the face, in the child that covers this cell
+      const int t = s < 2 ? iy : ix;
+      const int fb = t >= 4 ? n1 : n0, f = (t % 4) * 2;
+      for (int j = 0; j < 2; j++) {
+        long long close, far;
+        if (s == 0) { close = cell(fb, 7, f + j); far = cell(fb, 6, f + j); }
+        else if (s == 1) { close = cell(fb, 0, f + j); far = cell(fb, 1, f + j); }
+        else if (s == 2) { close = cell(fb, f + j, 7); far = cell(fb, f + j, 6); }
+        else { close = cell(fb, f + j, 0); far = cell(fb, f + j, 1); }
+        r.add(close, 1.);
+        interpolate(r, b, s, ix, iy, close, far, -1., j == 0 ? -1. : 1.);
+      }
+    }
+  }
+}
+
+}  // namespace
+
 extern "C" long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half,
                                            long long cap, int32_t *row, int32_t *col, double *val) {
   if (nblocks <= 0 || !kind || !nbr2 || !half) {
@@ -77,51 +131,7 @@ extern "C" long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, con
       for (int ix = 0; ix < BS; ix++) {
         Row r;
         const long long me = cell(b, ix, iy);
-        if (ix > 0 && ix < BS - 1 && iy > 0 && iy < BS - 1) {  // main.cpp:7075-7087
-          r.add(cell(b, ix, iy - 1), 1.);
-          r.add(cell(b, ix - 1, iy), 1.);
-          r.add(me, -4.);
-          r.add(cell(b, ix + 1, iy), 1.);
-          r.add(cell(b, ix, iy + 1), 1.);
-        } else {
-          const bool inblock[4] = {ix > 0, ix < BS - 1, iy > 0, iy < BS - 1};
-          const long long inner[4] = {cell(b, ix - 1, iy), cell(b, ix + 1, iy), cell(b, ix, iy - 1), cell(b, ix, iy + 1)};
-          for (int s = 0; s < 4; s++) {
-            if (inblock[s]) {
-              r.add(inner[s], 1.);
-              r.add(me, -1.);
-              continue;
-            }
-            const int k = kind[4 * b + s];
-            if (k == CUP2D_AMR_WALL) continue;
-            const int n0 = nbr2[(4 * b + s) * 2], n1 = nbr2[(4 * b + s) * 2 + 1];
-            if (k == CUP2D_AMR_SAME) {  // makeFlux, same level
-              r.add(s == 0 ? cell(n0, 7, iy) : s == 1 ? cell(n0, 0, iy) : s == 2 ? cell(n0, ix, 7) : cell(n0, ix, 0), 1.);
-              r.add(me, -1.);
-            } else if (k == CUP2D_AMR_COARSER) {
-              const int h = half[4 * b + s];
-              const int ixc = s == 0 ? 7 : s == 1 ? 0 : ix / 2 + 4 * h;
-              const int iyc = s == 2 ? 7 : s == 3 ? 0 : iy / 2 + 4 * h;
-              const long long inward = s == 0 ? cell(b, ix + 1, iy) : s == 1 ? cell(b, ix - 1, iy) : s == 2 ? cell(b, ix, iy + 1)
-                                                                                                    : cell(b, ix, iy - 1);
-              const int t = s < 2 ? iy : ix;
-              interpolate(r, n0, s, ixc, iyc, me, inward, 1., t % 2 == 0 ? -1. : 1.);
-              r.add(me, -1.);
-            } else {  // the two finer cells across the face, in the child that covers this cell
-              const int t = s < 2 ? iy : ix;
-              const int fb = t >= 4 ? n1 : n0, f = (t % 4) * 2;
-              for (int j = 0; j < 2; j++) {
-                long long close, far;
-                if (s == 0) { close = cell(fb, 7, f + j); far = cell(fb, 6, f + j); }
-                else if (s == 1) { close = cell(fb, 0, f + j); far = cell(fb, 1, f + j); }
-                else if (s == 2) { close = cell(fb, f + j, 7); far = cell(fb, f + j, 6); }
-                else { close = cell(fb, f + j, 0); far = cell(fb, f + j, 1); }
-                r.add(close, 1.);
-                interpolate(r, b, s, ix, iy, close, far, -1., j == 0 ? -1. : 1.);
-              }
-            }
-          }
-        }
+        build_row(r, b, ix, iy, kind, nbr2, half);
         if (fill) {
           if (nnz + r.n > cap) {
             cup2d::set_error("amr_poisson_coo: capacity %lld too small", cap);
@@ -142,6 +152,68 @@ extern "C" long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, con
       }
   return nnz;
 }
+
+namespace cup2d {
+
+// The same operator straight in the hybrid form cup2d_set_matrix_coo arrives at (ctx.h SellMatrix) for the `nowned` first
+// blocks of tables that cover `nowned` + ghost blocks: a block whose four sides are walls or same-level OWNED blocks is
+// plain -- no row is built for it --, every other block gets its 64 rows as sliced-ELL entries, each row's entries in
+// column order with duplicate columns summed in arrival order (what the triplet route stores).  At regrid time this is
+// the difference between 0.14 s and 0.01 s on a 63 k-block grid: 94 % of the blocks are plain.
+void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half,
+                         std::vector<int32_t> &reg, std::vector<long long> &ptr, std::vector<int32_t> &ecol,
+                         std::vector<double> &eval, int *nregular) {
+  reg.assign((size_t)4 * nowned, CUP2D_WALL);
+  ptr.assign((size_t)nowned + 1, 0);
+  ecol.clear();
+  eval.clear();
+  int nreg = 0;
+  std::vector<std::pair<long long, double>> sorted;
+  Row rows[64];
+  for (int b = 0; b < nowned; b++) {
+    bool plain = true;
+    for (int s = 0; s < 4; s++) {
+      const int k = kind[4 * b + s];
+      plain = plain && (k == CUP2D_AMR_WALL || (k == CUP2D_AMR_SAME && nbr2[(4 * b + s) * 2] < nowned));
+    }
+    if (plain) {
+      for (int s = 0; s < 4; s++)
+        reg[(size_t)4 * b + s] = kind[4 * b + s] == CUP2D_AMR_SAME ? nbr2[(4 * b + s) * 2] : CUP2D_WALL;
+      nreg++;
+      ptr[b + 1] = ptr[b];
+      continue;
+    }
+    reg[(size_t)4 * b] = SELL_STORED;
+    int w = 0;
+    for (int l = 0; l < 64; l++) {
+      rows[l] = Row();
+      build_row(rows[l], b, l & 7, l >> 3, kind, nbr2, half);
+      w = rows[l].n > w ? rows[l].n : w;
+    }
+    const size_t base = ecol.size();
+    ecol.resize(base + (size_t)w * 64);
+    eval.resize(base + (size_t)w * 64, 0.0);
+    for (int l = 0; l < 64; l++) {
+      sorted.clear();
+      for (int k = 0; k < rows[l].n; k++) sorted.emplace_back(rows[l].col[k], rows[l].val[k]);
+      std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &c2) { return a.first < c2.first; });
+      for (int k = 0; k < w; k++) {
+        const size_t e = base + (size_t)k * 64 + l;
+        if (k < (int)sorted.size()) {
+          ecol[e] = (int32_t)sorted[k].first;
+          eval[e] = sorted[k].second;
+        } else {  // padding: own row, coefficient 0
+          ecol[e] = b * 64 + l;
+          eval[e] = 0.0;
+        }
+      }
+    }
+    ptr[b + 1] = ptr[b] + (long long)w * 64;
+  }
+  *nregular = nreg;
+}
+
+}  // namespace cup2d
 
 // ======================================================================================================================
 // Regridding on the host: topology tables, state validation, prolongation / restriction.

@@ -369,6 +369,9 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   CUP2D_HIP_CHECK(hipMemset(A.d_faces, 0, sizeof(double) * nb * 4 * BS));
   CUP2D_HIP_CHECK(hipMalloc(&A.d_faces2, sizeof(double) * nb * 4 * BS * 2));
   CUP2D_HIP_CHECK(hipMemset(A.d_faces2, 0, sizeof(double) * nb * 4 * BS * 2));
+  A.h_kind.assign(kind, kind + (size_t)nb * 4);
+  A.h_nbr2.assign(nbr2, nbr2 + (size_t)nb * 8);
+  A.h_half.assign(half, half + (size_t)nb * 4);
   A.h0 = h0;
   int lmax = 0;
   for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;
@@ -624,6 +627,92 @@ int cup2d_clear_matrix(cup2d_ctx *c) {
   c->mat = SellMatrix();
   return CUP2D_OK;
 }
+// upload of an operator in (hybrid) sliced-ELL form + the tables of the tile-fused sweeps
+static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<int32_t> &reg, const std::vector<long long> &ptr,
+                        const std::vector<int32_t> &ecol, const std::vector<double> &eval, int nregular) {
+  const size_t entries = ecol.size();
+  const auto stored = [&](int s) { return reg[(size_t)4 * s] == SELL_STORED; };
+  CUP2D_TRY(cup2d_clear_matrix(c));
+  SellMatrix &M = c->mat;
+  CUP2D_HIP_CHECK(hipMalloc(&M.d_ptr, ptr.size() * sizeof(long long)));
+  CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
+  if (entries) {
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_col, entries * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_val, entries * sizeof(double)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval.data(), entries * sizeof(double), hipMemcpyHostToDevice));
+  }
+  CUP2D_HIP_CHECK(hipMalloc(&M.d_reg, reg.size() * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(hipMemcpy(M.d_reg, reg.data(), reg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  M.nregular = nregular;
+  M.entries = entries;
+  M.halo = halo;
+  if (hybrid) {
+    // tables of the tile-fused sweeps (ctx.h SellMatrix): the tiling, which tiles are all plain, whose z the rows of the
+    // other tiles read
+    const int nbk = c->nblocks;
+    std::vector<int> plain_run((size_t)nbk + 1, 0);  // number of consecutive plain slices from s on
+    for (int s = nbk - 1; s >= 0; s--) plain_run[s] = stored(s) ? 0 : plain_run[s + 1] + 1;
+    const auto good = [&](int s) {  // 16 plain slices from s on with <= 16 neighbour slots outside the set
+      if (plain_run[s] < FUSED_TILE) return false;
+      int ring = 0;
+      for (int b = s; b < s + FUSED_TILE; b++)
+        for (int side = 0; side < 4; side++) {
+          const int32_t nb_ = reg[(size_t)4 * b + side];
+          ring += nb_ >= 0 && (nb_ < s || nb_ >= s + FUSED_TILE);
+        }
+      return ring <= FUSED_TILE;
+    };
+    std::vector<int32_t> tile0;
+    for (int s = 0; s < nbk;) {
+      tile0.push_back(s);
+      if (good(s)) { s += FUSED_TILE; continue; }
+      int e = s + 1;  // a chunk: up to the next good start, at most 16
+      while (e < nbk && e - s < FUSED_TILE && !good(e)) e++;
+      s = e;
+    }
+    tile0.push_back(nbk);
+    const int ntiles = (int)tile0.size() - 1;
+    std::vector<int32_t> fnbr(reg), gen;
+    M.h_zmask.assign((size_t)ntiles, 0);
+    M.h_slot.assign((size_t)nbk, 0);
+    for (int t = 0; t < ntiles; t++)
+      for (int s = tile0[t]; s < tile0[t + 1]; s++) M.h_slot[s] = t * FUSED_TILE + (s - tile0[t]);
+    const auto flag = [&](long long b) {
+      if (b >= 0 && b < nbk) M.h_zmask[(size_t)(M.h_slot[b] / FUSED_TILE)] |= 1 << (M.h_slot[b] % FUSED_TILE);
+    };
+    for (int t = 0; t < ntiles; t++) {
+      const int b0 = tile0[t], b1 = tile0[t + 1];
+      bool general = false;
+      for (int s = b0; s < b1; s++) general = general || stored(s);
+      if (!general) continue;
+      for (int s = b0; s < b1; s++) {
+        gen.push_back(s);
+        flag(s);
+        if (stored(s)) {
+          for (long long e = ptr[s]; e < ptr[s + 1]; e++) flag(ecol[e] >> 6);
+        } else {
+          for (int side = 0; side < 4; side++) flag(reg[(size_t)4 * s + side]);
+        }
+        for (int side = 0; side < 4; side++) fnbr[(size_t)4 * s + side] = FUSED_GENERAL;
+      }
+    }
+    M.ntiles = ntiles;
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_fnbr, fnbr.data(), fnbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    CUP2D_HIP_CHECK(hipMalloc(&M.d_zmask, M.h_zmask.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(M.d_zmask, M.h_zmask.data(), M.h_zmask.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    M.ngen = (int)gen.size();
+    if (M.ngen) {
+      CUP2D_HIP_CHECK(hipMalloc(&M.d_gen, gen.size() * sizeof(int32_t)));
+      CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
+  M.active = true;
+  return CUP2D_OK;
+}
 int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *row, const int32_t *col, const double *val) {
   CUP2D_CHECK_CTX(c);
   const long long m = (long long)c->nblocks * BC;
@@ -728,86 +817,7 @@ int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *r
     ecol[e] = col[k];
     eval[e] = val[k];
   }
-  CUP2D_TRY(cup2d_clear_matrix(c));
-  SellMatrix &M = c->mat;
-  CUP2D_HIP_CHECK(hipMalloc(&M.d_ptr, ptr.size() * sizeof(long long)));
-  CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
-  if (entries) {
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_col, entries * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_val, entries * sizeof(double)));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval.data(), entries * sizeof(double), hipMemcpyHostToDevice));
-  }
-  CUP2D_HIP_CHECK(hipMalloc(&M.d_reg, reg.size() * sizeof(int32_t)));
-  CUP2D_HIP_CHECK(hipMemcpy(M.d_reg, reg.data(), reg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  M.nregular = nregular;
-  M.entries = entries;
-  M.halo = halo;
-  if (hybrid) {
-    // tables of the tile-fused sweeps (ctx.h SellMatrix): the tiling, which tiles are all plain, whose z the rows of the
-    // other tiles read
-    const int nbk = c->nblocks;
-    std::vector<int> plain_run((size_t)nbk + 1, 0);  // number of consecutive plain slices from s on
-    for (int s = nbk - 1; s >= 0; s--) plain_run[s] = stored(s) ? 0 : plain_run[s + 1] + 1;
-    const auto good = [&](int s) {  // 16 plain slices from s on with <= 16 neighbour slots outside the set
-      if (plain_run[s] < FUSED_TILE) return false;
-      int ring = 0;
-      for (int b = s; b < s + FUSED_TILE; b++)
-        for (int side = 0; side < 4; side++) {
-          const int32_t nb_ = reg[(size_t)4 * b + side];
-          ring += nb_ >= 0 && (nb_ < s || nb_ >= s + FUSED_TILE);
-        }
-      return ring <= FUSED_TILE;
-    };
-    std::vector<int32_t> tile0;
-    for (int s = 0; s < nbk;) {
-      tile0.push_back(s);
-      if (good(s)) { s += FUSED_TILE; continue; }
-      int e = s + 1;  // a chunk: up to the next good start, at most 16
-      while (e < nbk && e - s < FUSED_TILE && !good(e)) e++;
-      s = e;
-    }
-    tile0.push_back(nbk);
-    const int ntiles = (int)tile0.size() - 1;
-    std::vector<int32_t> fnbr(reg), gen;
-    M.h_zmask.assign((size_t)ntiles, 0);
-    M.h_slot.assign((size_t)nbk, 0);
-    for (int t = 0; t < ntiles; t++)
-      for (int s = tile0[t]; s < tile0[t + 1]; s++) M.h_slot[s] = t * FUSED_TILE + (s - tile0[t]);
-    const auto flag = [&](long long b) {
-      if (b >= 0 && b < nbk) M.h_zmask[(size_t)(M.h_slot[b] / FUSED_TILE)] |= 1 << (M.h_slot[b] % FUSED_TILE);
-    };
-    for (int t = 0; t < ntiles; t++) {
-      const int b0 = tile0[t], b1 = tile0[t + 1];
-      bool general = false;
-      for (int s = b0; s < b1; s++) general = general || stored(s);
-      if (!general) continue;
-      for (int s = b0; s < b1; s++) {
-        gen.push_back(s);
-        flag(s);
-        if (stored(s)) {
-          for (long long e = ptr[s]; e < ptr[s + 1]; e++) flag(ecol[e] >> 6);
-        } else {
-          for (int side = 0; side < 4; side++) flag(reg[(size_t)4 * s + side]);
-        }
-        for (int side = 0; side < 4; side++) fnbr[(size_t)4 * s + side] = FUSED_GENERAL;
-      }
-    }
-    M.ntiles = ntiles;
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_fnbr, fnbr.data(), fnbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_zmask, M.h_zmask.size() * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_zmask, M.h_zmask.data(), M.h_zmask.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    M.ngen = (int)gen.size();
-    if (M.ngen) {
-      CUP2D_HIP_CHECK(hipMalloc(&M.d_gen, gen.size() * sizeof(int32_t)));
-      CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-  }
-  M.active = true;
-  return CUP2D_OK;
+  return install_sell(c, halo, hybrid, reg, ptr, ecol, eval, nregular);
 }
 int cup2d_matrix_stats(cup2d_ctx *c, int *plain_blocks, int *general_tile_blocks, long long *stored_entries) {
   CUP2D_CHECK_CTX(c);
@@ -816,6 +826,16 @@ int cup2d_matrix_stats(cup2d_ctx *c, int *plain_blocks, int *general_tile_blocks
   if (general_tile_blocks) *general_tile_blocks = c->mat.d_fnbr ? c->mat.ngen : c->nblocks;
   if (stored_entries) *stored_entries = (long long)c->mat.entries;
   return CUP2D_OK;
+}
+int cup2d_amr_install_poisson(cup2d_ctx *c) {
+  CUP2D_CHECK_CTX(c);
+  if (!c->amr.active) { set_error("amr_install_poisson: cup2d_set_amr first"); return CUP2D_ERR_ARG; }
+  std::vector<int32_t> reg, ecol;
+  std::vector<long long> ptr;
+  std::vector<double> eval;
+  int nregular = 0;
+  amr_assemble_hybrid(c->nblocks, c->amr.h_kind.data(), c->amr.h_nbr2.data(), c->amr.h_half.data(), reg, ptr, ecol, eval, &nregular);
+  return install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, nregular);
 }
 int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
   CUP2D_CHECK_CTX(c);

@@ -118,6 +118,7 @@ struct AmrTopo {
   int32_t *d_half = nullptr;     // [nblocks][4]  coarser neighbour: which half of its face this block touches
   double *d_faces = nullptr;     // [nblocks][4][8] fluxes recorded by the functors (BlockCase::d, main.cpp:513-517)
   double *d_faces2 = nullptr;    // [nblocks][4][8][2] the same for vector functors (KernelAdvectDiffuse)
+  std::vector<int32_t> h_kind, h_nbr2, h_half;  // host copies: cup2d_amr_install_poisson assembles from them
 };
 
 }  // namespace cup2d
@@ -253,6 +254,9 @@ int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
 int launch_precond_add(cup2d_ctx *c, const double *y, double *x, double *tmp);
 int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the installed SellMatrix
+// amr_host.hip: the Poisson operator of an adapted grid straight in the hybrid sliced-ELL form
+void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half, std::vector<int32_t> &reg,
+                         std::vector<long long> &ptr, std::vector<int32_t> &ecol, std::vector<double> &eval, int *nregular);
 int matrix_exchange(cup2d_ctx *c, double *vec);         // fill vec[m .. m+halo) from the neighbour ranks
 int project_impl(cup2d_ctx *c, double dt);
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,

@@ -612,3 +612,31 @@ def test_amr_tile_fused_solver_on_the_hybrid_operator_gpu(gpu_lib, which):
         assert np.abs(b.ravel() - A @ x.ravel()).max() <= 1.05e-9
         d = x.ravel() - xt
         assert np.abs(d - d.mean()).max() < 1e-5  # the solution up to the constant (residual 1e-9 times the conditioning)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["golden", "circle7"])
+def test_amr_operator_installed_from_the_tables_equals_the_triplet_route_gpu(gpu_lib, which):
+    """cup2d_amr_install_poisson builds rows only for the blocks with a coarse-fine side; the operator is the one
+    cup2d_amr_poisson_coo -> cup2d_set_matrix_coo installs: same split into plain blocks and stored entries, same product
+    and same solve, bit for bit"""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    g = AmrBlockGrid(golden("amr_functors.npz")["blocks"]) if which == "golden" else _circle_grid(7)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (g.nblocks, 8, 8))
+    out = {}
+    with AmrSimulation(g) as s:
+        for via in (True, False):
+            s.install_poisson_matrix(via_triplets=via)
+            st = s.matrix_stats()
+            s.set_field(L.PRES, x)
+            s.apply_A(L.TMP, L.PRES)
+            ax = s.get_field(L.TMP).copy()
+            s.set_field(L.TMP, ax)
+            s.set_field(L.PRES, np.zeros_like(x))
+            info = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=6)
+            out[via] = (st, ax, s.get_field(L.PRES).copy(), info)
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
+    assert out[True][3] == out[False][3]

@@ -5,6 +5,8 @@
 // on the dense topology tables of cup2d_set_amr instead of the tree / Info hash maps.  (The tests keep a Python
 // statement of the same algorithm and require the two to agree bit for bit.)
 #include <algorithm>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "ctx.h"
@@ -12,6 +14,34 @@
 namespace {
 
 constexpr int BS = CUP2D_BS;
+
+// regrid-time host loops over independent blocks run on a few threads (CUP2D_HOST_THREADS, default min(16, cores)):
+// n items in chunk_count(n, grain) contiguous chunks, fn(lo, hi, chunk)
+int host_threads() {
+  static const int want = [] {
+    const char *e = getenv("CUP2D_HOST_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int v = e ? atoi(e) : (int)(hw ? (hw < 16u ? hw : 16u) : 1u);
+    return v < 1 ? 1 : v;
+  }();
+  return want;
+}
+int chunk_count(long long n, long long grain) {
+  long long nt = (n + grain - 1) / grain;
+  if (nt > host_threads()) nt = host_threads();
+  return (int)(nt < 1 ? 1 : nt);
+}
+template <class F>
+void parallel_chunks(long long n, long long grain, F fn) {
+  const long long nt = chunk_count(n, grain);
+  if (nt <= 1) {
+    fn(0LL, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (long long t = 0; t < nt; t++) th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
+  for (auto &x : th) x.join();
+}
 
 struct Row {  // a row under construction: duplicate columns are summed in the order they arrive (mapColVal)
   int n = 0;
@@ -167,48 +197,69 @@ void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, c
   ptr.assign((size_t)nowned + 1, 0);
   ecol.clear();
   eval.clear();
-  int nreg = 0;
-  std::vector<std::pair<long long, double>> sorted;
-  Row rows[64];
-  for (int b = 0; b < nowned; b++) {
-    bool plain = true;
-    for (int s = 0; s < 4; s++) {
-      const int k = kind[4 * b + s];
-      plain = plain && (k == CUP2D_AMR_WALL || (k == CUP2D_AMR_SAME && nbr2[(4 * b + s) * 2] < nowned));
-    }
-    if (plain) {
-      for (int s = 0; s < 4; s++)
-        reg[(size_t)4 * b + s] = kind[4 * b + s] == CUP2D_AMR_SAME ? nbr2[(4 * b + s) * 2] : CUP2D_WALL;
-      nreg++;
-      ptr[b + 1] = ptr[b];
-      continue;
-    }
-    reg[(size_t)4 * b] = SELL_STORED;
-    int w = 0;
-    for (int l = 0; l < 64; l++) {
-      rows[l] = Row();
-      build_row(rows[l], b, l & 7, l >> 3, kind, nbr2, half);
-      w = rows[l].n > w ? rows[l].n : w;
-    }
-    const size_t base = ecol.size();
-    ecol.resize(base + (size_t)w * 64);
-    eval.resize(base + (size_t)w * 64, 0.0);
-    for (int l = 0; l < 64; l++) {
-      sorted.clear();
-      for (int k = 0; k < rows[l].n; k++) sorted.emplace_back(rows[l].col[k], rows[l].val[k]);
-      std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &c2) { return a.first < c2.first; });
-      for (int k = 0; k < w; k++) {
-        const size_t e = base + (size_t)k * 64 + l;
-        if (k < (int)sorted.size()) {
-          ecol[e] = (int32_t)sorted[k].first;
-          eval[e] = sorted[k].second;
-        } else {  // padding: own row, coefficient 0
-          ecol[e] = b * 64 + l;
-          eval[e] = 0.0;
+  // chunks of blocks in parallel, each into its own entry lists (a block's 64 rows are independent of every other
+  // block's); then laid end to end
+  const int nchunks = chunk_count(nowned, 512);
+  std::vector<std::vector<int32_t>> ccol((size_t)nchunks);
+  std::vector<std::vector<double>> cval((size_t)nchunks);
+  std::vector<long long> clo((size_t)nchunks + 1, 0);
+  std::vector<int> cplain((size_t)nchunks, 0);
+  std::vector<long long> width((size_t)nowned, 0);
+  parallel_chunks(nowned, 512, [&](long long lo, long long hi, int t) {
+    clo[t] = lo;
+    clo[t + 1] = hi;
+    std::vector<std::pair<long long, double>> sorted;
+    std::vector<Row> rows(64);
+    std::vector<int32_t> &oc = ccol[t];
+    std::vector<double> &ov = cval[t];
+    for (int b = (int)lo; b < (int)hi; b++) {
+      bool plain = true;
+      for (int s = 0; s < 4; s++) {
+        const int k = kind[4 * b + s];
+        plain = plain && (k == CUP2D_AMR_WALL || (k == CUP2D_AMR_SAME && nbr2[(4 * b + s) * 2] < nowned));
+      }
+      if (plain) {
+        for (int s = 0; s < 4; s++)
+          reg[(size_t)4 * b + s] = kind[4 * b + s] == CUP2D_AMR_SAME ? nbr2[(4 * b + s) * 2] : CUP2D_WALL;
+        cplain[t]++;
+        continue;
+      }
+      reg[(size_t)4 * b] = SELL_STORED;
+      int w = 0;
+      for (int l = 0; l < 64; l++) {
+        rows[l] = Row();
+        build_row(rows[l], b, l & 7, l >> 3, kind, nbr2, half);
+        w = rows[l].n > w ? rows[l].n : w;
+      }
+      width[b] = w;
+      const size_t base = oc.size();
+      oc.resize(base + (size_t)w * 64);
+      ov.resize(base + (size_t)w * 64, 0.0);
+      for (int l = 0; l < 64; l++) {
+        sorted.clear();
+        for (int k = 0; k < rows[l].n; k++) sorted.emplace_back(rows[l].col[k], rows[l].val[k]);
+        std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &c2) { return a.first < c2.first; });
+        for (int k = 0; k < w; k++) {
+          const size_t e = base + (size_t)k * 64 + l;
+          if (k < (int)sorted.size()) {
+            oc[e] = (int32_t)sorted[k].first;
+            ov[e] = sorted[k].second;
+          } else {  // padding: own row, coefficient 0
+            oc[e] = b * 64 + l;
+            ov[e] = 0.0;
+          }
         }
       }
     }
-    ptr[b + 1] = ptr[b] + (long long)w * 64;
+  });
+  int nreg = 0;
+  for (int b = 0; b < nowned; b++) ptr[b + 1] = ptr[b] + width[b] * 64;
+  ecol.reserve((size_t)ptr[nowned]);
+  eval.reserve((size_t)ptr[nowned]);
+  for (int t = 0; t < nchunks; t++) {  // chunk t covers blocks [clo[t], clo[t+1]): in block order
+    ecol.insert(ecol.end(), ccol[t].begin(), ccol[t].end());
+    eval.insert(eval.end(), cval[t].begin(), cval[t].end());
+    nreg += cplain[t];
   }
   *nregular = nreg;
 }
@@ -628,7 +679,8 @@ extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bp
     const double *f = fields[fi];
     double *g = new_fields[fi];
     const size_t bsz = (size_t)BC * dim;
-    for (long long p = 0; p < (long long)nb.size(); p++) {
+    parallel_chunks((long long)nb.size(), 256, [&](long long p_lo, long long p_hi, int) {
+    for (long long p = p_lo; p < p_hi; p++) {
       const New &b = nb[p];
       if (b.part == -1) {
         std::copy(f + b.src * bsz, f + (b.src + 1) * bsz, g + where[p] * bsz);
@@ -653,6 +705,7 @@ extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bp
         for (int c = 0; c < 4; c++) std::copy(kids + c * bsz, kids + (c + 1) * bsz, g + where[p + c] * bsz);
       }
     }
+    });
   }
   return n_new;
 }

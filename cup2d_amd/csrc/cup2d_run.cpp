@@ -160,15 +160,7 @@ struct AmrRun {
     RUN(cup2d_create(&ctx, n, 0, n, nbr.data(), h0, device));
     RUN(cup2d_set_amr(ctx, h0, level.data(), kind.data(), nbr2.data(), half.data()));
     RUN(cup2d_set_math(ctx, math));
-    const long long nnz = cup2d_amr_poisson_coo(n, kind.data(), nbr2.data(), half.data(), 0, nullptr, nullptr, nullptr);
-    if (nnz < 0) { std::fprintf(stderr, "cup2d_run: amr_poisson_coo: %s\n", cup2d_last_error()); std::exit(1); }
-    std::vector<int32_t> row((size_t)nnz), col((size_t)nnz);
-    std::vector<double> val((size_t)nnz);
-    if (cup2d_amr_poisson_coo(n, kind.data(), nbr2.data(), half.data(), nnz, row.data(), col.data(), val.data()) != nnz) {
-      std::fprintf(stderr, "cup2d_run: amr_poisson_coo: %s\n", cup2d_last_error());
-      std::exit(1);
-    }
-    RUN(cup2d_set_matrix_coo(ctx, 0, nnz, row.data(), col.data(), val.data()));
+    RUN(cup2d_amr_install_poisson(ctx));  // the coarse-fine operator of main.cpp:7034-7113, from the tables just set
   }
   // adapt(): returns true if the grid changed
   bool adapt(double rtol, double ctol, int level_max) {

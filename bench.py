@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--cpu-n", type=int, default=1024, help="grid of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0 = sweep 16 / 64 / 128 and report the best)")
+    ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
+    ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
     return ap.parse_args()
 
 
@@ -224,6 +226,46 @@ class Runner:
 
     def close(self):
         self.sim.close()
+
+
+def amr_leg(args, device):
+    from cup2d_amd import amr as A, lib as L
+    t0 = time.perf_counter()
+    g = A.circle_band_grid(args.amr_lfine)
+    t_grid = time.perf_counter() - t0
+    with A.AmrSimulation(g, nu=1e-3, cfl=0.5, device=device) as s:
+        xc, yc = g.cell_centres()
+        s.set_field(L.VEL, np.stack([np.sin(2 * np.pi * xc) * np.cos(2 * np.pi * yc), -np.cos(2 * np.pi * xc) * np.sin(2 * np.pi * yc)], -1))
+        s.set_math(args.math == "strict")
+        t0 = time.perf_counter()
+        s.install_poisson_matrix()
+        t_op = time.perf_counter() - t0
+        for _ in range(2):
+            s.step(max_iter=args.iters)
+        nst = 5
+        L.check(s.L.cup2d_synchronize(s._ctx), "synchronize")
+        t0 = time.perf_counter()
+        for _ in range(nst):
+            r = s.step(max_iter=args.iters)
+            beat("amr step")
+        L.check(s.L.cup2d_synchronize(s._ctx), "synchronize")
+        el = (time.perf_counter() - t0) / nst
+        solver, stats = s.last_solver(), s.matrix_stats()
+        # one regrid the way a run does it (tags from max|vorticity| per block: here the band moves with the thresholds)
+        s.vorticity()
+        om = np.abs(s.get_field(L.TMP)).reshape(g.nblocks, -1).max(1)
+        t0 = time.perf_counter()
+        changed = s.adapt(float(np.quantile(om, 0.97)), float(np.quantile(om, 0.5)), args.amr_lfine + 1)
+        t_adapt = time.perf_counter() - t0
+        nb_after = s.grid.nblocks
+    return {"workload": "three-level block-AMR grid, finest level %d^2-equivalent in a band around a circle; same step, %d BiCGSTAB "
+                        "iters on the assembled coarse-fine operator" % (8 << args.amr_lfine, args.iters),
+            "blocks": g.nblocks, "cells": g.nblocks * 64, "blocks_per_level": np.bincount(g.blocks[:, 0]).tolist(),
+            "value": round(g.nblocks * 64 / el / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_step": round(el * 1e3, 3),
+            "iters": r["iters"], "solver": solver, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
+            "grid_build_ms": round(t_grid * 1e3, 1),
+            "regrid": {"changed": bool(changed), "blocks_after": nb_after, "ms": round(t_adapt * 1e3, 1),
+                       "what": "adapt(): tags, 2:1 balance, prolongation/restriction of five fields on the host, new context, operator"}}
 
 
 def main():
@@ -503,6 +545,17 @@ def main():
         except Exception as e:  # the baseline is informative; never fail the bench on it
             cpu = {"error": str(e)[:200]}
 
+    # BASELINE.json configs[4] on this GPU (not the headline; one GPU only -- the N-rank AMR path is covered by the tests):
+    # a three-level block-AMR grid with the finest level 4096^2-equivalent in a band around a circle, the same step
+    amr = None
+    if rank == 0 and world == 1 and not args.no_amr:
+        beat("amr leg")
+        try:
+            amr = amr_leg(args, local_rank)
+        except Exception as e:  # informative; never fail the bench on it
+            amr = {"error": str(e)[:200]}
+        beat("amr leg done")
+
     if rank == 0:
         out = {
             "metric": "Mcell-updates/sec (advect-diffuse+Poisson sweep) at 4096^2",
@@ -521,7 +574,7 @@ def main():
             "verified": verified, "second_layout": second,
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "kernels": timers, "roofline_extra_sampled_steps_outside_timed_region": extra_sampled_steps,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "amr_configs4": amr,
         }
     if second is None or world == 1:
         run.close()

@@ -299,3 +299,19 @@ def regrid(blocks, states, fields, level_max, bpdx=1, bpdy=1):
     if got != n_new:
         _l.check(int(min(got, -1)), "amr_regrid")
     return new_blocks.astype(np.int64), dict(zip(names, dst))
+
+
+def circle_band_grid(lfine, radius=0.25, width=0.06):
+    """A three-level grid whose finest level (2^lfine blocks per side) is a band around a circle: the shape of
+    BASELINE.json configs[4] (flow past a cylinder, finest level ~4096^2-equivalent at lfine = 9).  Built with the library's
+    host routines (state validation with 2:1 balance, regrid), the way a run arrives at it."""
+    l0 = lfine - 2
+    blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
+    for lvl in range(l0, lfine):
+        cx = (blocks[:, 1] + 0.5) / (1 << blocks[:, 0]) - 0.5
+        cy = (blocks[:, 2] + 0.5) / (1 << blocks[:, 0]) - 0.5
+        d = np.abs(np.hypot(cx, cy) - radius)
+        st = np.where((blocks[:, 0] == lvl) & (d < width), REFINE, LEAVE).astype(np.int32)
+        st = validate_states(blocks, st, lfine + 1)
+        blocks, _ = regrid(blocks, st, {}, lfine + 1)
+    return AmrBlockGrid(blocks)

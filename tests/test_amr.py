@@ -550,18 +550,8 @@ def test_penalisation_kernels_on_an_adapted_grid_gpu(gpu_lib, oracle):
 
 
 def _circle_grid(lfine):
-    """three levels, the finest (2^lfine blocks per side) in a band around a circle: the shape of BASELINE.json configs[4]"""
-    from cup2d_amd import amr as A
-    l0 = lfine - 2
-    blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
-    for lvl in range(l0, lfine):
-        cx = (blocks[:, 1] + 0.5) / (1 << blocks[:, 0]) - 0.5
-        cy = (blocks[:, 2] + 0.5) / (1 << blocks[:, 0]) - 0.5
-        d = np.abs(np.hypot(cx, cy) - 0.25)
-        st = np.where((blocks[:, 0] == lvl) & (d < 0.06), A.REFINE, A.LEAVE).astype(np.int32)
-        st = A.validate_states(blocks, st, lfine + 1)
-        blocks, _ = A.regrid(blocks, st, {}, lfine + 1)
-    return A.AmrBlockGrid(blocks)
+    from cup2d_amd.amr import circle_band_grid
+    return circle_band_grid(lfine)
 
 
 @pytest.mark.gpu

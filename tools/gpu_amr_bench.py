@@ -13,18 +13,9 @@ import cup2d_amd  # noqa: E402
 from cup2d_amd import amr as A, lib as L  # noqa: E402
 
 LF = int(os.environ.get("LFINE", "8"))  # finest level: 2^LF blocks per side (8 -> 2048^2 equivalent, 9 -> 4096^2)
-l0 = LF - 2
-blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
 t0 = time.perf_counter()
-for lvl in range(l0, LF):  # refine the blocks near a circle of radius 0.25 twice
-    n = 1 << lvl
-    cx = (blocks[:, 1] + 0.5) / (1 << blocks[:, 0]) - 0.5
-    cy = (blocks[:, 2] + 0.5) / (1 << blocks[:, 0]) - 0.5
-    d = np.abs(np.hypot(cx, cy) - 0.25)
-    st = np.where((blocks[:, 0] == lvl) & (d < 0.06), A.REFINE, A.LEAVE).astype(np.int32)
-    st = A.validate_states(blocks, st, LF + 1)
-    blocks, _ = A.regrid(blocks, st, {}, LF + 1)
-g = A.AmrBlockGrid(blocks)
+g = A.circle_band_grid(LF)
+blocks = g.blocks
 t_grid = time.perf_counter() - t0
 nb = g.nblocks
 print("grid: %d blocks, levels %s, host regrid+tables %.2f s" % (nb, np.bincount(blocks[:, 0]).tolist(), t_grid), flush=True)

@@ -433,7 +433,7 @@ def main():
         # fused kernels: MERGE 1 = the last workgroup finishes the reduction and updates the scalars (one GPU),
         # 2 = it sums the rank's partials, all-reduce + scalar kernel follow (N GPUs), 0 = finish launch
         mf = 0 if args.finish != "kernel" else (1 if dist is None else 2)
-        KERNEL_OF.update({"sweep_A": "k_fused<0, %d, false>" % mf, "sweep_C": "k_fused<1, %d, false>" % mf, "sweep_E": "k_sweepE_y<%d>" % mf})
+        KERNEL_OF.update({"sweep_A": "k_fused<0, %d>" % mf, "sweep_C": "k_fused<1, %d>" % mf, "sweep_E": "k_sweepE_y<%d>" % mf})
         sweeps = ("sweep_A", "sweep_C", "sweep_E")
     finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on
@@ -444,8 +444,10 @@ def main():
         for f in sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_traffic.json")):
             try:
                 for k, v in json.load(open(os.path.join(prof_dir, f)))["kernels"].items():
-                    if k.startswith("k_fused<") and k.count(",") == 1:
-                        k = k[:-1] + ", false>"
+                    if k.startswith("k_fused<") and k.count(",") > 1:  # <MODE, MERGE, hybrid operator, ghost edges>: the
+                        if "true" in k:                                  # uniform bench runs <MODE, MERGE, false, false>
+                            continue
+                        k = ",".join(k.split(",")[:2]) + ">"
                     traffic_tab[k] = v
                     traffic_src[k] = "profiles/" + f
             except Exception:
@@ -458,7 +460,6 @@ def main():
         sec = t["ms_total"] / t["launches"] * 1e-3
         gbs = ALGO_BYTES[fam] * cells_rank / sec / 1e9
         tr = traffic_tab.get(KERNEL_OF[fam], {}).get("hbm_bytes") if (nx, ny) == (4096, 4096) and world == 1 else None
-        # (summaries older than the hybrid-operator template parameter carry the kernel's name without it)
         return {"kernel": KERNEL_OF[fam], "family": fam, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr,
                 "traffic_source": traffic_src.get(KERNEL_OF[fam]) if tr else None,

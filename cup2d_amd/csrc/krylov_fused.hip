@@ -193,7 +193,9 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 // slice with stored rows: the wave forms v and z = P_inv v of its blocks and stores them (v as always, z to zg), the rows
 // themselves are applied by k_hyb_rows from z in memory; a fused tile also stores the z of the blocks zmask names (the
 // ones those rows read).  Ring entries work as ever: the neighbour of a plain block is a block with p, nu, r in memory.
-template <int MODE, int MERGE, bool HYB = false>
+// EDGES: neighbour ids >= nowned are ghost blocks whose z edges the owner rank computed (k_fused_edges; N ranks,
+// CUP2D_FUSED_GHOST=edges) -- compiled out otherwise: the path costs the one-rank kernel six spilled registers
+template <int MODE, int MERGE, bool HYB = false, bool EDGES = false>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                   int first, int count, int poff, int nowned,
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       continue;
     }
     if (si < nvalid && !T.is_ring) {
-      if (!HYB && T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
+      if (EDGES && T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
         const double *g = zg + (size_t)T.nb * BC;
 #pragma unroll
         for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = g[edge_cell(ss ^ 1, q)];
@@ -732,15 +734,19 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
   // merge 1 (one GPU, one launch): the launch finishes the reduction and updates the scalars; merge 2: the LAST
   // launch of the sweep sums this rank's partials, finish_local() does the rest
   const auto launch = [&](int first, int count, int poff, int g, int mg) {
-    if (mg == 1)
-      hipLaunchKernelGGL((k_fused<MODE, 1>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
-    else if (mg == 2)
-      hipLaunchKernelGGL((k_fused<MODE, 2>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
-    else
-      hipLaunchKernelGGL((k_fused<MODE, 0>), dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr,
-                         c->d_sc, c->d_partials, first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
+    const auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials,
+                         first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
+    };
+    if (ghosts) {
+      if (mg == 1) go(k_fused<MODE, 1, false, true>);
+      else if (mg == 2) go(k_fused<MODE, 2, false, true>);
+      else go(k_fused<MODE, 0, false, true>);
+    } else {
+      if (mg == 1) go(k_fused<MODE, 1>);
+      else if (mg == 2) go(k_fused<MODE, 2>);
+      else go(k_fused<MODE, 0>);
+    }
   };
   if (n_in > 0) launch(0, n_in, 0, G_in, n_ha > 0 && merge == 2 ? 0 : merge);
   if (ghosts) CUP2D_TRY(exchange_end(c, zg, 1, 1));
@@ -781,7 +787,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>),
                         reinterpret_cast<const void *>(&k_fused<0, 0, true>), reinterpret_cast<const void *>(&k_fused<0, 1, true>),
                         reinterpret_cast<const void *>(&k_fused<0, 2, true>), reinterpret_cast<const void *>(&k_fused<1, 0, true>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>)};
+                        reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>),
+                        reinterpret_cast<const void *>(&k_fused<0, 0, false, true>), reinterpret_cast<const void *>(&k_fused<0, 1, false, true>),
+                        reinterpret_cast<const void *>(&k_fused<0, 2, false, true>), reinterpret_cast<const void *>(&k_fused<1, 0, false, true>),
+                        reinterpret_cast<const void *>(&k_fused<1, 1, false, true>), reinterpret_cast<const void *>(&k_fused<1, 2, false, true>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     c->fused_lds_opt_in = true;

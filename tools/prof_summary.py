@@ -32,7 +32,7 @@ if os.path.exists(stats_csv):
     full_csv = os.path.join(os.path.dirname(stats_csv), "stats_full_launches.csv")
     if os.path.exists(full_csv):
         full = {r["Name"]: r for r in csv.DictReader(open(full_csv))}
-    cmd = "python bench.py --steps %s --warmup 1 --no-cpu-baseline" % os.environ.get("STEPS", "2")
+    cmd = "python bench.py --steps %s --warmup 1 --no-cpu-baseline --no-amr" % os.environ.get("STEPS", "2")
     with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.txt" % tag), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- %s   (MI355X, gfx950)\n" % cmd)
         f.write("# source: %s (stats_kernel_stats.csv), durations in ns\n" % out_dir)

@@ -251,9 +251,14 @@ def test_amr_poisson_solve_gpu(gpu_lib, oracle):
 
 @pytest.mark.gpu
 def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
+    for name, F in _grid_cases(oracle):
+        _check_amr_kernels(oracle, name, F)
+
+
+def _check_amr_kernels(oracle, name, F):
     from cup2d_amd import lib as L
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
-    for name, F in _grid_cases(oracle):
+    if True:
         dt = float(F["dt"])
         with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
             # tmp -= Lap5(pold) with the flux correction (main.cpp:7022-7027)
@@ -294,6 +299,43 @@ def test_amr_kernels_bit_exact_gpu(gpu_lib, oracle):
             umax = np.abs(F["vel"]).max()
             hmin = s.grid.h(F["blocks"][:, 0].max())
             assert s.compute_dt() == oracle.compute_dt(hmin, 1e-3, 0.5, umax)
+            return s.grid.nblocks
+
+
+@pytest.mark.gpu
+def test_amr_kernels_bit_exact_at_configs4_scale_gpu(gpu_lib, oracle):
+    """The same functor-by-functor comparison on a grid of the size BASELINE.json configs[4] names, built by the REFERENCE's
+    own adapt() in a live run on the box (vortex pair, levels 3..9 = up to 4096^2-equivalent, ~39 k blocks on seven
+    levels): block indices, neighbour tables and face arrays at a scale the 76..232-block fixtures cannot reach.  Then the
+    reference-assembled matrix: its action on the reference's pressure, and a solve with the tile-fused sweeps checked
+    against that action."""
+    if not oracle.have_reference():
+        pytest.skip("reference harness not built")
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = oracle.ref_amr_functors(4, 10, 8, 0.5, 0.1)
+    nb = len(F["blocks"])
+    levels = np.bincount(F["blocks"][:, 0])
+    print("reference grid: %d blocks, per level %s" % (nb, levels.tolist()))
+    assert nb > 20000 and (levels > 0).sum() >= 6
+    assert _check_amr_kernels(oracle, "live-configs4", F) == nb
+    g = AmrBlockGrid(F["blocks"])
+    with AmrSimulation(g) as s:
+        s.install_poisson_matrix()
+        st = s.matrix_stats()
+        print("operator:", st)
+        s.set_field(L.PRES, F["pres"])
+        s.apply_A(L.TMP, L.PRES)
+        assert np.abs(s.get_field(L.TMP) - F["Ax"]).max() <= 1e-12 * np.abs(F["Ax"]).max()  # vs the reference-assembled matrix
+        b = F["Ax"].copy()
+        s.set_field(L.TMP, b)
+        s.set_field(L.PRES, np.zeros_like(b))
+        info = s.poisson_solve(tol=0.0, rel_tol=1e-6, max_restarts=100, max_iter=3000)
+        assert s.last_solver() == "fused" and info["err"] <= 1e-6 * info["err_init"]
+        x = s.get_field(L.PRES).copy()
+        s.set_field(L.PRES, x)
+        s.apply_A(L.TMP, L.PRES)
+        assert np.abs(s.get_field(L.TMP) - b).max() <= 1.05 * info["err"] + 1e-12 * np.abs(b).max()
 
 
 @pytest.mark.gpu

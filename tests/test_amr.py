@@ -672,3 +672,32 @@ def test_amr_operator_installed_from_the_tables_equals_the_triplet_route_gpu(gpu
     assert out[True][0] == out[False][0], (out[True][0], out[False][0])
     assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
     assert out[True][3] == out[False][3]
+
+
+@pytest.mark.gpu
+def test_amr_adapt_at_configs4_scale_vs_reference_gpu(gpu_lib, oracle):
+    """AmrSimulation.adapt() -- tags from max|vorticity| per block on the GPU, the library's state validation and
+    (threaded) prolongation / restriction, new context, operator from the tables -- against the reference's own adapt()
+    (main.cpp:4657-5440) on the ~39 k-block, seven-level grid of a live run: same leaves afterwards, all five fields bit
+    for bit."""
+    if not oracle.have_reference():
+        pytest.skip("reference harness not built")
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    pre, post = oracle.ref_amr_adapt(4, 10, 8, 0.5, 0.1)
+    names = {"chi": L.CHI, "vel": L.VEL, "vold": L.VOLD, "pres": L.PRES, "pold": L.POLD}
+    with AmrSimulation(AmrBlockGrid(pre["blocks"])) as s:
+        for k, f in names.items():
+            s.set_field(f, pre[k])
+        assert s.adapt(0.5, 0.1, 10)
+        blocks = s.grid.blocks
+        print("reference adapt: %d -> %d blocks; here %d" % (len(pre["blocks"]), len(post["blocks"]), len(blocks)))
+        assert len(blocks) == len(post["blocks"]) != len(pre["blocks"])
+        assert set(map(tuple, blocks.tolist())) == set(map(tuple, post["blocks"].tolist()))
+        for k, f in names.items():
+            ref = _by_block(post["blocks"], post[k].reshape(len(post["blocks"]), -1))
+            mine = _by_block(blocks, s.get_field(f).reshape(len(blocks), -1))
+            assert all(np.array_equal(ref[b], mine[b]) for b in ref), k
+        assert s.matrix_stats()["plain_blocks"] > 0  # the operator of the new grid is installed
+        r = s.step(max_iter=20)
+        assert np.isfinite(r["err"]) and r["dt"] > 0

@@ -416,18 +416,25 @@ def test_amr_adapt_then_step_gpu(gpu_lib, oracle):
 
 
 @pytest.mark.gpu
-def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle):
-    """BASELINE.json configs[4] end to end on one GPU: from the uniform level-2 grid and the analytic vortex pair, six
-    passes of [adapt(); time step] -- the grid grows 16 -> 40 -> 76 blocks on three levels -- against the reference's own
-    time loop (ref_harness 'amr': its adapt(), labs, flux correction, matrix; solver = CPU restatement of cuda.cu)."""
+@pytest.mark.parametrize("lstart,lmax,steps,rtol,ctol,iters,tv,tp,threads", [(2, 5, 6, 2.0, 0.5, 200, 1e-8, 1e-7, 1),
+                                                                              (4, 9, 8, 0.5, 0.1, 400, 1e-8, 1e-5, 16)])
+def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle, lstart, lmax, steps, rtol, ctol, iters, tv, tp, threads):
+    """BASELINE.json configs[4] end to end on one GPU: from a uniform grid and the analytic vortex pair, passes of
+    [adapt(); time step] against the reference's own time loop (ref_harness 'amr': its adapt(), labs, flux correction,
+    matrix; solver = CPU restatement of cuda.cu).  Small: level 2, six passes, 16 -> 40 -> 76 blocks on three levels.
+    Large: level 4, eight passes, 256 -> 292 -> 868 -> 2 884 -> 10 096 -> 10 132 blocks on six levels (3..8).  Same block
+    count and dt at every step, same leaves at the end, fields to the solve tolerance.  The solves run to round-off
+    (200 / 400 iterations): iterates of an UNCONVERGED BiCGSTAB solve are not comparable between two summation orders --
+    with the bench's fifty iterations the two runs agree to 1e-11 for four steps and then drift to the size of the
+    unconverged error itself, exactly as the fused and the five-sweep solver drift from each other
+    (tools/gpu_amr_sensitivity.py, tools/gpu_amr_debug_steps.py)."""
     if not oracle.have_reference():
         pytest.skip("needs oracle/_ref/ref_harness")
     from cup2d_amd import lib as L
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
-    steps, lmax, rtol, ctol = 6, 5, 2.0, 0.5
-    R = oracle.ref_run_amr(level_start=2, level_max=lmax, steps=steps, rtol=rtol, ctol=ctol, nu=1e-3, max_iter=200,
-                           env={"OMP_NUM_THREADS": "1"})  # fixed reduction order in the reference's run
-    g = AmrBlockGrid([(2, i, j) for j in range(4) for i in range(4)])
+    R = oracle.ref_run_amr(level_start=lstart, level_max=lmax, steps=steps, rtol=rtol, ctol=ctol, nu=1e-3, max_iter=iters,
+                           env={"OMP_NUM_THREADS": str(threads)})  # 1: fixed reduction order in the reference's run
+    g = AmrBlockGrid([(lstart, i, j) for j in range(1 << lstart) for i in range(1 << lstart)])
     x, y = g.cell_centres()
     u, v = np.zeros_like(x), np.zeros_like(x)
     for cx, cy, gam in ((0.35, 0.5, 1.0), (0.65, 0.5, -1.0)):  # ref_harness.cpp inject()
@@ -444,7 +451,7 @@ def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle):
             dt = s.compute_dt()  # before the regrid, as main.cpp:6579-6603 orders them
             s.adapt(rtol, ctol, lmax)
             counts.append(s.grid.nblocks)
-            dts.append(s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=200, dt=dt)["dt"])
+            dts.append(s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=iters, dt=dt)["dt"])
         assert counts == [st["blocks"] for st in R["steps"][1:steps + 1]], (counts, [st["blocks"] for st in R["steps"]])
         assert np.allclose(dts, [st["dt"] for st in R["steps"][1:steps + 1]], rtol=1e-8, atol=0)
         assert set(map(tuple, s.grid.blocks.tolist())) == set(map(tuple, R["blocks"].tolist()))
@@ -453,7 +460,9 @@ def test_amr_run_with_regridding_vs_reference_gpu(gpu_lib, oracle):
         vel, pres = s.get_field(L.VEL).reshape(s.grid.nblocks, -1), s.get_field(L.PRES)
         dv = max(np.abs(vel[k] - ref_v[b]).max() for k, b in enumerate(map(tuple, s.grid.blocks.tolist())))
         dp = max(np.abs(pres[k] - ref_p[b]).max() for k, b in enumerate(map(tuple, s.grid.blocks.tolist())))
-        assert dv < 1e-8 * max(1.0, np.abs(R["vel"]).max()) and dp < 1e-7 * max(1.0, np.abs(R["pres"]).max()), (dv, dp)
+        print("blocks per step %s; max|dv| = %.2e (max|v| %.2f), max|dp| = %.2e (max|p| %.2f)"
+              % (counts, dv, np.abs(R["vel"]).max(), dp, np.abs(R["pres"]).max()))
+        assert dv < tv * max(1.0, np.abs(R["vel"]).max()) and dp < tp * max(1.0, np.abs(R["pres"]).max()), (dv, dp)
 
 
 @pytest.mark.gpu

@@ -248,16 +248,87 @@ def run_amr_gpu(rank, world):
     dist.barrier()
 
 
+def run_amr_big_gpu(rank, world):
+    """the same on a grid of 4 084 blocks (three levels, a band around a circle, Hilbert order): the single context on the
+    whole grid is the reference here -- every block operator on a rank's owned blocks bit for bit, a step to the solve
+    tolerance, the regrid across the ranks bit for bit.  Contiguous Hilbert ranges of ~1 400 blocks: interior tiles take the
+    fused sweeps, rank boundaries cut through all three levels."""
+    import torch.distributed as dist
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrSimulation, circle_band_grid
+    from cup2d_amd.amr_dist import DistributedAmrSimulation
+    G = circle_band_grid(7)
+    nb = G.nblocks
+    rng = np.random.default_rng(77)
+    x, y = G.cell_centres()
+    vel = np.stack([np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), -np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y)], -1)\
+        .reshape(nb, 64, 2) + 1e-2 * rng.uniform(-1, 1, (nb, 64, 2))
+    pold, tmp_in, pres = (rng.uniform(-1, 1, (nb, 64)) for _ in range(3))
+    chi = rng.uniform(0, 1, (nb, 64)) * (rng.uniform(0, 1, (nb, 1)) < 0.2)
+    udef = rng.uniform(-1, 1, (nb, 64, 2)) * (chi[:, :, None] > 0)
+    nu, dt = 1e-3, 1e-4
+    ref_out = {}
+    with AmrSimulation(G, nu=nu) as ref, DistributedAmrSimulation(G, nu=nu, device=0) as s:
+        own = slice(s.part.lo, s.part.hi)
+        n_own = s.part.nowned
+        for sim, sl, out in ((ref, slice(None), ref_out), (s, own, None)):
+            got = {}
+            sim.set_math(True)
+            sim.set_field(L.POLD, pold[sl]); sim.set_field(L.TMP, tmp_in[sl]); sim.laplacian_sub(); got["lap"] = sim.get_field(L.TMP).copy()
+            sim.set_field(L.VEL, vel[sl]); sim.vorticity(); got["vort"] = sim.get_field(L.TMP).copy()
+            sim.set_field(L.TMPV, udef[sl]); sim.set_field(L.CHI, chi[sl]); sim.pressure_rhs(dt); got["prhs"] = sim.get_field(L.TMP).copy()
+            sim.set_field(L.PRES, pres[sl]); sim.pressure_correction(dt); got["pcorr"] = sim.get_field(L.TMPV).copy()
+            sim.set_field(L.VEL, vel[sl]); sim.advect_diffuse_rhs(dt); got["advdiff"] = sim.get_field(L.TMPV).copy()
+            if out is not None:
+                out.update(got)
+            else:
+                for k, v in got.items():
+                    assert np.array_equal(v, ref_out[k][own]), "%s rank %d" % (k, rank)
+        # ---- a whole step ----
+        for sim, sl, n in ((ref, slice(None), nb), (s, own, n_own)):
+            sim.set_field(L.VEL, vel[sl])
+            for f in (L.PRES, L.POLD, L.CHI):
+                sim.set_field(f, np.zeros((n, 64)))
+            sim.set_field(L.TMPV, np.zeros((n, 64, 2)))
+            sim.install_poisson_matrix()
+        rr = ref.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=1000)
+        r = s.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=1000)
+        assert r["dt"] == rr["dt"] and s.last_solver() == ref.last_solver() == "fused", (r, rr)
+        dv = np.abs(s.get_field(L.VEL) - ref.get_field(L.VEL)[own]).max()
+        dp = np.abs(s.get_field(L.PRES) - ref.get_field(L.PRES)[own]).max()
+        assert dv < 1e-8 and dp < 1e-6, (rank, dv, dp, r, rr)
+        # ---- regrid across the ranks = the single-context regrid ----
+        ref.set_field(L.VEL, vel); s.set_field(L.VEL, vel[own])
+        ref.vorticity()
+        om = np.abs(ref.get_field(L.TMP)).reshape(nb, -1).max(1)
+        rt, ct = float(np.quantile(om, 0.9)), float(np.quantile(om, 0.3))
+        changed_ref = ref.adapt(rt, ct, 8)
+        blocks_ref, vel_ref = ref.grid.blocks.copy(), ref.get_field(L.VEL)
+        changed = s.adapt(rt, ct, 8)
+        assert changed and changed_ref
+        assert np.array_equal(s.global_grid.blocks, blocks_ref)
+        assert np.array_equal(s.get_field(L.VEL), vel_ref[s.part.lo:s.part.hi])
+        counts = [None] * world
+        dist.all_gather_object(counts, s.part.nowned)
+        assert max(counts) - min(counts) <= 1 and sum(counts) == len(blocks_ref)
+        r2 = s.step(tol=1e-9, rel_tol=0.0, max_restarts=100, max_iter=1000)
+        assert np.isfinite(r2["err"]) and r2["err"] <= 1e-9
+        assert not s.comm_errors, s.comm_errors
+        if rank == 0:
+            print("amr_big: %d blocks on %d ranks; step dv %.1e dp %.1e; regrid -> %d blocks" % (nb, world, dv, dp, len(blocks_ref)), flush=True)
+    dist.barrier()
+
+
 def main():
     import torch.distributed as dist
     mode = sys.argv[1]
     px, py, nbx, nby = (int(a) for a in sys.argv[2:6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode == "amr":
-        run_amr_gpu(rank, world)
+    if mode in ("amr", "amr_big"):
+        (run_amr_gpu if mode == "amr" else run_amr_big_gpu)(rank, world)
         if rank == 0:
-            print("DIST_OK mode=amr world=%d" % world)
+            print("DIST_OK mode=%s world=%d" % (mode, world))
         dist.destroy_process_group()
         return
     assert world == px * py

@@ -77,3 +77,9 @@ def test_amr_partition_plans_are_consistent(nranks):
 @pytest.mark.parametrize("world", [2, 3])
 def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world):
     launch("amr", world, 0, 0, 0, 0, 29811 + world, timeout=900)
+
+
+@pytest.mark.gpu
+def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu():
+    """the circle-band grid (three levels, Hilbert order) on three ranks: block operators bit for bit, step, regrid"""
+    launch("amr_big", 3, 0, 0, 0, 0, 29831, timeout=900)

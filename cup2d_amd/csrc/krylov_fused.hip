@@ -53,7 +53,7 @@ constexpr bool PREG = CUP2D_FUSED_PREG != 0;
 // everything.  Policy: a stream that is consumed once, or whose consumer is a whole iteration away, bypasses
 // (p', t, y' stores; y, p, t, rhat loads of sweep E; rhat of sweep AB); the streams the NEXT launch consumes first
 // allocate (nu' for CD, s for E, r for AB) -- and so do the tile and ring loads of AB / CD, whose second touch by the
-// neighbouring tile must find them in L2.  Measured at 4096^2 (tools/build_policy_variants.sh, tools/gpu_call6.sh;
+// neighbouring tile must find them in L2.  Measured at 4096^2 (tools/build_policy_variants.sh, tools/gpu_calls/gpu_call6.sh;
 // A / C / E in us, step in ms):
 //   0x000 nothing non-temporal             200 / 153 / 187   27.9
 //   0x00F stores of AB and CD              201 / 153 / 175   27.4    (the previous default)

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "ctx.h"
 
@@ -100,9 +102,105 @@ int prof_resolve(cup2d_ctx *c) {
   return CUP2D_OK;
 }
 
+// ---- device-memory pool (ctx.h dev_malloc / dev_free) ---------------------------------------------
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, bucket) -> buffers not in use
+  std::map<void *, std::pair<int, size_t>> owner;              // every buffer the pool has handed out or holds
+  size_t idle_bytes = 0;
+  const bool on = [] { const char *e = getenv("CUP2D_POOL"); return !e || atoi(e) != 0; }();
+  const size_t cap = [] { const char *e = getenv("CUP2D_POOL_MAX_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+  static size_t bucket(size_t bytes) {
+    if (bytes < 4096) return 4096;
+    int k = 0;
+    while ((bytes >> k) >= 16) k++;  // bytes >> k in [8, 16)
+    const size_t m = (bytes + ((size_t)1 << k) - 1) >> k;
+    return m << k;
+  }
+};
+DevPool &pool() {
+  static DevPool P;
+  return P;
+}
+}  // namespace
+
+hipError_t dev_malloc_raw(void **p, size_t bytes) {
+  DevPool &P = pool();
+  if (!P.on) return hipMalloc(p, bytes);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t b = DevPool::bucket(bytes ? bytes : 1);
+  void *q = nullptr;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.idle.find({dev, b});
+    if (it != P.idle.end() && !it->second.empty()) {
+      q = it->second.back();
+      it->second.pop_back();
+      P.idle_bytes -= b;
+    }
+  }
+  if (!q) {
+    e = hipMalloc(&q, b);
+    if (e != hipSuccess) {  // out of memory with buffers idling in the pool: give them back and try once more
+      (void)hipGetLastError();
+      cup2d_trim_pool();
+      e = hipMalloc(&q, b);
+      if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.owner[q] = {dev, b};
+  }
+  // zero-filled, always: a recycled buffer must not look different from a fresh one
+  e = hipMemsetAsync(q, 0, b, nullptr);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) return e;
+  *p = q;
+  return hipSuccess;
+}
+
+void dev_free(void *q) {
+  if (!q) return;
+  DevPool &P = pool();
+  std::unique_lock<std::mutex> g(P.mu);
+  auto it = P.owner.find(q);
+  if (it == P.owner.end()) {  // not ours (pool off)
+    g.unlock();
+    (void)hipFree(q);
+    return;
+  }
+  if (P.idle_bytes + it->second.second > P.cap) {
+    P.owner.erase(it);
+    g.unlock();
+    (void)hipFree(q);
+    return;
+  }
+  P.idle[it->second].push_back(q);
+  P.idle_bytes += it->second.second;
+}
+
 }  // namespace cup2d
 
 using namespace cup2d;
+
+extern "C" int cup2d_trim_pool(void) {
+  auto &P = cup2d::pool();
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto &kv : P.idle)
+      for (void *q : kv.second) {
+        drop.push_back(q);
+        P.owner.erase(q);
+      }
+    P.idle.clear();
+    P.idle_bytes = 0;
+  }
+  for (void *q : drop) (void)hipFree(q);
+  return CUP2D_OK;
+}
 
 extern "C" {
 
@@ -159,22 +257,22 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   }
   CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
   CUP2D_HIP_CHECK(hipMemcpy(c->d_nbr, nbr, sizeof(int32_t) * 4 * nblocks, hipMemcpyHostToDevice));
   for (int f = 0; f < CUP2D_NFIELDS; f++) {
     const size_t bytes = slab_doubles(c, dim_of(f)) * sizeof(double);
-    CUP2D_HIP_CHECK(hipMalloc(&c->d_field[f], bytes));
+    CUP2D_HIP_CHECK(dev_malloc(&c->d_field[f], bytes));
     CUP2D_HIP_CHECK(hipMemset(c->d_field[f], 0, bytes));  // calloc, main.cpp:6517
   }
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_vscratch, slab_doubles(c, 2) * sizeof(double)));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_vscratch, slab_doubles(c, 2) * sizeof(double)));
   CUP2D_HIP_CHECK(hipMemset(c->d_vscratch, 0, slab_doubles(c, 2) * sizeof(double)));
   double **kv[] = {&c->d_r, &c->d_rhat, &c->d_p, &c->d_nu, &c->d_t, &c->d_z, &c->d_z2, &c->d_xopt};
   for (double **p : kv) {
-    CUP2D_HIP_CHECK(hipMalloc(p, slab_doubles(c, 1) * sizeof(double)));
+    CUP2D_HIP_CHECK(dev_malloc(p, slab_doubles(c, 1) * sizeof(double)));
     CUP2D_HIP_CHECK(hipMemset(*p, 0, slab_doubles(c, 1) * sizeof(double)));
   }
   build_P_inv(c->h_Pinv);
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_Pinv, BC * BC * sizeof(double)));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_Pinv, BC * BC * sizeof(double)));
   // the dense kernels read d_Pinv[k][n] as the coefficient of input k in output n, i.e. the transpose of
   // the row-major matrix the caller means (cuda.cu:484-486 Dgemm(T,N) on a column-major view); the
   // built-in matrix is exactly symmetric
@@ -188,15 +286,15 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
     }
     for (int i = 0; i < BS; i++)  // exact symmetry
       for (int k = i + 1; k < BS; k++) fd[k * BS + i] = fd[i * BS + k];
-    CUP2D_HIP_CHECK(hipMalloc(&c->d_fd, sizeof fd));
+    CUP2D_HIP_CHECK(dev_malloc(&c->d_fd, sizeof fd));
     CUP2D_HIP_CHECK(hipMemcpy(c->d_fd, fd, sizeof fd, hipMemcpyHostToDevice));
   }
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_partials, sizeof(double) * NSLOT * PSTRIDE));
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_red_own, sizeof(double) * 8));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_partials, sizeof(double) * NSLOT * PSTRIDE));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_red_own, sizeof(double) * 8));
   c->d_red = c->d_red_own;
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_ticket, sizeof(unsigned)));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_ticket, sizeof(unsigned)));
   CUP2D_HIP_CHECK(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
-  CUP2D_HIP_CHECK(hipMalloc(&c->d_sc, sizeof(KrylovScalars)));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
   CUP2D_HIP_CHECK(hipHostMalloc(&c->h_status, sizeof(int) * cup2d_ctx::SOLVE_AHEAD));
@@ -210,25 +308,25 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipDeviceSynchronize();
   (void)comm_finalize_impl(c);
   bodies_release(c);
-  (void)hipFree(c->d_nbr);
-  for (int f = 0; f < CUP2D_NFIELDS; f++) (void)hipFree(c->d_field[f]);
-  (void)hipFree(c->d_vscratch);
+  dev_free(c->d_nbr);
+  for (int f = 0; f < CUP2D_NFIELDS; f++) dev_free(c->d_field[f]);
+  dev_free(c->d_vscratch);
   double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_fd, c->d_partials, c->d_red_own};
-  for (double *p : kv) (void)hipFree(p);
+  for (double *p : kv) dev_free(p);
   double *fv[] = {c->d_p2, c->d_nu2, c->d_s, c->d_y, c->d_yopt};
-  for (double *p : fv) (void)hipFree(p);
-  (void)hipFree(c->d_ticket);
-  (void)hipFree(c->d_sc);
+  for (double *p : fv) dev_free(p);
+  dev_free(c->d_ticket);
+  dev_free(c->d_sc);
   (void)hipHostFree(c->h_sc);
   (void)hipHostFree(c->h_red);
   (void)hipHostFree(c->h_status);
   for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
-  (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
-  (void)hipFree(c->mat.d_reg);
-  (void)hipFree(c->amr.d_level); (void)hipFree(c->amr.d_kind); (void)hipFree(c->amr.d_nbr2); (void)hipFree(c->amr.d_half);
-  (void)hipFree(c->amr.d_faces); (void)hipFree(c->amr.d_faces2);
-  (void)hipFree(c->plan.d_send_block); (void)hipFree(c->plan.d_send_face);
-  (void)hipFree(c->plan.d_recv_block); (void)hipFree(c->plan.d_recv_face);
+  dev_free(c->mat.d_ptr); dev_free(c->mat.d_col); dev_free(c->mat.d_val); dev_free(c->mat.d_gather);
+  dev_free(c->mat.d_reg);
+  dev_free(c->amr.d_level); dev_free(c->amr.d_kind); dev_free(c->amr.d_nbr2); dev_free(c->amr.d_half);
+  dev_free(c->amr.d_faces); dev_free(c->amr.d_faces2);
+  dev_free(c->plan.d_send_block); dev_free(c->plan.d_send_face);
+  dev_free(c->plan.d_recv_block); dev_free(c->plan.d_recv_face);
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -355,19 +453,19 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   cup2d::AmrTopo &A = c->amr;
-  (void)hipFree(A.d_level); (void)hipFree(A.d_kind); (void)hipFree(A.d_nbr2); (void)hipFree(A.d_half); (void)hipFree(A.d_faces); (void)hipFree(A.d_faces2);
+  dev_free(A.d_level); dev_free(A.d_kind); dev_free(A.d_nbr2); dev_free(A.d_half); dev_free(A.d_faces); dev_free(A.d_faces2);
   A = cup2d::AmrTopo();
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_level, sizeof(int32_t) * nb));
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_kind, sizeof(int32_t) * nb * 4));
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_nbr2, sizeof(int32_t) * nb * 8));
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_half, sizeof(int32_t) * nb * 4));
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_faces, sizeof(double) * nb * 4 * BS));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_level, sizeof(int32_t) * nb));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_kind, sizeof(int32_t) * nb * 4));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_nbr2, sizeof(int32_t) * nb * 8));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_half, sizeof(int32_t) * nb * 4));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_faces, sizeof(double) * nb * 4 * BS));
   CUP2D_HIP_CHECK(hipMemcpy(A.d_level, level, sizeof(int32_t) * nb, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(A.d_kind, kind, sizeof(int32_t) * nb * 4, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(A.d_nbr2, nbr2, sizeof(int32_t) * nb * 8, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(A.d_half, half, sizeof(int32_t) * nb * 4, hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemset(A.d_faces, 0, sizeof(double) * nb * 4 * BS));
-  CUP2D_HIP_CHECK(hipMalloc(&A.d_faces2, sizeof(double) * nb * 4 * BS * 2));
+  CUP2D_HIP_CHECK(dev_malloc(&A.d_faces2, sizeof(double) * nb * 4 * BS * 2));
   CUP2D_HIP_CHECK(hipMemset(A.d_faces2, 0, sizeof(double) * nb * 4 * BS * 2));
   A.h_kind.assign(kind, kind + (size_t)nb * 4);
   A.h_nbr2.assign(nbr2, nbr2 + (size_t)nb * 8);
@@ -622,8 +720,8 @@ int cup2d_set_P_inv(cup2d_ctx *c, const double *P) {
 int cup2d_clear_matrix(cup2d_ctx *c) {
   CUP2D_CHECK_CTX(c);
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  (void)hipFree(c->mat.d_ptr); (void)hipFree(c->mat.d_col); (void)hipFree(c->mat.d_val); (void)hipFree(c->mat.d_gather);
-  (void)hipFree(c->mat.d_reg); (void)hipFree(c->mat.d_fnbr); (void)hipFree(c->mat.d_zmask); (void)hipFree(c->mat.d_tile0); (void)hipFree(c->mat.d_gen);
+  dev_free(c->mat.d_ptr); dev_free(c->mat.d_col); dev_free(c->mat.d_val); dev_free(c->mat.d_gather);
+  dev_free(c->mat.d_reg); dev_free(c->mat.d_fnbr); dev_free(c->mat.d_zmask); dev_free(c->mat.d_tile0); dev_free(c->mat.d_gen);
   c->mat = SellMatrix();
   return CUP2D_OK;
 }
@@ -634,15 +732,15 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
   const auto stored = [&](int s) { return reg[(size_t)4 * s] == SELL_STORED; };
   CUP2D_TRY(cup2d_clear_matrix(c));
   SellMatrix &M = c->mat;
-  CUP2D_HIP_CHECK(hipMalloc(&M.d_ptr, ptr.size() * sizeof(long long)));
+  CUP2D_HIP_CHECK(dev_malloc(&M.d_ptr, ptr.size() * sizeof(long long)));
   CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
   if (entries) {
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_col, entries * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_val, entries * sizeof(double)));
+    CUP2D_HIP_CHECK(dev_malloc(&M.d_col, entries * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&M.d_val, entries * sizeof(double)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval.data(), entries * sizeof(double), hipMemcpyHostToDevice));
   }
-  CUP2D_HIP_CHECK(hipMalloc(&M.d_reg, reg.size() * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(dev_malloc(&M.d_reg, reg.size() * sizeof(int32_t)));
   CUP2D_HIP_CHECK(hipMemcpy(M.d_reg, reg.data(), reg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   M.nregular = nregular;
   M.entries = entries;
@@ -698,15 +796,15 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
       }
     }
     M.ntiles = ntiles;
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_fnbr, fnbr.data(), fnbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMalloc(&M.d_zmask, M.h_zmask.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&M.d_zmask, M.h_zmask.size() * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_zmask, M.h_zmask.data(), M.h_zmask.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     M.ngen = (int)gen.size();
     if (M.ngen) {
-      CUP2D_HIP_CHECK(hipMalloc(&M.d_gen, gen.size() * sizeof(int32_t)));
+      CUP2D_HIP_CHECK(dev_malloc(&M.d_gen, gen.size() * sizeof(int32_t)));
       CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
   }
@@ -843,11 +941,11 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
   for (int i = 0; i < nsend; i++)
     if (idx[i] < 0 || idx[i] >= c->nblocks * BC) { set_error("set_gather: idx[%d] = %d", i, idx[i]); return CUP2D_ERR_ARG; }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  (void)hipFree(c->mat.d_gather);
+  dev_free(c->mat.d_gather);
   c->mat.d_gather = nullptr;
   c->mat.ngather = nsend;
   if (nsend) {
-    CUP2D_HIP_CHECK(hipMalloc(&c->mat.d_gather, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&c->mat.d_gather, nsend * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(c->mat.d_gather, idx, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (c->mat.d_zmask) {  // the fused sweeps store z where it is read from memory: the gathered entries are
@@ -892,18 +990,18 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
   for (int i = 0; i < nrecv; i++)
     if (rb[i] < c->nblocks || rb[i] >= c->ntotal || rf[i] < 0 || rf[i] > 3) { set_error("halo_plan: recv entry %d", i); return CUP2D_ERR_ARG; }
   HaloPlan &p = c->plan;
-  (void)hipFree(p.d_send_block); (void)hipFree(p.d_send_face); (void)hipFree(p.d_recv_block); (void)hipFree(p.d_recv_face);
+  dev_free(p.d_send_block); dev_free(p.d_send_face); dev_free(p.d_recv_block); dev_free(p.d_recv_face);
   p = HaloPlan();
   p.nsend = nsend; p.nrecv = nrecv;
   if (nsend) {
-    CUP2D_HIP_CHECK(hipMalloc(&p.d_send_block, nsend * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMalloc(&p.d_send_face, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&p.d_send_block, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&p.d_send_face, nsend * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_send_block, sb, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_send_face, sf, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (nrecv) {
-    CUP2D_HIP_CHECK(hipMalloc(&p.d_recv_block, nrecv * sizeof(int32_t)));
-    CUP2D_HIP_CHECK(hipMalloc(&p.d_recv_face, nrecv * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&p.d_recv_block, nrecv * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(dev_malloc(&p.d_recv_face, nrecv * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_block, rb, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_face, rf, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
   }

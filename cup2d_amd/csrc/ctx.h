@@ -254,6 +254,15 @@ int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
 int launch_precond_add(cup2d_ctx *c, const double *y, double *x, double *tmp);
 int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the installed SellMatrix
+// Device memory of a context comes from a per-process pool (api.hip): cup2d_destroy / cup2d_clear_matrix / a new
+// cup2d_set_amr hand their buffers back, the next context -- after every regrid a host builds one -- takes them again
+// instead of paying hipFree + hipMalloc (28 ms of a 89 ms regrid on a 63 k-block grid).  Sizes are rounded up to
+// m * 2^k, m in 8..15 (<= 12.5 % slack) so that a grid that grew or shrank a little still finds its buffers; a buffer
+// is ALWAYS handed out zero-filled.  CUP2D_POOL=0 turns the pool off; cup2d_trim_pool() returns the cache to the driver.
+hipError_t dev_malloc_raw(void **p, size_t bytes);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_raw(reinterpret_cast<void **>(p), bytes); }
+void dev_free(void *p);
 // amr_host.hip: the Poisson operator of an adapted grid straight in the hybrid sliced-ELL form
 void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half, std::vector<int32_t> &reg,
                          std::vector<long long> &ptr, std::vector<int32_t> &ecol, std::vector<double> &eval, int *nregular);

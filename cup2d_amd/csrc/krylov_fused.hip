@@ -639,7 +639,7 @@ static int ensure_fused_buffers(cup2d_ctx *c) {
   double **v[] = {&c->d_p2, &c->d_nu2, &c->d_s, &c->d_y, &c->d_yopt, &c->d_z};
   for (double **p : v)
     if (!*p) {
-      CUP2D_HIP_CHECK(hipMalloc(p, bytes));
+      CUP2D_HIP_CHECK(dev_malloc(p, bytes));
       CUP2D_HIP_CHECK(hipMemsetAsync(*p, 0, bytes, c->stream));
     }
   return CUP2D_OK;

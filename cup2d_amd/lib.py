@@ -30,7 +30,7 @@ SYMBOLS = [
     "cup2d_max_abs_vel", "cup2d_compute_dt", "cup2d_poisson_solve", "cup2d_apply_A", "cup2d_precond",
     "cup2d_get_P_inv", "cup2d_step", "cup2d_halo_plan", "cup2d_halo_pack", "cup2d_halo_unpack",
     "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_timing", "cup2d_get_timing",
-    "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather", "cup2d_matrix_stats", "cup2d_amr_install_poisson",
+    "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather", "cup2d_matrix_stats", "cup2d_amr_install_poisson", "cup2d_trim_pool",
     "cup2d_set_solver", "cup2d_get_last_solver", "cup2d_set_amr", "cup2d_amr_poisson_coo", "cup2d_amr_tables", "cup2d_amr_validate_states", "cup2d_amr_regrid",
     "cup2d_jacobi_sweeps", "cup2d_poisson_residual", "cup2d_block_linf",
     "cup2d_comm_unique_id", "cup2d_comm_init", "cup2d_comm_finalize", "cup2d_comm_stats", "cup2d_halo_exchange",
@@ -115,6 +115,7 @@ def load_library():
     L.cup2d_set_gather.argtypes = [vp, i, vp]
     L.cup2d_matrix_stats.argtypes = [vp, vp, vp, vp]
     L.cup2d_amr_install_poisson.argtypes = [vp]
+    L.cup2d_trim_pool.argtypes = []
     L.cup2d_step.argtypes = [vp, d, d, d, d, i, i, ctypes.POINTER(d), ctypes.POINTER(i), ctypes.POINTER(d)]
     L.cup2d_halo_plan.argtypes = [vp, i, vp, vp, i, vp, vp]
     L.cup2d_halo_pack.argtypes = [vp, i, i, vp]

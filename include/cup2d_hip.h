@@ -74,6 +74,11 @@ typedef enum { CUP2D_BLOCKS_ALL = 0, CUP2D_BLOCKS_INNER = 1, CUP2D_BLOCKS_HALO =
 int cup2d_create(cup2d_ctx **ctx, int nblocks, int nghost, int n_inner, const int32_t *nbr, double h,
                  int device);
 void cup2d_destroy(cup2d_ctx *ctx);
+/* A context's device buffers come from a per-process pool: cup2d_destroy (and cup2d_clear_matrix, a new cup2d_set_amr)
+ * hand them back to it, the next context takes them again -- a host that regrids builds a new context every few steps.
+ * Buffers are always handed out zero-filled.  cup2d_trim_pool returns the idle buffers to the driver; CUP2D_POOL=0 turns
+ * the pool off, CUP2D_POOL_MAX_GB (default 64) bounds what it keeps. */
+int cup2d_trim_pool(void);
 const char *cup2d_last_error(void);
 const char *cup2d_version(void);
 /* run every later call on this hipStream_t (NULL = the context's own stream) */

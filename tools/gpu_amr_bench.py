@@ -40,6 +40,8 @@ with A.AmrSimulation(g) as s:
     el = (time.perf_counter() - t0) / nst
     print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e  [%s solver]"
           % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"], s.last_solver()), flush=True)
+    if os.environ.get("NOTIMING"):
+        sys.exit(0)
     L.check(s.L.cup2d_set_timing(s._ctx, 1))  # per-launch events: the breakdown below, not the figure above
     for _ in range(3):
         r = s.step(max_iter=50)

@@ -248,6 +248,43 @@ def run_amr_gpu(rank, world):
     dist.barrier()
 
 
+def run_amr_cpu(rank, world):
+    """the AMR plan in a real exchange (gloo, host tensors): every rank packs the blocks its peers list as ghosts, one
+    batched send/receive per peer with the plan's offsets and counts (different in the two directions), and every ghost
+    block that arrives is the owner's block of that global id; then the face arrays (4 faces x 8 x dim per sent block) and
+    the two reductions of the AMR step (max, and the {sum, sum} pair of the volume-weighted mean)."""
+    import torch
+    import torch.distributed as dist
+    from cup2d_amd.amr import AmrBlockGrid, circle_band_grid
+    from cup2d_amd.amr_dist import AmrPartition
+    from cup2d_amd.distributed import TorchComm
+    for G in (AmrBlockGrid(np.load(os.path.join(ROOT, "tests", "golden", "amr_functors.npz"))["blocks"]), circle_band_grid(6)):
+        P = AmrPartition(G, world, rank)
+        cm = TorchComm(P, "host")
+        nb = G.nblocks
+        for unit, seed in ((64, 1), (128, 2), (32, 3)):  # a scalar block, two scalar blocks / one vector block, a scalar face array
+            field = np.random.default_rng(seed).uniform(-1, 1, (nb, unit))  # the same global field on every rank
+            slab = np.zeros((P.nowned + P.nghost, unit))
+            slab[:P.nowned] = field[P.lo:P.hi]
+            cm.send[:P.nsend * unit] = torch.from_numpy(slab[P.send_block].ravel())
+            cm.exchange(unit)
+            cm.wait()
+            got = cm.recv[:P.nrecv * unit].numpy().reshape(P.nrecv, unit)
+            slab[P.recv_block] = got
+            assert np.array_equal(slab, field[P.local_ids]), (rank, unit)
+        # reductions as the AMR step issues them
+        cm.red[0] = float(rank + 1)
+        cm.allreduce(0, 1, 1)  # max
+        assert cm.red[0].item() == float(world)
+        cm.red[0], cm.red[1] = 0.5 * (rank + 1), 2.0
+        cm.allreduce(0, 2, 0)  # sums
+        assert cm.red[0].item() == 0.5 * world * (world + 1) / 2 and cm.red[1].item() == 2.0 * world
+        # the ghost tables are closed under what the kernels read: every non-wall side of an owned block is held
+        k = P.kind[:P.nowned]
+        assert (P.nbr2[:P.nowned][k != 0][:, 0] >= 0).all() and (P.nbr2[:P.nowned][k == 3] >= 0).all()
+    dist.barrier()
+
+
 def run_amr_big_gpu(rank, world):
     """the same on a grid of 4 084 blocks (three levels, a band around a circle, Hilbert order): the single context on the
     whole grid is the reference here -- every block operator on a rank's owned blocks bit for bit, a step to the solve
@@ -325,8 +362,8 @@ def main():
     px, py, nbx, nby = (int(a) for a in sys.argv[2:6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode in ("amr", "amr_big"):
-        (run_amr_gpu if mode == "amr" else run_amr_big_gpu)(rank, world)
+    if mode in ("amr", "amr_big", "amr_cpu"):
+        {"amr": run_amr_gpu, "amr_big": run_amr_big_gpu, "amr_cpu": run_amr_cpu}[mode](rank, world)
         if rank == 0:
             print("DIST_OK mode=%s world=%d" % (mode, world))
         dist.destroy_process_group()

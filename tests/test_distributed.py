@@ -83,3 +83,10 @@ def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world):
 def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu():
     """the circle-band grid (three levels, Hilbert order) on three ranks: block operators bit for bit, step, regrid"""
     launch("amr_big", 3, 0, 0, 0, 0, 29831, timeout=900)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_amr_whole_block_exchange_cpu_gloo(world):
+    """the adapted-grid plan driven through a real multi-process exchange on the CPU (gloo): ghost blocks, face arrays,
+    reductions"""
+    launch("amr_cpu", world, 0, 0, 0, 0, 29851 + world)

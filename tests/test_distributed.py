@@ -90,3 +90,44 @@ def test_amr_whole_block_exchange_cpu_gloo(world):
     """the adapted-grid plan driven through a real multi-process exchange on the CPU (gloo): ghost blocks, face arrays,
     reductions"""
     launch("amr_cpu", world, 0, 0, 0, 0, 29851 + world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("px,py", [(2, 1), (1, 2), (2, 2)])
+def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py):
+    """csrc/cup2d_run_mpi.cpp -- the N-rank time loop with the host side in C++ (Cartesian plan, cup2d_halo_plan, the
+    callback transport over MPI; with one GPU per rank the same program takes the in-library RCCL communicator) -- on
+    ranks sharing the one GPU: three steps of the Taylor-Green vortex land on the single-context run (dt to round-off,
+    fields to the solve tolerance)."""
+    import shutil
+    import numpy as np
+    import cup2d_amd
+    exe = os.path.join(ROOT, "cup2d_amd", "cup2d_run_mpi")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    assert os.path.exists(exe) and os.path.exists(mpiexec), "cup2d_run_mpi / mpiexec not shipped"
+    n, steps, iters = 128, 3, 400
+    cmd = [mpiexec, "-n", str(px * py), exe, "-n", str(n), "-px", str(px), "-py", str(py), "-steps", str(steps), "-maxiter", str(iters),
+           "-comm", "mpi", "-math", "strict", "-state", str(tmp_path / "s")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "done: %d steps on %d ranks" % (steps, px * py) in out, out[-3000:]
+    dts = [float(line.split()[5]) for line in out.splitlines() if line.startswith("step ")]
+    h = 1.0 / n
+    c = (np.arange(n) + 0.5) * h
+    X, Y = np.meshgrid(c, c, indexing="xy")
+    vel0 = np.stack([np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y), -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)], -1)
+    with cup2d_amd.Simulation(n // 8, nu=1e-3) as s:
+        s.set_math(True)
+        s.vel = vel0
+        ref_dt = [s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=iters)["dt"] for _ in range(steps)]
+        vref, pref = s.vel, s.pres
+    assert np.allclose(dts, ref_dt, rtol=1e-10, atol=0), (dts, ref_dt)
+    pnx, pny = n // px, n // py
+    vel, pres = np.empty((n, n, 2)), np.empty((n, n))
+    for rank in range(px * py):
+        cx, cy = rank % px, rank // px
+        vel[cy * pny:(cy + 1) * pny, cx * pnx:(cx + 1) * pnx] = np.fromfile(tmp_path / ("s.%d.vel.f64" % rank)).reshape(pny, pnx, 2)
+        pres[cy * pny:(cy + 1) * pny, cx * pnx:(cx + 1) * pnx] = np.fromfile(tmp_path / ("s.%d.pres.f64" % rank)).reshape(pny, pnx)
+    dv, dp = np.abs(vel - vref).max(), np.abs(pres - pref).max()
+    print("cup2d_run_mpi %dx%d: max|dv| %.2e max|dp| %.2e" % (px, py, dv, dp))
+    assert dv < 1e-9 and dp < 1e-8, (dv, dp)

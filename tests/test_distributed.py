@@ -93,12 +93,13 @@ def test_amr_whole_block_exchange_cpu_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("px,py", [(2, 1), (1, 2), (2, 2)])
-def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py):
+@pytest.mark.parametrize("px,py,comm", [(2, 1, "mpi"), (1, 2, "mpi"), (2, 2, "mpi"), (1, 1, "rccl")])
+def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py, comm):
     """csrc/cup2d_run_mpi.cpp -- the N-rank time loop with the host side in C++ (Cartesian plan, cup2d_halo_plan, the
     callback transport over MPI; with one GPU per rank the same program takes the in-library RCCL communicator) -- on
     ranks sharing the one GPU: three steps of the Taylor-Green vortex land on the single-context run (dt to round-off,
-    fields to the solve tolerance)."""
+    fields to the solve tolerance).  (1, 1, rccl): the program's RCCL branch -- token over MPI_Bcast, cup2d_comm_init,
+    every reduction an ncclAllGather -- on the one rank a one-GPU box allows."""
     import shutil
     import numpy as np
     import cup2d_amd
@@ -107,8 +108,9 @@ def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py):
     assert os.path.exists(exe) and os.path.exists(mpiexec), "cup2d_run_mpi / mpiexec not shipped"
     n, steps, iters = 128, 3, 400
     cmd = [mpiexec, "-n", str(px * py), exe, "-n", str(n), "-px", str(px), "-py", str(py), "-steps", str(steps), "-maxiter", str(iters),
-           "-comm", "mpi", "-math", "strict", "-state", str(tmp_path / "s")]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
+           "-comm", comm, "-math", "strict", "-state", str(tmp_path / "s")]
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT, env=env)
     out = r.stdout.decode()
     assert r.returncode == 0 and "done: %d steps on %d ranks" % (steps, px * py) in out, out[-3000:]
     dts = [float(line.split()[5]) for line in out.splitlines() if line.startswith("step ")]

@@ -403,6 +403,7 @@ int cup2d_field_ptr(cup2d_ctx *c, int field, void **p) {
   CHECK_FIELD(field);
   if (!p) return CUP2D_ERR_ARG;
   *p = c->d_field[field];
+  if (field == CUP2D_VEL) c->vel_ptr_exposed = true;  // the caller may write the velocity behind the library's back
   return CUP2D_OK;
 }
 __global__ void k_fill(double *p, double v, size_t n) {
@@ -561,24 +562,26 @@ int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
   if (c->amr.active) return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1);
   return launch_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1, first, count);
 }
-int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
-  CUP2D_CHECK_CTX(c);
-  if (c->amr.active) {
-    if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
-    return amr_poisson_rhs(c, dt);
-  }
-  if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
+// zero_pres = false (cup2d_step only): the solve that follows is told that its initial guess is zero (ctx.h x0_is_zero)
+// and neither reads nor needs the fill -- pres receives the solution
+static int poisson_rhs_uniform(cup2d_ctx *c, double dt, int use_bodies, bool zero_pres) {
   // pold = pres; pres = 0 (main.cpp:7016-7021): a device copy, not a pointer swap -- the slab pointers a caller got
   // from cup2d_field_ptr stay valid for the life of the context
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_POLD], c->d_field[CUP2D_PRES], (size_t)c->nblocks * BC * sizeof(double),
                                  hipMemcpyDeviceToDevice, c->stream));
-  CUP2D_TRY(launch_zero(c, c->d_field[CUP2D_PRES], slab_doubles(c, 1)));
+  if (zero_pres) CUP2D_TRY(launch_zero(c, c->d_field[CUP2D_PRES], slab_doubles(c, 1)));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_POLD], 1, 1));
   if (use_bodies) CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_TMPV], 2, 1));
   return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
                              use_bodies ? c->d_field[CUP2D_CHI] : nullptr, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], dt,
                              0, c->nblocks);
+}
+int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
+  CUP2D_CHECK_CTX(c);
+  if (!(dt > 0)) { set_error("poisson_rhs: dt"); return CUP2D_ERR_ARG; }
+  if (c->amr.active) return amr_poisson_rhs(c, dt);
+  return poisson_rhs_uniform(c, dt, use_bodies, true);
 }
 int cup2d_pressure_correction(cup2d_ctx *c, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
@@ -604,7 +607,10 @@ int cup2d_project(cup2d_ctx *c, double dt) {
 int cup2d_max_abs_vel(cup2d_ctx *c, double *umax) {
   CUP2D_CHECK_CTX(c);
   if (!umax) return CUP2D_ERR_ARG;
-  CUP2D_TRY(launch_max_abs(c, c->d_field[CUP2D_VEL], (size_t)c->nblocks * BC * 2, c->d_red));
+  if (c->use_cached_umax)  // the maxima the previous step's projection left (ctx.h umax_partials)
+    CUP2D_TRY(launch_max_from_partials(c, c->d_partials + (size_t)3 * PSTRIDE, c->umax_partials, c->d_red));
+  else
+    CUP2D_TRY(launch_max_abs(c, c->d_field[CUP2D_VEL], (size_t)c->nblocks * BC * 2, c->d_red));
   if (c->allreduce && c->allreduce(c->comm_user, c->d_red, 1, 1, c->stream) != 0) return CUP2D_ERR_COMM;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_red, c->d_red, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -966,16 +972,34 @@ int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max
     set_error("step: on an adapted grid install the assembled Poisson operator first (cup2d_set_matrix_coo)");
     return CUP2D_ERR_UNSUPPORTED;
   }
+  // the previous call on this context was a cup2d_step that left max|u| of its result behind (ctx.h)
+  c->use_cached_umax = !c->amr.active && !c->vel_ptr_exposed && c->umax_partials > 0 && c->api_calls == c->umax_valid_at + 1;
   double dt = 0;
-  CUP2D_TRY(cup2d_compute_dt(c, nu, cfl, &dt));
+  const int rc_dt = cup2d_compute_dt(c, nu, cfl, &dt);
+  c->use_cached_umax = false;
+  c->umax_partials = 0;
+  CUP2D_TRY(rc_dt);
   if (!(dt > 2e-16)) {  // main.cpp:6596
     if (dt_out) *dt_out = dt;
     return CUP2D_OK;
   }
   CUP2D_TRY(cup2d_advect_diffuse_rk2(c, nu, dt));
-  CUP2D_TRY(cup2d_poisson_rhs(c, dt, 0));
-  CUP2D_TRY(cup2d_poisson_solve(c, max_error, max_rel_error, max_restarts, max_iter, iters, nullptr, linf, nullptr));
+  // the same-level stencil with the tile-fused solver: pres = 0 is the solve's initial guess (main.cpp:7016-7021) and
+  // that solver works on the correction alone (x = x0 + P_inv y) -- told that x0 = 0 it forms r = b without reading x and
+  // writes x = P_inv y at the end: no fill of pres, no stencil pass over zeros, one read less in the last pass.  The
+  // numbers are the ones the unfused sequence produces (b - A 0 = b and 0 + v = v exactly).
+  const bool lazy_zero = !c->amr.active && !c->mat.active && c->solver == CUP2D_SOLVER_FUSED && fused_supported(c);
+  if (lazy_zero) {
+    CUP2D_TRY(poisson_rhs_uniform(c, dt, 0, false));
+    c->x0_is_zero = true;
+  } else {
+    CUP2D_TRY(cup2d_poisson_rhs(c, dt, 0));
+  }
+  const int rc_solve = cup2d_poisson_solve(c, max_error, max_rel_error, max_restarts, max_iter, iters, nullptr, linf, nullptr);
+  c->x0_is_zero = false;
+  CUP2D_TRY(rc_solve);
   CUP2D_TRY(cup2d_project(c, dt));
+  c->umax_valid_at = c->api_calls;  // (umax_partials > 0 only if the same-level projection kernel wrote them)
   if (dt_out) *dt_out = dt;
   return CUP2D_OK;
 }

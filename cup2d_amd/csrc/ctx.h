@@ -34,6 +34,7 @@ void set_error(const char *fmt, ...);
       return CUP2D_ERR_ARG;                                  \
     }                                                        \
     CUP2D_HIP_CHECK(hipSetDevice((c)->device));              \
+    (c)->api_calls++;                                        \
   } while (0)
 #define CUP2D_TRY(expr)        \
   do {                         \
@@ -154,6 +155,14 @@ struct cup2d_ctx {
   cup2d::KrylovScalars *d_sc = nullptr;
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned
   static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)
+  bool x0_is_zero = false;               // set by cup2d_step around its solve: the initial guess is zero, PRES is not read
+  // max|u| of the velocity a cup2d_step leaves behind: its projection kernel writes per-workgroup maxima (slot 3 of
+  // d_partials) and the NEXT cup2d_step takes its dt from them instead of reading the field again -- valid only if that
+  // step is the very next call on the context (every entry point counts itself in api_calls) and nobody holds a raw
+  // pointer to VEL (cup2d_field_ptr).  A maximum does not depend on the order it is taken in: the same number.
+  unsigned long long api_calls = 0, umax_valid_at = ~0ull;
+  int umax_partials = 0;
+  bool vel_ptr_exposed = false, use_cached_umax = false;
   int *h_status = nullptr;               // pinned [SOLVE_AHEAD], written by the last scalar kernel of an iteration
   hipEvent_t solve_ev[SOLVE_AHEAD] = {nullptr};
   double *h_red = nullptr;               // pinned [8]
@@ -245,8 +254,9 @@ int launch_vorticity(cup2d_ctx *c, const double *vel, double *out, int first, in
 int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi,
                         const double *pold, double *out, double dt, int first, int count);
 int launch_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int first, int count);
+int launch_max_from_partials(cup2d_ctx *c, const double *partials, int n, double *d_out);
 int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double *vel, double dt,
-                               int fused_update, int first, int count);
+                               int fused_update, int first, int count, double *umax_partials = nullptr);
 int launch_axpy_field(cup2d_ctx *c, double *y, const double *x, double a, size_t n);
 int launch_zero(cup2d_ctx *c, double *v, size_t n);
 int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out);

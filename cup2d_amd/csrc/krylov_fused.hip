@@ -645,7 +645,7 @@ static int ensure_fused_buffers(cup2d_ctx *c) {
   return CUP2D_OK;
 }
 
-int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP);  // krylov.hip
+int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP, bool x0_zero);  // krylov.hip
 
 // one wave per 16-block tile; 8 waves = ONE 512-thread workgroup per CU (P_inv fragments + 8 staging tiles
 // are 134 KiB of its 160 KiB LDS)
@@ -760,6 +760,8 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                      int *restarts, double *linf, double *linf_init) {
   CUP2D_TRY(ensure_fused_buffers(c));
+  // cup2d_step's solve on the same-level stencil: the initial guess is zero and PRES need not hold it (api.hip)
+  const bool x0_zero = c->x0_is_zero && !c->mat.active;
   const int nb = c->nblocks;
   const size_t n = (size_t)nb * BC;
   double *x = c->d_field[CUP2D_PRES];
@@ -813,7 +815,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   int GP = 0;
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
-    CUP2D_TRY(launch_init_residual(c, x, b, &GP));
+    CUP2D_TRY(launch_init_residual(c, x, b, &GP, x0_zero));
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
   // p, nu start at zero (cuda.cu:436-437): the first AB sweep knows (k_fused: fresh) and does not use them; the
@@ -878,7 +880,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
   const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];
-  CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
+  if (x0_zero) CUP2D_TRY(launch_precond(c, ybest, x, 0, nb));  // x = 0 + P_inv y_opt, written, not added
+  else CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (iters) *iters = c->h_sc->iter;
   if (restarts) *restarts = c->h_sc->restarts;

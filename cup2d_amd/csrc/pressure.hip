@@ -120,12 +120,14 @@ int launch_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int
 template <bool UPDATE>
 __global__ __launch_bounds__(WG) void k_pressure_correction(const double *__restrict__ pres, double2 *__restrict__ tmpV,
                                                             double2 *__restrict__ vel, const int *__restrict__ nbr,
-                                                            int first, int count, double pFac, double ih2) {
+                                                            int first, int count, double pFac, double ih2,
+                                                            double *__restrict__ umax_partials) {
   __shared__ double slabs[WPG][LAB1 * LAB1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *slab = slabs[wave];
   const int ix = lane & 7, iy = lane >> 3;
   const int c0 = (iy + 1) * LAB1 + ix + 1;
+  double m[1] = {0.0};  // UPDATE: max|u| of the velocity written (the next step's dt, ctx.h umax_partials)
   const GroupRange gr = group_range(count);
   for (int g = gr.begin; g < gr.end; g += gr.stride) {
     const int rel = g * WPG + wave;
@@ -142,27 +144,30 @@ __global__ __launch_bounds__(WG) void k_pressure_correction(const double *__rest
         v.x += t.x * ih2;
         v.y += t.y * ih2;
         vel[o] = v;
+        m[0] = fmax(m[0], fmax(fabs(v.x), fabs(v.y)));
       } else {
         tmpV[o] = t;
       }
       wave_lds_sync();
     }
   }
+  if (UPDATE && umax_partials) workgroup_reduce_store<1, true>(m, umax_partials, 3);
 }
 
 int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double *vel, double dt, int fused_update,
-                               int first, int count) {
+                               int first, int count, double *umax_partials) {
   if (count <= 0) return CUP2D_OK;
   const double pFac = -0.5 * dt * c->h;  // main.cpp:6027
   const double ih2 = 1.0 / c->h / c->h;  // main.cpp:7182
   const int grid = grid_for(c, count);
   if (fused_update)
     hipLaunchKernelGGL(k_pressure_correction<true>, dim3(grid), dim3(WG), 0, c->stream, pres, (double2 *)tmpV,
-                       (double2 *)vel, c->d_nbr, first, count, pFac, ih2);
+                       (double2 *)vel, c->d_nbr, first, count, pFac, ih2, umax_partials);
   else
     hipLaunchKernelGGL(k_pressure_correction<false>, dim3(grid), dim3(WG), 0, c->stream, pres, (double2 *)tmpV,
-                       (double2 *)vel, c->d_nbr, first, count, pFac, ih2);
+                       (double2 *)vel, c->d_nbr, first, count, pFac, ih2, nullptr);
   CUP2D_HIP_CHECK(hipGetLastError());
+  if (fused_update && umax_partials) c->umax_partials = grid;
   return CUP2D_OK;
 }
 
@@ -251,6 +256,13 @@ static int reduce_field(cup2d_ctx *c, const double *v, size_t n, int op, double 
   return CUP2D_OK;
 }
 int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out) { return reduce_field(c, v, n, 1, d_out); }
+// max over n per-workgroup maxima (slot 3 of d_partials after the projection of a cup2d_step)
+int launch_max_from_partials(cup2d_ctx *c, const double *partials, int n, double *d_out) {
+  ProfScope prof(c, CUP2D_T_REDUCE);
+  hipLaunchKernelGGL(k_reduce_final<1>, dim3(1), dim3(WG), 0, c->stream, partials, n, d_out);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
 
 // out[b] = max |f| over the 64 cells of block b (the per-block Linf norm the reference tags blocks by, main.cpp:4671-4690)
 __global__ __launch_bounds__(WG) void k_block_linf(const double *__restrict__ f, double *__restrict__ out, int nblocks) {
@@ -269,17 +281,22 @@ int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out) {
 // out = (a - shift[0]*s0) (+ b - shift2...) helpers for the mean removal, main.cpp:7120-7173
 // MODE 0: p = p - mean0                    (7143-7148)   mean0 = red[0] / ncells_total
 // MODE 1: p = p + pold - mean1             (7166-7172)
+// MODE 0 also leaves the per-workgroup partial sums of the shifted field -- the second mean (7148-7158) -- in the loop
+// structure of k_reduce_partial<0> (same grid, same order: the sum is the one that kernel would compute, bit for bit)
 template <int MODE>
 __global__ __launch_bounds__(WG) void k_shift(double *__restrict__ p, const double *__restrict__ pold,
-                                              const double *__restrict__ red, double inv_cells, size_t n2) {
+                                              const double *__restrict__ red, double inv_cells, size_t n2,
+                                              double *__restrict__ partials) {
   double2 *p2 = (double2 *)p;
   const double2 *q2 = (const double2 *)pold;
   const double avg = red[0] * inv_cells;
+  double acc[1] = {0.0};
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
     double2 v = p2[i];
     if (MODE == 0) {
       v.x += -avg;
       v.y += -avg;
+      acc[0] += v.x + v.y;
     } else {
       const double2 q = q2[i];
       v.x += q.x - avg;
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(WG) void k_shift(double *__restrict__ p, const doub
     }
     p2[i] = v;
   }
+  if (MODE == 0) workgroup_reduce_store<1, false>(acc, partials, 0);
 }
 
 // main.cpp:7120-7187.  With uniform h the h^2 weights cancel: avg = sum(p)/ncells.  The global cell
@@ -300,7 +318,13 @@ int project_impl(cup2d_ctx *c, double dt) {
   double *pold = c->d_field[CUP2D_POLD];
   double cells = (double)n;
   for (int pass = 0; pass < 2; pass++) {
-    CUP2D_TRY(reduce_field(c, pres, n, 0, c->d_red));
+    if (pass == 0) {
+      CUP2D_TRY(reduce_field(c, pres, n, 0, c->d_red));
+    } else {  // the partial sums of the shifted field are there (k_shift<0>, same grid as reduce_field's)
+      ProfScope prof(c, CUP2D_T_REDUCE);
+      hipLaunchKernelGGL(k_reduce_final<0>, dim3(1), dim3(WG), 0, c->stream, c->d_partials, grid, c->d_red);
+      CUP2D_HIP_CHECK(hipGetLastError());
+    }
     if (c->allreduce) {
       // second entry carries the cell count (main.cpp:7137: quantities[1] = avg1)
       CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_red + 1, &cells, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -314,14 +338,14 @@ int project_impl(cup2d_ctx *c, double dt) {
     }
     const double inv = 1.0 / cells;
     if (pass == 0)
-      hipLaunchKernelGGL(k_shift<0>, dim3(grid), dim3(WG), 0, c->stream, pres, pold, c->d_red, inv, n2);
+      hipLaunchKernelGGL(k_shift<0>, dim3(grid), dim3(WG), 0, c->stream, pres, pold, c->d_red, inv, n2, c->d_partials);
     else
-      hipLaunchKernelGGL(k_shift<1>, dim3(grid), dim3(WG), 0, c->stream, pres, pold, c->d_red, inv, n2);
+      hipLaunchKernelGGL(k_shift<1>, dim3(grid), dim3(WG), 0, c->stream, pres, pold, c->d_red, inv, n2, c->d_partials);
     CUP2D_HIP_CHECK(hipGetLastError());
     cells = (double)n;
   }
   CUP2D_TRY(exchange_halo(c, pres, 1, 1));
-  return launch_pressure_correction(c, pres, nullptr, c->d_field[CUP2D_VEL], dt, 1, 0, c->nblocks);
+  return launch_pressure_correction(c, pres, nullptr, c->d_field[CUP2D_VEL], dt, 1, 0, c->nblocks, c->d_partials);
 }
 
 }  // namespace cup2d

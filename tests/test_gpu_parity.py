@@ -274,3 +274,36 @@ def test_properties_at_scale(gpu_lib):
         r = s.step(tol=0.0, rel_tol=1e-3, max_restarts=100, max_iter=400)
         assert r["iters"] < 400  # converged on the relative tolerance before the cap
         assert np.isfinite(s.vel).all() and np.abs(s.vel).max() < 1.1
+
+
+@pytest.mark.gpu
+def test_consecutive_steps_reuse_what_the_previous_step_left_gpu(gpu_lib, oracle):
+    """cup2d_step's short cuts between consecutive calls -- max|u| for dt from the maxima the previous projection kernel
+    wrote, the solve told that its initial guess is zero instead of filling pres -- change no number: a run of bare
+    step() calls equals a run where another call on the context sits between the steps (which switches the max|u| short
+    cut off) and equals the sequence of the separate entry points."""
+    import cup2d_amd
+    from cup2d_amd import lib as L
+    n = 128
+    vel = oracle.taylor_green(n)
+    runs = []
+    for mode in ("bare", "interleaved", "separate"):
+        with cup2d_amd.Simulation(n // 8, nu=1e-3) as s:
+            s.vel = vel
+            dts = []
+            for k in range(4):
+                if mode == "separate":
+                    dt = s.compute_dt()
+                    s.advect_diffuse_rk2(dt)
+                    s.poisson_rhs(dt)
+                    s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=60)
+                    s.project(dt)
+                    dts.append(dt)
+                else:
+                    dts.append(s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=60)["dt"])
+                    if mode == "interleaved":
+                        s.synchronize()
+            runs.append((dts, s.vel.copy(), s.pres.copy()))
+    for other in runs[1:]:
+        assert other[0] == runs[0][0]
+        assert np.array_equal(other[1], runs[0][1]) and np.array_equal(other[2], runs[0][2])

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_solver_variants_gpu.py tests/test_abi_and_host.py -m gpu -q -x 2>&1 | tail -3
+timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-amr > $OUT/r02_bench38.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02_bench38.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["ms_per_step_no_kernel_timers"], d["verified"]["ok"])
+for name,v in d["kernels"].items():
+    if v.get("launches"): print("  %-16s %8.1f us x %d"%(name, 1e3*v["ms_total"]/v["launches"], v["launches"]))
+PY

@@ -565,17 +565,25 @@ int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
 // zero_pres = false (cup2d_step only): the solve that follows is told that its initial guess is zero (ctx.h x0_is_zero)
 // and neither reads nor needs the fill -- pres receives the solution
 static int poisson_rhs_uniform(cup2d_ctx *c, double dt, int use_bodies, bool zero_pres) {
+  double *pres = c->d_field[CUP2D_PRES], *pold = c->d_field[CUP2D_POLD];
+  if (!zero_pres) {
+    // cup2d_step: the rhs kernel reads pres AS pold and writes the block's own cells to POLD on its way (pold = pres
+    // without a pass of its own); pres is left as it is -- the solve does not read it and overwrites it
+    CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
+    CUP2D_TRY(exchange_halo(c, pres, 1, 1));
+    if (use_bodies) CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_TMPV], 2, 1));
+    return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
+                               use_bodies ? c->d_field[CUP2D_CHI] : nullptr, pres, c->d_field[CUP2D_TMP], dt, 0, c->nblocks, pold);
+  }
   // pold = pres; pres = 0 (main.cpp:7016-7021): a device copy, not a pointer swap -- the slab pointers a caller got
   // from cup2d_field_ptr stay valid for the life of the context
-  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_POLD], c->d_field[CUP2D_PRES], (size_t)c->nblocks * BC * sizeof(double),
-                                 hipMemcpyDeviceToDevice, c->stream));
-  if (zero_pres) CUP2D_TRY(launch_zero(c, c->d_field[CUP2D_PRES], slab_doubles(c, 1)));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(pold, pres, (size_t)c->nblocks * BC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  CUP2D_TRY(launch_zero(c, pres, slab_doubles(c, 1)));
   CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_VEL], 2, 1));
-  CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_POLD], 1, 1));
+  CUP2D_TRY(exchange_halo(c, pold, 1, 1));
   if (use_bodies) CUP2D_TRY(exchange_halo(c, c->d_field[CUP2D_TMPV], 2, 1));
   return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
-                             use_bodies ? c->d_field[CUP2D_CHI] : nullptr, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], dt,
-                             0, c->nblocks);
+                             use_bodies ? c->d_field[CUP2D_CHI] : nullptr, pold, c->d_field[CUP2D_TMP], dt, 0, c->nblocks);
 }
 int cup2d_poisson_rhs(cup2d_ctx *c, double dt, int use_bodies) {
   CUP2D_CHECK_CTX(c);

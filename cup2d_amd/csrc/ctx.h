@@ -252,7 +252,7 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
                   double dt, double coef, int first, int count);
 int launch_vorticity(cup2d_ctx *c, const double *vel, double *out, int first, int count);
 int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi,
-                        const double *pold, double *out, double dt, int first, int count);
+                        const double *pold, double *out, double dt, int first, int count, double *pold_copy = nullptr);
 int launch_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int first, int count);
 int launch_max_from_partials(cup2d_ctx *c, const double *partials, int n, double *d_out);
 int launch_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double *vel, double dt,

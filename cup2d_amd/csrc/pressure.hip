@@ -10,11 +10,13 @@ namespace cup2d {
 
 // tmp = facDiv*(div vel) - facDiv*chi*(div udef)   [BODIES]
 //       - Lap5(pold)                               [SUBLAP: pressure_rhs1 fused, main.cpp:7026]
+//       pold_copy (SUBLAP): the block's own cells of pold are written there as well -- cup2d_step hands PRES in as
+//       pold and POLD as the copy: `pold = pres` (main.cpp:7016-7021) without a pass of its own
 template <bool BODIES, bool SUBLAP>
 __global__ __launch_bounds__(WG) void k_pressure_rhs(const double2 *__restrict__ vel, const double2 *__restrict__ udef,
                                                      const double *__restrict__ chi, const double *__restrict__ pold,
                                                      double *__restrict__ out, const int *__restrict__ nbr, int first,
-                                                     int count, double facDiv) {
+                                                     int count, double facDiv, double *__restrict__ pold_copy) {
   __shared__ double2 vlabs[WPG][LAB1 * LAB1];
   __shared__ double slabs[WPG][LAB1 * LAB1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(WG) void k_pressure_rhs(const double2 *__restrict__
       double r = facDiv * (vlab[c0 + 1].x - vlab[c0 - 1].x + vlab[c0 + LAB1].y - vlab[c0 - LAB1].y);
       if (SUBLAP) {  // main.cpp:6228
         const double l0 = slab[c0], l1 = slab[c0 - 1], l2 = slab[c0 + 1], l3 = slab[c0 - LAB1], l4 = slab[c0 + LAB1];
+        if (pold_copy) pold_copy[(size_t)b * BC + lane] = l0;
         if (!BODIES) r -= l1 + l2 + l3 + l4 - 4 * l0;
         else {
           // with bodies the chi term must be subtracted before the Laplacian (statement order
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(WG) void k_pressure_rhs(const double2 *__restrict__
 }
 
 int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, const double *pold,
-                        double *out, double dt, int first, int count) {
+                        double *out, double dt, int first, int count, double *pold_copy) {
   if (count <= 0) return CUP2D_OK;
   const double facDiv = 0.5 * c->h / dt;  // main.cpp:6117
   const int grid = grid_for(c, count);
@@ -67,7 +70,7 @@ int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, con
   ProfScope prof(c, CUP2D_T_POISSON_RHS);
 #define LAUNCH(B, S)                                                                                              \
   hipLaunchKernelGGL((k_pressure_rhs<B, S>), dim3(grid), dim3(WG), 0, c->stream, (const double2 *)vel,             \
-                     (const double2 *)udef, chi, pold, out, c->d_nbr, first, count, facDiv)
+                     (const double2 *)udef, chi, pold, out, c->d_nbr, first, count, facDiv, sub ? pold_copy : nullptr)
   if (bodies && sub) LAUNCH(true, true);
   else if (bodies) LAUNCH(true, false);
   else if (sub) LAUNCH(false, true);

@@ -57,7 +57,7 @@ struct KrylovScalars {
   int restart_flag;  // next p-update must do rhat = r, p = r (cuda.cu:461-476)
   int x_is_best;     // the iterate held in x is the best so far (cuda.cu:535-538)
   int ycur, ybest;   // fused solver: which of its three y buffers holds the current / the best iterate
-  int pad;
+  int best_is_x0;    // fused solver: no iterate has beaten the initial guess yet (y_best = 0: its buffer is never written or read)
 };
 
 struct HaloPlan {

@@ -40,6 +40,7 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
     sc->err = sc->err_init = sc->err_opt = red[2];
     sc->x_is_best = 1;
     sc->ycur = sc->ybest = 0;
+    sc->best_is_x0 = 1;
     sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
     begin_iteration(sc);
     break;
@@ -57,6 +58,7 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
       sc->err_opt = sc->err;
       sc->x_is_best = 1;
       sc->ybest = sc->ycur;
+      sc->best_is_x0 = 0;
       if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
     } else {
       sc->x_is_best = 0;

@@ -599,8 +599,12 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, doubl
   const double2 *__restrict__ yin = cur == 0 ? y0 : (cur == 1 ? y1 : y2);
   double2 *__restrict__ yout = out == 0 ? y0 : (out == 1 ? y1 : y2);
   double sm[2] = {0.0, 0.0}, m[1] = {0.0};
+  // the accumulated correction starts at zero (cuda.cu:436-437 in the preconditioned space): the first sweep does not
+  // read it -- its buffer is never filled
+  const bool first = sc->iter == 0;
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
-    double2 yv = ld2<(POL & 0x040) != 0>(yin + i);
+    double2 yv = {0.0, 0.0};
+    if (!first) yv = ld2<(POL & 0x040) != 0>(yin + i);
     const double2 pv = ld2<(POL & 0x080) != 0>(p + i), ro = r[i], nv = ld2<(POL & 0x100) != 0>(nu + i);
     const double2 tv = ld2<(POL & 0x200) != 0>(t + i), hv = ld2<(POL & 0x400) != 0>(rhat + i);
     double2 sv;
@@ -818,9 +822,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     CUP2D_TRY(launch_init_residual(c, x, b, &GP, x0_zero));
   }
   CUP2D_TRY(finish(c, GP, 1, 1, 0, false));
-  // p, nu start at zero (cuda.cu:436-437): the first AB sweep knows (k_fused: fresh) and does not use them; the
-  // accumulated correction starts at zero and its first buffer may remain the best iterate
-  CUP2D_TRY(launch_zero(c, c->d_y, n));
+  // p, nu and the accumulated correction y start at zero (cuda.cu:436-437): the first AB sweep and the first sweep E
+  // know (k_fused: fresh, k_sweepE_y: first) and do not read them; y's first buffer stays "the best iterate" only as
+  // long as no iterate has beaten the initial guess (KrylovScalars::best_is_x0) and is not read then either -- no fills
   if (gb) CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
 
   static const int AHEAD = [] {
@@ -880,8 +884,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
   const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];
-  if (x0_zero) CUP2D_TRY(launch_precond(c, ybest, x, 0, nb));  // x = 0 + P_inv y_opt, written, not added
-  else CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
+  if (c->h_sc->best_is_x0) {  // the initial guess is the answer: x = x0
+    if (x0_zero) CUP2D_TRY(launch_zero(c, x, n));
+  } else if (x0_zero) {
+    CUP2D_TRY(launch_precond(c, ybest, x, 0, nb));  // x = 0 + P_inv y_opt, written, not added
+  } else {
+    CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
+  }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (iters) *iters = c->h_sc->iter;
   if (restarts) *restarts = c->h_sc->restarts;

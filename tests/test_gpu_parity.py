@@ -307,3 +307,26 @@ def test_consecutive_steps_reuse_what_the_previous_step_left_gpu(gpu_lib, oracle
     for other in runs[1:]:
         assert other[0] == runs[0][0]
         assert np.array_equal(other[1], runs[0][1]) and np.array_equal(other[2], runs[0][2])
+
+
+@pytest.mark.gpu
+def test_contexts_reuse_pooled_buffers_zero_filled_gpu(gpu_lib, oracle):
+    """cup2d_destroy hands a context's device buffers to the library's pool, the next cup2d_create takes them back
+    zero-filled: a second simulation in recycled memory starts from zero fields and reproduces the first bit for bit;
+    cup2d_trim_pool returns the idle buffers to the driver (and the next context still works)."""
+    import cup2d_amd
+    from cup2d_amd import lib as L
+    n = 128
+    vel = oracle.taylor_green(n)
+    out = []
+    for k in range(3):
+        with cup2d_amd.Simulation(n // 8, nu=1e-3) as s:
+            assert not s.pres.any() and not s.vel.any() and not s.tmp.any()  # recycled or fresh: zeros
+            s.vel = vel
+            r = [s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=40) for _ in range(2)]
+            out.append((r, s.vel.copy(), s.pres.copy()))
+            s.pres = np.full((n, n), 7.0)  # leave something behind in the buffers
+        if k == 1:
+            assert L.load_library().cup2d_trim_pool() == 0
+    for o in out[1:]:
+        assert o[0] == out[0][0] and np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2])

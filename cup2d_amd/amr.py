@@ -3,6 +3,7 @@ across every side of each -- the tables of cup2d_set_amr (include/cup2d_hip.h). 
 reference's tree / Info::Znei / Zchild / Zparent lookups (main.cpp:672-738, 2197-2198) with dense arrays built once
 per regrid.  Fields of an adapted grid are per-block arrays [nblocks][64 * dim] in the order of `blocks`."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -218,10 +219,11 @@ class AmrSimulation(BodyOps):
         _l.check(self.L.cup2d_project(self._ctx, dt), "project")
         return dict(dt=dt, iters=it.value, err=e.value)
 
-    def adapt(self, rtol, ctol, level_max):
+    def adapt(self, rtol, ctol, level_max, host_fields=None):
         """The reference's adapt() (main.cpp:4657-5440) for this simulation: tag by max|vorticity| per block (GPU),
-        validate the states, prolong / restrict every field on the host (regrid-time work, as in the reference), then
-        rebuild the device context on the new grid and re-assemble the Poisson operator.  Returns True if the grid
+        validate the states, prolong / restrict the blocks that change on the host (regrid-time work, as in the reference;
+        the unchanged blocks never leave the device), then rebuild the device context on the new grid and re-assemble the
+        Poisson operator.  Returns True if the grid
         changed.  The caller decides WHEN (should_adapt() is the reference's rule, main.cpp:6603).  Body-free: the
         reference also runs GradChiOnTmp on chi before tagging (main.cpp:4660), which only matters with bodies."""
         self.vorticity()
@@ -231,16 +233,71 @@ class AmrSimulation(BodyOps):
                              self.grid.bpdx, self.grid.bpdy)
         if not (st != LEAVE).any():
             return False
-        nbk = self.grid.nblocks
+        G = self.grid
+        nbk, vp = G.nblocks, ctypes.c_void_p
         names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
-        fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
-        blocks, data = regrid(self.grid.blocks, st, fields, level_max, self.grid.bpdx, self.grid.bpdy)
-        new_grid = AmrBlockGrid(blocks, self.grid.bpdx, self.grid.bpdy, self.grid.h0 * max(self.grid.bpdx, self.grid.bpdy) * BS)
-        self.close()
-        # same device, same settings (the rebuilt context gets policy / solver / timing re-applied by __init__)
-        self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, adapt_steps=self.adapt_steps)
-        for k, f in names.items():
-            self.set_field(f, data[k])
+        if host_fields is None:  # most blocks change (a start-up regrid): everything through host memory is the shorter way
+            host_fields = int((st != LEAVE).sum()) > 0.3 * nbk
+        if host_fields:  # every field through host memory (the round-1 form; also the cross-check of the tests)
+            fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
+            blocks, data = regrid(G.blocks, st, fields, level_max, G.bpdx, G.bpdy)
+            new_grid = AmrBlockGrid(blocks, G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
+            self.close()
+            # same device, same settings (the rebuilt context gets policy / solver / timing re-applied by __init__)
+            self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, adapt_steps=self.adapt_steps)
+            for k, f in names.items():
+                self.set_field(f, data[k])
+            self.install_poisson_matrix()
+            return True
+        # The fields stay on the device: the library's plan says which new blocks are unchanged copies of which old ones
+        # (moved by a kernel between the old and the new context) and which old blocks the prolonged / restricted ones are
+        # computed from; only those come to the host, only the changed blocks go back.
+        b32 = np.ascontiguousarray(G.blocks, dtype=np.int32).reshape(-1, 3)
+        st32 = np.ascontiguousarray(st, dtype=np.int32)
+        n_new = self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), 0, None, None, None)
+        if n_new < 0:
+            _l.check(int(n_new), "amr_regrid_plan")
+        new_blocks = np.empty((n_new, 3), dtype=np.int32)
+        src = np.empty(n_new, dtype=np.int32)
+        needed = np.empty(nbk, dtype=np.int32)
+        if self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), n_new, _p(new_blocks), _p(src), _p(needed)) != n_new:
+            _l.check(-1, "amr_regrid_plan")
+        need_idx = np.ascontiguousarray(np.flatnonzero(needed), dtype=np.int32)
+        changed = np.ascontiguousarray(np.flatnonzero(src < 0), dtype=np.int32)
+        kept_new = np.ascontiguousarray(np.flatnonzero(src >= 0), dtype=np.int32)
+        kept_old = np.ascontiguousarray(src[kept_new], dtype=np.int32)
+        order = list(names)
+        dims = np.array([_l.FIELD_DIM[names[k]] for k in order], dtype=np.int32)
+        vec = (dims == 2).astype(np.int32)
+        old_host, new_host = [], []
+        poison = bool(os.environ.get("CUP2D_REGRID_POISON"))
+        for k, d in zip(order, dims):  # full-size arrays the host routine indexes by block; only the needed blocks are filled
+            # (untouched pages of np.empty cost nothing; CUP2D_REGRID_POISON=1 fills with NaN to catch a read outside the plan)
+            a = np.full((nbk, 64 * int(d)), np.nan) if poison else np.empty((nbk, 64 * int(d)))
+            got = np.empty((len(need_idx), 64 * int(d)))
+            _l.check(self.L.cup2d_download_blocks(self._ctx, names[k], len(need_idx), _p(need_idx), _p(got)), "download_blocks")
+            a[need_idx] = got
+            old_host.append(a)
+            new_host.append(np.empty((n_new, 64 * int(d))))
+        srcp = (vp * len(order))(*[a.ctypes.data for a in old_host])
+        dstp = (vp * len(order))(*[a.ctypes.data for a in new_host])
+        chk = np.empty((n_new, 3), dtype=np.int32)
+        if self.L.cup2d_amr_regrid_changed(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), len(order), srcp, _p(dims), _p(vec), n_new,
+                                           _p(chk), dstp) != n_new:
+            _l.check(-1, "amr_regrid_changed")
+        new_grid = AmrBlockGrid(new_blocks.astype(np.int64), G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
+        old_ctx = self._ctx
+        self._ctx = ctypes.c_void_p()  # the old context lives on until its blocks have been copied over
+        try:
+            self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, adapt_steps=self.adapt_steps)
+            for k, a in zip(order, new_host):
+                up = np.ascontiguousarray(a[changed])
+                if poison and np.isnan(up).any():  # a block the plan did not name was read: the plan is the library's, so this is a bug
+                    raise RuntimeError("regrid: a prolonged / restricted block of %s was computed from a block that was not downloaded" % k)
+                _l.check(self.L.cup2d_copy_blocks(self._ctx, old_ctx, names[k], len(kept_new), _p(kept_new), _p(kept_old)), "copy_blocks")
+                _l.check(self.L.cup2d_upload_blocks(self._ctx, names[k], len(changed), _p(changed), _p(up)), "upload_blocks")
+        finally:
+            self.L.cup2d_destroy(old_ctx)
         self.install_poisson_matrix()
         return True
 
@@ -298,6 +355,43 @@ def regrid(blocks, states, fields, level_max, bpdx=1, bpdy=1):
     got = L.cup2d_amr_regrid(nb, _p(b32), bpdx, bpdy, level_max, _p(st), n, srcp, _p(dims), _p(vec), n_new, _p(new_blocks), dstp)
     if got != n_new:
         _l.check(int(min(got, -1)), "amr_regrid")
+    return new_blocks.astype(np.int64), dict(zip(names, dst))
+
+
+def regrid_plan(blocks, states, level_max, bpdx=1, bpdy=1):
+    """cup2d_amr_regrid_plan: (new_blocks (n,3), src_of_new (n,) old block of an unchanged copy or -1, needed_old (nb,) bool:
+    the old blocks the prolonged / restricted blocks are computed from)"""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, dtype=np.int32)
+    L, nb = _l.load_library(), len(b32)
+    n = L.cup2d_amr_regrid_plan(nb, _p(b32), bpdx, bpdy, level_max, _p(st), 0, None, None, None)
+    if n < 0:
+        _l.check(int(n), "amr_regrid_plan")
+    new_blocks, src, needed = np.empty((n, 3), dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(nb, dtype=np.int32)
+    if L.cup2d_amr_regrid_plan(nb, _p(b32), bpdx, bpdy, level_max, _p(st), n, _p(new_blocks), _p(src), _p(needed)) != n:
+        _l.check(-1, "amr_regrid_plan")
+    return new_blocks.astype(np.int64), src, needed.astype(bool)
+
+
+def regrid_changed(blocks, states, fields, level_max, bpdx=1, bpdy=1):
+    """cup2d_amr_regrid_changed: like regrid(), but only the prolonged / restricted blocks of the returned arrays are
+    written (the rest is uninitialised) and only the needed blocks of `fields` are read"""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, dtype=np.int32)
+    nb, names = len(b32), list(fields)
+    src = [np.ascontiguousarray(fields[k][0], dtype=np.float64).reshape(nb, -1) for k in names]
+    dims = np.array([fields[k][1] for k in names], dtype=np.int32)
+    vec = np.array([1 if fields[k][2] else 0 for k in names], dtype=np.int32)
+    L, vp = _l.load_library(), ctypes.c_void_p
+    n = L.cup2d_amr_regrid_plan(nb, _p(b32), bpdx, bpdy, level_max, _p(st), 0, None, None, None)
+    if n < 0:
+        _l.check(int(n), "amr_regrid_plan")
+    new_blocks = np.empty((n, 3), dtype=np.int32)
+    dst = [np.empty((n, BS * BS * int(d))) for d in dims]
+    srcp = (vp * max(len(names), 1))(*[a.ctypes.data for a in src])
+    dstp = (vp * max(len(names), 1))(*[a.ctypes.data for a in dst])
+    if L.cup2d_amr_regrid_changed(nb, _p(b32), bpdx, bpdy, level_max, _p(st), len(names), srcp, _p(dims), _p(vec), n, _p(new_blocks), dstp) != n:
+        _l.check(-1, "amr_regrid_changed")
     return new_blocks.astype(np.int64), dict(zip(names, dst))
 
 

@@ -599,10 +599,16 @@ extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int
   return CUP2D_OK;
 }
 
-extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
-                                      const int32_t *st, int nfields, const double *const *fields, const int32_t *dims,
-                                      const int32_t *is_vector, long long cap, int32_t *new_blocks,
-                                      double *const *new_fields) {
+// src_of_new [cap] (optional): per new block the old block it is an unchanged copy of, or -1 (prolonged / restricted).
+// needed_old [nblocks] (optional): 1 for every old block a prolonged or restricted block is computed from -- the refined
+// parents and every leaf that overlaps the 3 x 3 block neighbourhood of one (the tensorial halo-1 tile: sides, corners,
+// the coarse cells TestInterp looks at), the compressing siblings.  changed_only: unchanged copies are NOT written to
+// new_fields and of `fields` only the needed blocks are read (a host that keeps the fields on the device moves the
+// unchanged blocks there, cup2d_copy_blocks).
+static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *st,
+                             int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
+                             long long cap, int32_t *new_blocks, double *const *new_fields, int32_t *src_of_new,
+                             int32_t *needed_old, bool changed_only) {
   if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid")) return CUP2D_ERR_ARG;
   if (!st || nfields < 0 || (nfields && (!fields || !dims || !is_vector))) {
     cup2d::set_error("amr_regrid: bad argument");
@@ -668,6 +674,27 @@ extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bp
     new_blocks[3 * p] = b.l;
     new_blocks[3 * p + 1] = b.i;
     new_blocks[3 * p + 2] = b.j;
+    if (src_of_new) src_of_new[p] = b.part == -1 ? b.src : -1;
+  }
+  if (needed_old) {
+    std::fill(needed_old, needed_old + nblocks, 0);
+    for (int k = 0; k < nblocks; k++) {
+      if (st[k] == COMPRESS) needed_old[k] = 1;
+      if (st[k] != REFINE) continue;
+      const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+      for (int dj = -1; dj <= 1; dj++)
+        for (int di = -1; di <= 1; di++) {
+          const int x = i + di, y = j + dj;
+          int s = L.find(l, x, y);
+          if (s >= 0) { needed_old[s] = 1; continue; }
+          s = l > 0 ? L.find(l - 1, x >> 1, y >> 1) : -1;  // (negative coordinates: outside the domain, no leaf)
+          if (x >= 0 && y >= 0 && s >= 0) { needed_old[s] = 1; continue; }
+          for (int a = 0; a < 4; a++) {
+            const int c = L.find(l + 1, 2 * x + (a & 1), 2 * y + (a >> 1));
+            if (c >= 0) needed_old[c] = 1;
+          }
+        }
+    }
   }
   constexpr int BS = CUP2D_BS;
   for (int fi = 0; fi < nfields; fi++) {
@@ -683,7 +710,7 @@ extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bp
     for (long long p = p_lo; p < p_hi; p++) {
       const New &b = nb[p];
       if (b.part == -1) {
-        std::copy(f + b.src * bsz, f + (b.src + 1) * bsz, g + where[p] * bsz);
+        if (!changed_only) std::copy(f + b.src * bsz, f + (b.src + 1) * bsz, g + where[p] * bsz);
       } else if (b.part == 4) {  // mean of the 2 x 2 cells of the four siblings (main.cpp:5149-5166)
         const int l = L.level(b.src), i = L.bi(b.src), j = L.bj(b.src);
         double *o = g + where[p] * bsz;
@@ -708,4 +735,25 @@ extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bp
     });
   }
   return n_new;
+}
+
+extern "C" long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                      const int32_t *st, int nfields, const double *const *fields, const int32_t *dims,
+                                      const int32_t *is_vector, long long cap, int32_t *new_blocks,
+                                      double *const *new_fields) {
+  return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, nfields, fields, dims, is_vector, cap, new_blocks, new_fields,
+                     nullptr, nullptr, false);
+}
+extern "C" long long cup2d_amr_regrid_plan(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                           const int32_t *st, long long cap, int32_t *new_blocks, int32_t *src_of_new,
+                                           int32_t *needed_old) {
+  return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, 0, nullptr, nullptr, nullptr, cap, new_blocks, nullptr, src_of_new,
+                     needed_old, true);
+}
+extern "C" long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                              const int32_t *st, int nfields, const double *const *fields,
+                                              const int32_t *dims, const int32_t *is_vector, long long cap,
+                                              int32_t *new_blocks, double *const *new_fields) {
+  return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, nfields, fields, dims, is_vector, cap, new_blocks, new_fields,
+                     nullptr, nullptr, true);
 }

@@ -398,6 +398,92 @@ int cup2d_download_slab(cup2d_ctx *c, int field, double *slab) {
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   return CUP2D_OK;
 }
+// ---- block-wise transfers (a regridding host moves only the blocks that change, the rest stays on the device) ----
+// one wave per block, `per` doubles per lane
+__global__ void k_blocks_gather(const double *__restrict__ f, const int32_t *__restrict__ idx, double *__restrict__ out, int n, int per) {
+  const int lane = threadIdx.x & 63;
+  for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n; k += gridDim.x * (blockDim.x >> 6)) {
+    const size_t src = (size_t)idx[k] * 64 * per, dst = (size_t)k * 64 * per;
+    for (int j = 0; j < per; j++) out[dst + j * 64 + lane] = f[src + j * 64 + lane];
+  }
+}
+__global__ void k_blocks_scatter(double *__restrict__ f, const int32_t *__restrict__ didx, const double *__restrict__ in,
+                                 const int32_t *__restrict__ sidx, int n, int per) {
+  const int lane = threadIdx.x & 63;
+  for (int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n; k += gridDim.x * (blockDim.x >> 6)) {
+    const size_t dst = (size_t)didx[k] * 64 * per, src = (size_t)(sidx ? sidx[k] : k) * 64 * per;
+    for (int j = 0; j < per; j++) f[dst + j * 64 + lane] = in[src + j * 64 + lane];
+  }
+}
+static int blocks_grid(int n) { return n < 4 ? 1 : (n / 4 > 2048 ? 2048 : n / 4); }
+static int check_block_list(const cup2d_ctx *c, int n, const int32_t *blocks, const char *what) {
+  if (n < 0 || (n && !blocks)) { set_error("%s: block list", what); return CUP2D_ERR_ARG; }
+  for (int k = 0; k < n; k++)
+    if (blocks[k] < 0 || blocks[k] >= c->nblocks) { set_error("%s: block %d of %d", what, blocks[k], c->nblocks); return CUP2D_ERR_ARG; }
+  return CUP2D_OK;
+}
+int cup2d_download_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, double *host) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  CUP2D_TRY(check_block_list(c, n, blocks, "download_blocks"));
+  if (n == 0) return CUP2D_OK;
+  if (!host) return CUP2D_ERR_ARG;
+  const int per = dim_of(field);
+  const size_t bytes = (size_t)n * BC * per * sizeof(double);
+  int32_t *d_idx = nullptr;
+  double *d_buf = nullptr;
+  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)n * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(dev_malloc(&d_buf, bytes));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_blocks_gather, dim3(blocks_grid(n)), dim3(WG), 0, c->stream, c->d_field[field], d_idx, d_buf, n, per);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  CUP2D_HIP_CHECK(hipMemcpyAsync(host, d_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  dev_free(d_idx);
+  dev_free(d_buf);
+  return CUP2D_OK;
+}
+int cup2d_upload_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, const double *host) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  CUP2D_TRY(check_block_list(c, n, blocks, "upload_blocks"));
+  if (n == 0) return CUP2D_OK;
+  if (!host) return CUP2D_ERR_ARG;
+  const int per = dim_of(field);
+  const size_t bytes = (size_t)n * BC * per * sizeof(double);
+  int32_t *d_idx = nullptr;
+  double *d_buf = nullptr;
+  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)n * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(dev_malloc(&d_buf, bytes));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_buf, host, bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_blocks_scatter, dim3(blocks_grid(n)), dim3(WG), 0, c->stream, c->d_field[field], d_idx, d_buf,
+                     (const int32_t *)nullptr, n, per);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  dev_free(d_idx);
+  dev_free(d_buf);
+  return CUP2D_OK;
+}
+int cup2d_copy_blocks(cup2d_ctx *c, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks) {
+  CUP2D_CHECK_CTX(c);
+  CHECK_FIELD(field);
+  if (!src || src->device != c->device) { set_error("copy_blocks: the source context must live on the same device"); return CUP2D_ERR_ARG; }
+  CUP2D_TRY(check_block_list(c, n, dst_blocks, "copy_blocks (destination)"));
+  CUP2D_TRY(check_block_list(src, n, src_blocks, "copy_blocks (source)"));
+  if (n == 0) return CUP2D_OK;
+  int32_t *d_idx = nullptr;
+  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)2 * n * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(src->stream));  // what the source context has enqueued is done
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, dst_blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx + n, src_blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_blocks_scatter, dim3(blocks_grid(n)), dim3(WG), 0, c->stream, c->d_field[field], d_idx,
+                     (const double *)src->d_field[field], (const int32_t *)(d_idx + n), n, dim_of(field));
+  CUP2D_HIP_CHECK(hipGetLastError());
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  dev_free(d_idx);
+  return CUP2D_OK;
+}
 int cup2d_field_ptr(cup2d_ctx *c, int field, void **p) {
   CUP2D_CHECK_CTX(c);
   CHECK_FIELD(field);

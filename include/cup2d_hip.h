@@ -287,6 +287,23 @@ int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int bpdx, int 
 long long cup2d_amr_regrid(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
                            int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
                            long long cap, int32_t *new_blocks, double *const *new_fields);
+/* The same for a host that keeps the fields on the device (only the blocks that change cross PCIe):
+ * cup2d_amr_regrid_plan: the new leaves, per new block the old block it is an unchanged copy of (src_of_new[cap], -1 for a
+ *   prolonged or restricted block) and needed_old[nblocks] = 1 for every old block such a block is computed from (refined
+ *   parents and every leaf overlapping the 3 x 3 block neighbourhood of one -- the tensorial halo-1 tile --, compressing
+ *   siblings).  new_blocks == NULL: only the count.
+ * cup2d_amr_regrid_changed: cup2d_amr_regrid that reads only the needed blocks of `fields` (full-size arrays, the other
+ *   blocks may hold anything) and writes only the prolonged / restricted blocks of new_fields.
+ * cup2d_download_blocks / cup2d_upload_blocks: field data of a list of blocks, host[n][64 * dim].
+ * cup2d_copy_blocks: block dst_blocks[k] of `ctx` = block src_blocks[k] of `src` (the context of the old grid, same device). */
+long long cup2d_amr_regrid_plan(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
+                                long long cap, int32_t *new_blocks, int32_t *src_of_new, int32_t *needed_old);
+long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
+                                   int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
+                                   long long cap, int32_t *new_blocks, double *const *new_fields);
+int cup2d_download_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, double *host);
+int cup2d_upload_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, const double *host);
+int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks);
 
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:

@@ -124,6 +124,18 @@ def test_amr_host_regrid_library_vs_python_statement():
             assert np.array_equal(b_c, b_py), (seed, it)
             for k in d_py:
                 assert np.array_equal(d_c[k], d_py[k]) and not np.isnan(d_c[k]).any(), (seed, it, k)
+            # the plan of the same regrid for a host that keeps the fields on the device: same leaves; an unchanged block is
+            # the old block the plan names; the changed ones come out the same when every block the plan does NOT name as
+            # needed is poisoned -- nothing outside the plan is read
+            b_p, src, needed = A.regrid_plan(blocks, st, level_max)
+            assert np.array_equal(b_p, b_c), (seed, it)
+            kept = src >= 0
+            assert np.array_equal(d_c["vel"][kept], vel[src[kept]]) and np.array_equal(d_c["pres"][kept], pres[src[kept]])
+            vel_p, pres_p = np.where(needed[:, None], vel, np.nan), np.where(needed[:, None], pres, np.nan)
+            b_x, d_x = A.regrid_changed(blocks, st, {"vel": (vel_p, 2, True), "pres": (pres_p, 1, False)}, level_max)
+            assert np.array_equal(b_x, b_c)
+            for k in d_x:
+                assert np.array_equal(d_x[k][~kept], d_c[k][~kept]), (seed, it, k)
             blocks, vel, pres = b_c, d_c["vel"], d_c["pres"]
             g = A.AmrBlockGrid(blocks)  # stays 2:1 balanced (raises otherwise)
             assert g.nblocks == len(blocks)

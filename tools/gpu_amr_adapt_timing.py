@@ -22,12 +22,23 @@ with A.AmrSimulation(g) as s:
     s.step(max_iter=50)
     s.vorticity()
     om = np.abs(s.get_field(L.TMP)).reshape(g.nblocks, -1).max(1)
-    rtol, ctol = np.quantile(om, 0.97), np.quantile(om, 0.5)
-    t0 = time.perf_counter()
-    pr = cProfile.Profile(); pr.enable()
-    changed = s.adapt(rtol, ctol, LF + 1)
-    pr.disable()
-    t1 = time.perf_counter()
-    print("adapt: changed=%s -> %d blocks in %.3f s" % (changed, s.grid.nblocks, t1 - t0))
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    for qr, qc in ((0.97, 0.5), (0.99, 0.03), (0.99, 0.03), (0.995, 0.02)):  # a start-up regrid, then ones that change a few per cent
+        s.vorticity()
+        om = np.abs(s.get_field(L.TMP)).reshape(s.grid.nblocks, -1).max(1)
+        rtol, ctol = np.quantile(om, qr), np.quantile(om, qc)
+        for host in (True, False):
+            n0 = s.grid.nblocks
+            t0 = time.perf_counter()
+            if host is False:
+                pr = cProfile.Profile(); pr.enable()
+            changed = s.adapt(rtol, ctol, LF + 1, host_fields=host)
+            t1 = time.perf_counter()
+            print("adapt(host_fields=%s) quantiles %.3f/%.2f: changed=%s %d -> %d blocks in %.3f s" % (host, qr, qc, changed, n0, s.grid.nblocks, t1 - t0), flush=True)
+            if host is False:
+                pr.disable()
+                pstats.Stats(pr).sort_stats("cumulative").print_stats(8)
+            s.step(max_iter=20)
+            s.vorticity()
+            om = np.abs(s.get_field(L.TMP)).reshape(s.grid.nblocks, -1).max(1)
+            rtol, ctol = np.quantile(om, qr), np.quantile(om, qc)
     t0 = time.perf_counter(); s.step(max_iter=50); s.step(max_iter=50); print("2 steps after: %.1f ms each" % ((time.perf_counter() - t0) * 500))

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "advect_tile.h"
+#include "advect_walk.h"
 #include "block.h"
 #include "weno.h"
 
@@ -84,7 +85,8 @@ template <class W, int MODE>
 __global__ __launch_bounds__(WG, 4) void k_advect_diffuse(const double2 *__restrict__ vel,
                                                        const double2 *__restrict__ vold,
                                                        double2 *__restrict__ out, const int *__restrict__ nbr,
-                                                       int first, int count, int chunk, double afac, double dfac, double coef) {
+                                                       const int *__restrict__ list, int first, int count, int chunk,
+                                                       double afac, double dfac, double coef) {
   __shared__ AdvectLds lds[WPG];
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   AdvectLds &L = lds[wave];
@@ -96,25 +98,128 @@ __global__ __launch_bounds__(WG, 4) void k_advect_diffuse(const double2 *__restr
   int g = gr.begin;
   bool have = g < gr.end && g * WPG + wave < count;
   if (!have) return;
+  // list: the blocks of a plan that found no partners for a quad (advect_walk.h); otherwise the range [first, first + count)
+  auto block_of = [&](int i) { return list ? list[first + i] : first + i; };
   LabRegs R;
-  lab3_fetch<MODE>(R, vel, vold, nbr4, first + g * WPG + wave, lane);
+  int b = block_of(g * WPG + wave);
+  lab3_fetch<MODE>(R, vel, vold, nbr4, b, lane);
   while (have) {
-    const int b = first + g * WPG + wave;
     lab3_store(R, lane, L.lab);
     const double2 old = R.old;
     wave_lds_sync();
     // prefetch the next block of this wave (its last block is simply fetched twice)
     g += gr.stride;
     have = g < gr.end && g * WPG + wave < count;
-    lab3_fetch<MODE>(R, vel, vold, nbr4, have ? first + g * WPG + wave : b, lane);
+    const int bnext = have ? block_of(g * WPG + wave) : b;
+    lab3_fetch<MODE>(R, vel, vold, nbr4, bnext, lane);
     double2 r = advect_cell<W>(L, rim, lane, afac, dfac);
     if (MODE == 1) {
       r.x = old.x + r.x * coef;
       r.y = old.y + r.y * coef;
     }
     out[(size_t)b * BC + lane] = r;
+    b = bnext;
     wave_lds_sync();  // tile and face values are overwritten by the next block
   }
+}
+
+// ---- the quad form (advect_walk.h): one wave = 2 x 2 blocks, the reconstruction walks along the grid lines ----------
+// 13 KB of LDS per wave (ghosted 22 x 22 tile + hand-over buffer) -> three workgroups of four waves per CU; the next
+// quad's 11 loads per lane (own cells, old values, three ghost cells) are in flight while the current one is computed.
+template <int MODE, bool OLDLAB>
+__global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restrict__ vel, const walk::V2 *__restrict__ vold,
+                                                       double *__restrict__ out, const int *__restrict__ quads, int nq,
+                                                       int chunk, double afc, double dfc) {
+  constexpr bool NEED_OLD = MODE == 1 && !OLDLAB;
+  __shared__ walk::Lds lds[WPG];
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  walk::Lds &L = lds[wave];
+  int gp[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) gp[i] = walk::ghost_pack(lane, i);
+  const int ypos = 2 * (lane >> 5) + ((lane >> 4) & 1);  // the block the y walk of this lane writes to
+  const GroupRange gr = chunk > 0 ? group_range_chunked(nq, chunk) : group_range(nq);
+  int g = gr.begin;
+  bool have = g < gr.end && g * WPG + wave < nq;
+  if (!have) return;
+  // The plan entry of a quad (12 ints) is read by lanes 0..11 with ONE vector load, two quads ahead of its use, and
+  // handed out with v_readlane: the block ids are wave-uniform values by the time the loads that depend on them are
+  // issued (a per-lane load of the table in front of the ghost loads stalled every quad for a memory round trip).
+  const int tl = lane < walk::QINTS ? lane : 0;
+  auto entry_of = [&](int gg) {  // the quad of this wave in group gg, or its last one
+    const bool ok = gg < gr.end && gg * WPG + wave < nq;
+    return quads + (size_t)((ok ? gg : g) * WPG + wave) * walk::QINTS;
+  };
+  // (no copy of a loaded register anywhere: a v_mov of `vnext` is a use, and the wait it brings covers every load and
+  // store issued before it)
+#define WALK_READ(E, v)                                                                                             \
+  E.b0 = __builtin_amdgcn_readlane(v, 0), E.b1 = __builtin_amdgcn_readlane(v, 1), E.b2 = __builtin_amdgcn_readlane(v, 2),    \
+  E.b3 = __builtin_amdgcn_readlane(v, 3), E.n0 = __builtin_amdgcn_readlane(v, 4), E.n1 = __builtin_amdgcn_readlane(v, 5),    \
+  E.n2 = __builtin_amdgcn_readlane(v, 6), E.n3 = __builtin_amdgcn_readlane(v, 7), E.n4 = __builtin_amdgcn_readlane(v, 8),    \
+  E.n5 = __builtin_amdgcn_readlane(v, 9), E.n6 = __builtin_amdgcn_readlane(v, 10), E.n7 = __builtin_amdgcn_readlane(v, 11)
+  walk::Entry E;
+  {
+    const int v0 = entry_of(g)[tl];
+    WALK_READ(E, v0);
+  }
+  walk::Regs R;
+  walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
+  int vnext = entry_of(g + gr.stride)[tl];
+  while (have) {
+    walk::stage<NEED_OLD>(R, L, lane, gp);
+    const int sg = walk::lane_signs(R);
+    const bool nPx = __ballot(sg & 1) != 0ull, nMx = __ballot(sg & 2) != 0ull;
+    const bool nPy = __ballot(sg & 4) != 0ull, nMy = __ballot(sg & 8) != 0ull;
+    const int blk = ypos == 0 ? E.b0 : ypos == 1 ? E.b1 : ypos == 2 ? E.b2 : E.b3;
+    wave_lds_sync();
+    // the next quad of this wave (its last one is simply fetched twice)
+    g += gr.stride;
+    have = g < gr.end && g * WPG + wave < nq;
+    WALK_READ(E, vnext);
+    walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
+    vnext = entry_of(g + gr.stride)[tl];
+    if (!nMx) walk::xwalk<true, false, MODE, OLDLAB>(L, lane, afc, dfc);
+    else if (!nPx) walk::xwalk<false, true, MODE, OLDLAB>(L, lane, afc, dfc);
+    else walk::xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
+    wave_lds_sync();
+    if (!nMy) walk::ywalk<true, false>(L, lane, afc, dfc, out, blk);
+    else if (!nPy) walk::ywalk<false, true>(L, lane, afc, dfc, out, blk);
+    else walk::ywalk<true, true>(L, lane, afc, dfc, out, blk);
+    wave_lds_sync();  // the tile is overwritten by the next quad
+  }
+#undef WALK_READ
+}
+
+// the plan of a block range: built once per (first, count) of a context (the neighbour table never changes)
+static const WalkPlan *walk_plan(cup2d_ctx *c, int first, int count) {
+  for (const WalkPlan &p : c->walk_plans)
+    if (p.first == first && p.count == count) return &p;
+  std::vector<int32_t> quads, singles;
+  walk::build_plan(c->h_nbr.data(), first, count, quads, singles);
+  WalkPlan p;
+  p.first = first;
+  p.count = count;
+  p.nquads = (int)(quads.size() / walk::QINTS);
+  p.nsingles = (int)singles.size();
+  if (p.nquads) {
+    if (dev_malloc(&p.d_quads, quads.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(p.d_quads, quads.data(), quads.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+      return nullptr;
+  }
+  if (p.nsingles) {
+    if (dev_malloc(&p.d_singles, singles.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(p.d_singles, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+      return nullptr;
+  }
+  c->walk_plans.push_back(p);
+  return &c->walk_plans.back();
+}
+void walk_plans_release(cup2d_ctx *c) {
+  for (WalkPlan &p : c->walk_plans) {
+    dev_free(p.d_quads);
+    dev_free(p.d_singles);
+  }
+  c->walk_plans.clear();
 }
 
 int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *out, int mode, double nu, double dt,
@@ -126,11 +231,41 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
   double2 *o = (double2 *)out;
   // groups (of 4 blocks) per workgroup; CUP2D_ADVECT_CHUNK=0 selects the persistent grid
   static const int chunk = [] { const char *e = getenv("CUP2D_ADVECT_CHUNK"); return e ? atoi(e) : 16; }();
+  // FAST policy: quads of 2 x 2 blocks take the register-walk kernel, blocks without partners the per-block one
+  // (CUP2D_ADVECT_WALK=0: everything per block, the round-1 kernel -- A/B timing aid)
+  static const bool use_walk = [] { const char *e = getenv("CUP2D_ADVECT_WALK"); return !e || atoi(e) != 0; }();
+  static const int wchunk = [] { const char *e = getenv("CUP2D_WALK_CHUNK"); return e ? atoi(e) : 4; }();
+  const int *list = nullptr;
+  if (c->math != CUP2D_MATH_STRICT && use_walk) {
+    const WalkPlan *p = walk_plan(c, first, count);
+    if (!p) {
+      set_error("launch_advect: plan of blocks [%d, %d) could not be built", first, first + count);
+      return CUP2D_ERR_HIP;
+    }
+    if (p->nquads) {
+      const double k = mode == 0 ? 1.0 : coef;
+      const walk::V2 *wv = (const walk::V2 *)vel, *wo = (const walk::V2 *)vold;
+#define LAUNCHW(M, OL)                                                                                             \
+  hipLaunchKernelGGL((k_advect_walk<M, OL>),                                                                       \
+                     dim3(wchunk > 0 ? chunked_grid(p->nquads, wchunk)                                             \
+                                     : resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<M, OL>), p->nquads)), \
+                     dim3(WG), 0, c->stream, wv, wo, out, p->d_quads, p->nquads, wchunk, k * afac, k * dfac)
+      if (mode == 0) LAUNCHW(0, false);
+      else if (vold == vel) LAUNCHW(1, true);
+      else LAUNCHW(1, false);
+#undef LAUNCHW
+      CUP2D_HIP_CHECK(hipGetLastError());
+    }
+    if (!p->nsingles) return CUP2D_OK;
+    list = p->d_singles;
+    first = 0;
+    count = p->nsingles;
+  }
 #define LAUNCH(Wt, M)                                                                                              \
   hipLaunchKernelGGL((k_advect_diffuse<Wt, M>),                                                                    \
                      dim3(chunk > 0 ? chunked_grid(count, chunk)                                                   \
                                     : resident_grid(c, reinterpret_cast<const void *>(&k_advect_diffuse<Wt, M>), count)), \
-                     dim3(WG), 0, c->stream, v, vo, o, c->d_nbr, first, count, chunk, afac, dfac, coef)
+                     dim3(WG), 0, c->stream, v, vo, o, c->d_nbr, list, first, count, chunk, afac, dfac, coef)
   if (c->math == CUP2D_MATH_STRICT) {
     if (mode == 0) LAUNCH(WenoStrict, 0); else LAUNCH(WenoStrict, 1);
   } else {

@@ -1,0 +1,317 @@
+// advect_walk.h -- WENO5 advect-diffuse on a QUAD of 2x2 blocks per wavefront, the reconstruction walking along
+// the grid lines in registers (FAST arithmetic policy; KernelAdvectDiffuse main.cpp:5441-5503, weno5_* 162-208).
+//
+// Why.  The per-block kernel (advect_tile.h) is bound by FP64 issue: 5 reconstructions of 41 operations per cell
+// (4 own centres + the block's rim) although consecutive centres of a grid line share four of their five inputs.
+// Here a LANE owns one component on a STRIP of 8 cells of one grid line and visits the strip's centres in order:
+//   * first differences D, second differences e, 13/3 e^2 + eps and e/3, -e/2 are formed ONCE per cell and stay in
+//     registers for the three centres that use them (a centre costs 33 issue slots instead of 45);
+//   * the face value of centre c-1 is the previous iterate: no hand-off through LDS, and a strip of 8 cells needs
+//     9 centres (one-sided upwinding) -- the "rim" of the per-block form (one extra reconstruction per cell) is gone;
+//   * the 5-point Laplacian of a line IS the second difference e the smoothness indicators need anyway.
+// A 16x16 tile x 2 components = 512 strips cells per direction = 64 lanes x 8: the x walk runs with lane =
+// (component, row, half row), leaves old + c (afac u dc/dx + dfac c_xx) in an LDS buffer, the y walk runs with lane =
+// (component, column, half column), adds its part and writes the result.  ~165 FP64 slots per cell against 277.
+//
+// The arithmetic is the WenoFast policy (weno.h) on the same differences, with the common factors moved:
+//   plus (c) = s_c + D1/2 + [W1 e1/3 + 2 W2 e2 + W3 (3/2 e2 - e3/2)] / (W1 + 6 W2 + 3 W3)
+//   minus(c) = s_c - D2/2 + [W3 e3/3 + 2 W2 e2 + W1 (3/2 e2 - e1/2)] / (W3 + 6 W2 + 3 W1)
+// with D_j = s_{c-1+j} - s_{c-2+j}, e_j = D_j - D_{j-1}, b_k = 4 beta_k + 4e-6, W1 = b2^2 b3^2, W2 = b1^2 b3^2,
+// W3 = b1^2 b2^2 (the weights 0.1, 0.6, 0.3 times ten).  It differs from WenoStrict by round-off only (same
+// tolerance as WenoFast, tests/test_gpu_parity.py); the STRICT policy stays on the per-block kernel.
+//
+// Everything a lane does is written as host+device functions of (lane, LDS image): tests/walk_emul.cpp runs the
+// same code lane by lane on the CPU against the CPU restatement of the reference, so that the GPU is needed for timing,
+// not for debugging.
+#pragma once
+#include <stdint.h>
+
+#include <array>
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define WALK_HD __host__ __device__ __forceinline__
+#else
+#define WALK_HD inline
+#endif
+
+namespace cup2d {
+namespace walk {
+
+constexpr int TS = 16;      // tile edge in cells: 2 x 2 blocks of 8 x 8
+constexpr int LW = TS + 6;  // ghosted tile edge (halo 3, cross only)
+// row strides in cells (16 bytes): the x walk reads 16 rows at the same column (25 = odd: the 16 lanes of a
+// ds_read group land in 16 different 16-byte bank groups), the y walk reads consecutive columns
+constexpr int LS = 25;
+constexpr int TSTR = 17;
+constexpr int QINTS = 12;   // ints per quad of the plan
+typedef double V2 __attribute__((vector_size(16)));  // (u, v) of a cell: one 16-byte access, a first-class value in registers
+struct Lds {
+  V2 lab[LW * LS];   // the ghosted tile, cell (X, Y), X, Y in [-3, 19): lab[(Y + 3) * LS + X + 3]
+  V2 T[TS * TSTR];   // hand-over between the walks: old value in, old + x part out
+};
+
+// ---- the plan: which blocks form quads (host) ---------------------------------------------------------------
+// quad[0..3]  = the blocks at (px, py) = (0,0), (1,0), (0,1), (1,1)   (W -> E is +x, S -> N is +y)
+// quad[4..11] = what lies outside: W of row 0, W of row 1, E of row 0, E of row 1, S of column 0, S of column 1,
+//               N of column 0, N of column 1: a block id (owned or ghost), or -1 - (own block) at a domain wall.
+// Blocks of [first, first + count) that found no partners are `singles` (they take the per-block kernel).
+static inline void build_plan(const int32_t *nbr, int first, int count, std::vector<int32_t> &quads,
+                              std::vector<int32_t> &singles) {
+  quads.clear();
+  singles.clear();
+  if (count <= 0) return;
+  auto in = [&](int b) { return b >= first && b < first + count; };
+  auto N = [&](int b, int side) { return nbr[4 * b + side]; };  // 0 W, 1 E, 2 S, 3 N
+  // block coordinates from the neighbour table alone: flood fill of every connected piece of the range
+  std::vector<int> X(count), Y(count), comp(count, -1), stack;
+  std::vector<int> quad_of(count, -1);
+  std::vector<std::array<int, 4>> found;
+  int ncomp = 0;
+  for (int seed = first; seed < first + count; seed++) {
+    if (comp[seed - first] >= 0) continue;
+    std::vector<int> members;
+    comp[seed - first] = ncomp;
+    X[seed - first] = Y[seed - first] = 0;
+    stack.assign(1, seed);
+    while (!stack.empty()) {
+      const int b = stack.back();
+      stack.pop_back();
+      members.push_back(b);
+      const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+      for (int s = 0; s < 4; s++) {
+        const int nb = N(b, s);
+        if (nb < 0 || !in(nb) || comp[nb - first] >= 0) continue;
+        comp[nb - first] = ncomp;
+        X[nb - first] = X[b - first] + dx[s];
+        Y[nb - first] = Y[b - first] + dy[s];
+        stack.push_back(nb);
+      }
+    }
+    ncomp++;
+    // the parity of the 2 x 2 tiling that covers most blocks of this piece (an even-sized rectangle: all of them)
+    std::vector<std::array<int, 4>> best;
+    for (int par = 0; par < 4; par++) {
+      std::vector<std::array<int, 4>> cand;
+      for (int b : members) {  // b as the SW corner of a cell of the tiling
+        if (((X[b - first] ^ par) & 1) || ((Y[b - first] ^ (par >> 1)) & 1)) continue;
+        const int e = N(b, 1), n = N(b, 3);
+        if (e < 0 || n < 0 || !in(e) || !in(n)) continue;
+        const int ne = N(e, 3);
+        if (ne < 0 || !in(ne)) continue;
+        const int q[4] = {b, e, n, ne};
+        bool good = e != n && ne != b && N(q[0], 1) == q[1] && N(q[1], 0) == q[0] && N(q[2], 1) == q[3] &&
+                    N(q[3], 0) == q[2] && N(q[0], 3) == q[2] && N(q[2], 2) == q[0] && N(q[1], 3) == q[3] && N(q[3], 2) == q[1];
+        // the flood fill's coordinates agree (they could not on a wrapped topology)
+        good = good && X[e - first] == X[b - first] + 1 && Y[e - first] == Y[b - first] && X[n - first] == X[b - first] &&
+               Y[n - first] == Y[b - first] + 1 && X[ne - first] == X[b - first] + 1 && Y[ne - first] == Y[b - first] + 1;
+        if (good) cand.push_back({q[0], q[1], q[2], q[3]});
+      }
+      if (cand.size() > best.size()) best.swap(cand);
+    }
+    for (auto &q : best) {
+      for (int k = 0; k < 4; k++) quad_of[q[k] - first] = (int)found.size();
+      found.push_back(q);
+    }
+  }
+  // quads in the order of their first block: the caller's (space-filling-curve) locality carries over
+  std::vector<char> done(found.size(), 0);
+  for (int b = first; b < first + count; b++) {
+    const int qi = quad_of[b - first];
+    if (qi < 0) {
+      singles.push_back(b);
+      continue;
+    }
+    if (done[qi]) continue;
+    done[qi] = 1;
+    const auto &q = found[qi];
+    const int side_of[8] = {0, 0, 1, 1, 2, 2, 3, 3};
+    const int owner[8] = {q[0], q[2], q[1], q[3], q[0], q[1], q[2], q[3]};
+    for (int k = 0; k < 4; k++) quads.push_back(q[k]);
+    for (int s = 0; s < 8; s++) {
+      const int nb = N(owner[s], side_of[s]);
+      quads.push_back(nb >= 0 ? nb : -1 - owner[s]);
+    }
+  }
+}
+
+// ---- staging -------------------------------------------------------------------------------------------------
+// the 192 ghost cells of a tile (8 (side, half) slots of 8 x 3 cells) are three per lane; what a lane needs to know
+// about its i-th one, packed: cell in the neighbour block | cell in the own block (wall) << 6 | slot << 12 |
+// LDS position << 16
+WALK_HD int ghost_pack(int lane, int i) {
+  const int idx = i * 64 + lane;
+  const int slot = idx / 24, t = idx - 24 * slot;
+  const int side = slot >> 1, half = slot & 1;
+  const bool hi = side & 1;
+  const int r = t / 3, k = t - 3 * r;  // W / E: 8 rows x 3 columns
+  const int j = t >> 3, x = t & 7;     // S / N: 3 rows x 8 columns
+  const bool we = side < 2;
+  const int cell_nb = we ? r * 8 + (hi ? k : 5 + k) : (hi ? j : 5 + j) * 8 + x;
+  const int cell_own = we ? r * 8 + (hi ? 7 : 0) : (hi ? 7 : 0) * 8 + x;
+  const int X = we ? (hi ? 16 + k : k - 3) : 8 * half + x;
+  const int Y = we ? 8 * half + r : (hi ? 16 + j : j - 3);
+  return cell_nb | cell_own << 6 | slot << 12 | ((Y + 3) * LS + X + 3) << 16;
+}
+
+// one tile in flight from memory.  fetch() must not look at a loaded value (the first use is where the compiler
+// waits for the load): the wall sign flips happen in stage().
+struct Regs {
+  V2 own[4], gh[3], old[4];
+  int nb[3];
+};
+// The quad's plan entry arrives as twelve VALUES (wave-uniform: the kernel reads the entry a whole quad ahead, so that no
+// load of this function waits for another one).  Scalars, not an array: the selects below, written on an array, are
+// turned into an indexed read of that array from scratch memory.
+struct Entry {
+  int b0, b1, b2, b3;                   // the blocks at (0,0), (1,0), (0,1), (1,1)
+  int n0, n1, n2, n3, n4, n5, n6, n7;   // W0 W1 E0 E1 S0 S1 N0 N1
+};
+template <bool NEED_OLD>
+WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vold, int b0, int b1, int b2, int b3, int n0,
+                   int n1, int n2, int n3, int n4, int n5, int n6, int n7, int lane, const int (&gp)[3]) {
+  const int b[4] = {b0, b1, b2, b3};
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const size_t at = (size_t)b[p] * 64 + lane;
+    R.own[p] = f[at];
+    if (NEED_OLD) R.old[p] = vold[at];
+  }
+  // ghost cell 64 i + lane lies in slot (64 i + lane) / 24
+  R.nb[0] = lane < 24 ? n0 : lane < 48 ? n1 : n2;
+  R.nb[1] = lane < 8 ? n2 : lane < 32 ? n3 : lane < 56 ? n4 : n5;
+  R.nb[2] = lane < 16 ? n5 : lane < 40 ? n6 : n7;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int nb = R.nb[i];
+    const bool wall = nb < 0;
+    const int blk = wall ? -1 - nb : nb;
+    const int cell = wall ? (gp[i] >> 6) & 63 : gp[i] & 63;  // VectorLab::applyBCface main.cpp:3131-3204: every ghost layer repeats the edge cell
+    R.gh[i] = f[(size_t)blk * 64 + cell];
+  }
+}
+template <bool NEED_OLD>
+WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vold, const Entry &e, int lane,
+                   const int (&gp)[3]) {
+  fetch<NEED_OLD>(R, f, vold, e.b0, e.b1, e.b2, e.b3, e.n0, e.n1, e.n2, e.n3, e.n4, e.n5, e.n6, e.n7, lane, gp);
+}
+template <bool NEED_OLD>
+WALK_HD void stage(const Regs &R, Lds &L, int lane, const int (&gp)[3]) {
+  const int ix = lane & 7, iy = lane >> 3;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int px = p & 1, py = p >> 1;
+    L.lab[(8 * py + iy + 3) * LS + 8 * px + ix + 3] = R.own[p];
+    if (NEED_OLD) L.T[(8 * py + iy) * TSTR + 8 * px + ix] = R.old[p];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    V2 v = R.gh[i];
+    if (R.nb[i] < 0) {  // free-slip wall: the wall-normal component changes sign
+      if (((gp[i] >> 12) & 7) < 4) v[0] = -v[0]; else v[1] = -v[1];
+    }
+    L.lab[gp[i] >> 16] = v;
+  }
+}
+// which upwind sides anybody in the tile asks for (main.cpp:5493-5496: x derivatives follow u > 0, y derivatives
+// v > 0): bit 0 some u > 0, bit 1 some u <= 0, bit 2 some v > 0, bit 3 some v <= 0 -- of this lane's four cells
+WALK_HD int lane_signs(const Regs &R) {
+  int m = 0;
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    m |= R.own[p][0] > 0 ? 1 : 2;
+    m |= R.own[p][1] > 0 ? 4 : 8;
+  }
+  return m;
+}
+
+// ---- the walk ------------------------------------------------------------------------------------------------
+WALK_HD double rcp_newton(double d) {  // weno.h fast_rcp
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+#else
+  double r = 1.0 / d;
+#endif
+  return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
+// One strip of 8 cells of a grid line.  s -> the strip's cell 0, component of this lane; a -> the advecting
+// component of cell 0; consecutive cells are 2 * STRIDE doubles apart.  DOP / DOM: somebody in the tile upwinds with
+// plus / minus (wave-uniform).  tail(cell, d, lap, centre) receives the upwind difference (derivative(),
+// main.cpp:202-208), the second difference and the value of the cell.
+template <bool DOP, bool DOM, int STRIDE, class Tail>
+WALK_HD void walk_strip(const double *__restrict__ s, const double *__restrict__ a, Tail &&tail) {
+  constexpr double K = 13.0 / 3.0, E4 = 4e-6, THIRD = 1.0 / 3.0;
+  constexpr int C0 = DOP ? -1 : 0, C1 = DOM ? 8 : 7, ST = 2 * STRIDE;
+  // centre C0: s[C0-2 .. C0+1] are in, s[C0+2] arrives in the loop
+  double sB = s[ST * (C0 - 1)], sC = s[ST * C0], sD = s[ST * (C0 + 1)];
+  double D0 = sB - s[ST * (C0 - 2)], D1 = sC - sB, D2 = sD - sC;
+  double e1 = D1 - D0, e2 = D2 - D1;
+  double m1 = __builtin_fma(K * e1, e1, E4), m2 = __builtin_fma(K * e2, e2, E4);
+  double a1 = e1 * THIRD, a2 = e2 * THIRD, h1 = -0.5 * e1, h2 = -0.5 * e2;
+  double Pm1 = 0, Pm2 = 0, Mm1 = 0;
+#pragma unroll
+  for (int c = C0; c <= C1; c++) {
+    const double sE = s[ST * (c + 2)];
+    const double D3 = sE - sD, e3 = D3 - D2;
+    const double m3 = __builtin_fma(K * e3, e3, E4), a3 = e3 * THIRD, h3 = -0.5 * e3;
+    const double t2 = __builtin_fma(3.0, D1, -D0), t4 = D1 + D2, t6 = __builtin_fma(-3.0, D2, D3);
+    const double b1 = __builtin_fma(t2, t2, m1), b2 = __builtin_fma(t4, t4, m2), b3 = __builtin_fma(t6, t6, m3);
+    const double q1 = b1 * b1, q2 = b2 * b2, q3 = b3 * b3;
+    const double W1 = q2 * q3, W3 = q1 * q2, X2 = (q1 + q1) * q3;
+    double P = 0, M = 0;
+    if (DOP && c <= 7) {
+      const double num = __builtin_fma(W1, a1, __builtin_fma(X2, e2, W3 * __builtin_fma(1.5, e2, h3)));
+      const double den = __builtin_fma(3.0, X2 + W3, W1);
+      P = __builtin_fma(num, rcp_newton(den), __builtin_fma(0.5, D1, sC));
+    }
+    if (DOM && c >= 0) {
+      const double num = __builtin_fma(W3, a3, __builtin_fma(X2, e2, W1 * __builtin_fma(1.5, e2, h1)));
+      const double den = __builtin_fma(3.0, X2 + W1, W3);
+      M = __builtin_fma(num, rcp_newton(den), __builtin_fma(-0.5, D2, sC));
+    }
+    if (DOP && !DOM) {
+      if (c >= 0) tail(c, P - Pm1, e2, sC);                  // U > 0: plus(c) - plus(c-1)
+    } else if (!DOP && DOM) {
+      if (c >= 1) tail(c - 1, M - Mm1, e1, sB);              // else : minus(c+1) - minus(c)
+    } else {
+      if (c >= 1) tail(c - 1, a[ST * (c - 1)] > 0 ? Pm1 - Pm2 : M - Mm1, e1, sB);
+    }
+    Pm2 = Pm1; Pm1 = P; Mm1 = M;
+    sB = sC; sC = sD; sD = sE;
+    D0 = D1; D1 = D2; D2 = D3;
+    e1 = e2; e2 = e3; m1 = m2; m2 = m3; a1 = a2; a2 = a3; h1 = h2; h2 = h3;
+  }
+}
+
+// MODE 0: out = rhs; MODE 1: out = old + coef rhs (coef is inside afc, dfc).  OLDLAB: old is the tile's own
+// centre value (RK stage 1: vold = vel).
+// x walk: lane = (component, row, half row); leaves old + afc u dc/dx + dfc c_xx in L.T
+template <bool DOP, bool DOM, int MODE, bool OLDLAB>
+WALK_HD void xwalk(Lds &L, int lane, double afc, double dfc) {
+  const int comp = lane & 1, row = (lane >> 1) & 15, seg = lane >> 5;
+  const double *lab = reinterpret_cast<const double *>(&L.lab[(row + 3) * LS + 8 * seg + 3]);
+  double *T = reinterpret_cast<double *>(&L.T[row * TSTR + 8 * seg]) + comp;
+  walk_strip<DOP, DOM, 1>(lab + comp, lab, [&](int cell, double d, double lap, double centre) {
+    const double old = MODE == 0 ? 0.0 : (OLDLAB ? centre : T[2 * cell]);
+    const double aa = afc * lab[2 * cell];
+    T[2 * cell] = __builtin_fma(aa, d, MODE == 0 ? dfc * lap : __builtin_fma(dfc, lap, old));
+  });
+}
+// y walk: lane = (component, column, half column); adds afc v dc/dy + dfc c_yy and writes the result.  `out` is the
+// slab (doubles); blk = the block this lane's strip lies in (quad[2 seg + (column >> 3)])
+template <bool DOP, bool DOM>
+WALK_HD void ywalk(Lds &L, int lane, double afc, double dfc, double *__restrict__ out, int blk) {
+  const int comp = lane & 1, col = (lane >> 1) & 15, seg = lane >> 5;
+  const double *lab = reinterpret_cast<const double *>(&L.lab[(8 * seg + 3) * LS + col + 3]);
+  const double *T = reinterpret_cast<const double *>(&L.T[8 * seg * TSTR + col]) + comp;
+  double *o = out + ((size_t)blk * 64 + (col & 7)) * 2 + comp;
+  walk_strip<DOP, DOM, LS>(lab + comp, lab + 1, [&](int cell, double d, double lap, double) {
+    const double aa = afc * lab[2 * LS * cell + 1];
+    o[16 * cell] = __builtin_fma(aa, d, __builtin_fma(dfc, lap, T[2 * TSTR * cell]));
+  });
+}
+
+}  // namespace walk
+}  // namespace cup2d

@@ -259,6 +259,7 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   c->stream = c->own_stream;
   CUP2D_HIP_CHECK(dev_malloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
   CUP2D_HIP_CHECK(hipMemcpy(c->d_nbr, nbr, sizeof(int32_t) * 4 * nblocks, hipMemcpyHostToDevice));
+  c->h_nbr.assign(nbr, nbr + 4 * (size_t)nblocks);
   for (int f = 0; f < CUP2D_NFIELDS; f++) {
     const size_t bytes = slab_doubles(c, dim_of(f)) * sizeof(double);
     CUP2D_HIP_CHECK(dev_malloc(&c->d_field[f], bytes));
@@ -308,6 +309,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   (void)hipDeviceSynchronize();
   (void)comm_finalize_impl(c);
   bodies_release(c);
+  walk_plans_release(c);
   dev_free(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) dev_free(c->d_field[f]);
   dev_free(c->d_vscratch);

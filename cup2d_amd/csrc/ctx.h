@@ -105,6 +105,12 @@ constexpr int FUSED_TILE = 16;  // blocks per tile of the fused sweeps = N of v_
 
 enum { PRECOND_LDS = 0, PRECOND_MFMA = 1, PRECOND_FD = 2 };
 
+// advect.hip: the quads (advect_walk.h) of one block range of a context, and the blocks that found no partners
+struct WalkPlan {
+  int first = 0, count = 0, nquads = 0, nsingles = 0;
+  int32_t *d_quads = nullptr, *d_singles = nullptr;
+};
+
 struct RcclComm;  // comm.hip: the in-library RCCL communicator (cup2d_comm_init)
 struct Bodies;    // penalize.hip: host-supplied bodies (cup2d_body_set)
 
@@ -135,6 +141,8 @@ struct cup2d_ctx {
   int num_cus = 0;
   std::vector<std::pair<const void *, int>> resident;  // kernel -> workgroups per CU (occupancy query, cached)
   int32_t *d_nbr = nullptr;
+  std::vector<int32_t> h_nbr;                 // host copy (advect.hip builds its quad plans from it)
+  std::vector<cup2d::WalkPlan> walk_plans;    // one per block range asked for
   double *d_field[CUP2D_NFIELDS] = {nullptr};
   double *d_vscratch = nullptr;  // RK2 mid-point velocity (vector slab)
   // Krylov vectors (scalar slabs; z/z2 carry ghost blocks)
@@ -307,6 +315,7 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
 void bodies_release(cup2d_ctx *c);  // penalize.hip
+void walk_plans_release(cup2d_ctx *c);  // advect.hip
 // comm.hip
 int comm_finalize_impl(cup2d_ctx *c);
 // d_red[0 .. nsum) summed and d_red[2] maximised over the ranks in ONE all-gather, finished in rank order by the kernel that

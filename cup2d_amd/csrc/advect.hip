@@ -182,9 +182,9 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
     else if (!nPx) walk::xwalk<false, true, MODE, OLDLAB>(L, lane, afc, dfc);
     else walk::xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
     wave_lds_sync();
-    if (!nMy) walk::ywalk<true, false>(L, lane, afc, dfc, out, blk);
-    else if (!nPy) walk::ywalk<false, true>(L, lane, afc, dfc, out, blk);
-    else walk::ywalk<true, true>(L, lane, afc, dfc, out, blk);
+    if (!nMy) walk::ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc, out, blk);
+    else if (!nPy) walk::ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
+    else walk::ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
     wave_lds_sync();  // the tile is overwritten by the next quad
   }
 #undef WALK_READ

@@ -238,47 +238,61 @@ WALK_HD double rcp_newton(double d) {  // weno.h fast_rcp
 
 // One strip of 8 cells of a grid line.  s -> the strip's cell 0, component of this lane; a -> the advecting
 // component of cell 0; consecutive cells are 2 * STRIDE doubles apart.  DOP / DOM: somebody in the tile upwinds with
-// plus / minus (wave-uniform).  tail(cell, d, lap, centre) receives the upwind difference (derivative(),
-// main.cpp:202-208), the second difference and the value of the cell.
+// plus / minus (wave-uniform).  tail(cell, d, lap, centre, adv) receives the upwind difference (derivative(),
+// main.cpp:202-208), the second difference, the value of the cell and its advecting velocity.
 template <bool DOP, bool DOM, int STRIDE, class Tail>
 WALK_HD void walk_strip(const double *__restrict__ s, const double *__restrict__ a, Tail &&tail) {
   constexpr double K = 13.0 / 3.0, E4 = 4e-6, THIRD = 1.0 / 3.0;
   constexpr int C0 = DOP ? -1 : 0, C1 = DOM ? 8 : 7, ST = 2 * STRIDE;
+  // every LDS read of the strip is issued here, ahead of the arithmetic: read where they are used, each one exposes
+  // its latency (the walk is one dependent chain per lane and only three waves share a SIMD)
+  double v[C1 - C0 + 5], adv[8];
+#pragma unroll
+  for (int i = 0; i < C1 - C0 + 5; i++) v[i] = s[ST * (C0 - 2 + i)];
+#pragma unroll
+  for (int i = 0; i < 8; i++) adv[i] = a[ST * i];
   // centre C0: s[C0-2 .. C0+1] are in, s[C0+2] arrives in the loop
-  double sB = s[ST * (C0 - 1)], sC = s[ST * C0], sD = s[ST * (C0 + 1)];
-  double D0 = sB - s[ST * (C0 - 2)], D1 = sC - sB, D2 = sD - sC;
+  double sB = v[1], sC = v[2], sD = v[3];
+  double D0 = sB - v[0], D1 = sC - sB, D2 = sD - sC;
   double e1 = D1 - D0, e2 = D2 - D1;
   double m1 = __builtin_fma(K * e1, e1, E4), m2 = __builtin_fma(K * e2, e2, E4);
   double a1 = e1 * THIRD, a2 = e2 * THIRD, h1 = -0.5 * e1, h2 = -0.5 * e2;
-  double Pm1 = 0, Pm2 = 0, Mm1 = 0;
+  // The upwind difference is formed from the small parts only (the centre values cancel exactly):
+  //   plus(c) - plus(c-1)   = D1 + e1/2 + (QP(c) - QP(c-1))      QP, QM = the weighted corrections num / den
+  //   minus(c) - minus(c-1) = D1 - e2/2 + (QM(c) - QM(c-1))
+  // so that its rounding error scales with the differences, not with the values (the reference subtracts two rounded
+  // face values, main.cpp:202-208: its own error of ~1e-16 |u| is what the FAST tolerance has to cover).
+  double QPm1 = 0, QMm1 = 0, dPm1 = 0;
 #pragma unroll
   for (int c = C0; c <= C1; c++) {
-    const double sE = s[ST * (c + 2)];
+    const double sE = v[c + 2 - (C0 - 2)];
     const double D3 = sE - sD, e3 = D3 - D2;
     const double m3 = __builtin_fma(K * e3, e3, E4), a3 = e3 * THIRD, h3 = -0.5 * e3;
     const double t2 = __builtin_fma(3.0, D1, -D0), t4 = D1 + D2, t6 = __builtin_fma(-3.0, D2, D3);
     const double b1 = __builtin_fma(t2, t2, m1), b2 = __builtin_fma(t4, t4, m2), b3 = __builtin_fma(t6, t6, m3);
     const double q1 = b1 * b1, q2 = b2 * b2, q3 = b3 * b3;
     const double W1 = q2 * q3, W3 = q1 * q2, X2 = (q1 + q1) * q3;
-    double P = 0, M = 0;
+    double QP = 0, QM = 0;
     if (DOP && c <= 7) {
       const double num = __builtin_fma(W1, a1, __builtin_fma(X2, e2, W3 * __builtin_fma(1.5, e2, h3)));
       const double den = __builtin_fma(3.0, X2 + W3, W1);
-      P = __builtin_fma(num, rcp_newton(den), __builtin_fma(0.5, D1, sC));
+      QP = num * rcp_newton(den);
     }
     if (DOM && c >= 0) {
       const double num = __builtin_fma(W3, a3, __builtin_fma(X2, e2, W1 * __builtin_fma(1.5, e2, h1)));
       const double den = __builtin_fma(3.0, X2 + W1, W3);
-      M = __builtin_fma(num, rcp_newton(den), __builtin_fma(-0.5, D2, sC));
+      QM = num * rcp_newton(den);
     }
+    const double dP = (QP - QPm1) + __builtin_fma(0.5, e1, D1);   // plus(c) - plus(c-1): cell c
+    const double dM = (QM - QMm1) + __builtin_fma(-0.5, e2, D1);  // minus(c) - minus(c-1): cell c-1
     if (DOP && !DOM) {
-      if (c >= 0) tail(c, P - Pm1, e2, sC);                  // U > 0: plus(c) - plus(c-1)
+      if (c >= 0) tail(c, dP, e2, sC, adv[c < 0 ? 0 : c]);   // U > 0: plus(c) - plus(c-1)
     } else if (!DOP && DOM) {
-      if (c >= 1) tail(c - 1, M - Mm1, e1, sB);              // else : minus(c+1) - minus(c)
+      if (c >= 1) tail(c - 1, dM, e1, sB, adv[c < 1 ? 0 : c - 1]);  // else : minus(c+1) - minus(c)
     } else {
-      if (c >= 1) tail(c - 1, a[ST * (c - 1)] > 0 ? Pm1 - Pm2 : M - Mm1, e1, sB);
+      if (c >= 1) tail(c - 1, adv[c < 1 ? 0 : c - 1] > 0 ? dPm1 : dM, e1, sB, adv[c < 1 ? 0 : c - 1]);
     }
-    Pm2 = Pm1; Pm1 = P; Mm1 = M;
+    QPm1 = QP; QMm1 = QM; dPm1 = dP;
     sB = sC; sC = sD; sD = sE;
     D0 = D1; D1 = D2; D2 = D3;
     e1 = e2; e2 = e3; m1 = m2; m2 = m3; a1 = a2; a2 = a3; h1 = h2; h2 = h3;
@@ -293,23 +307,31 @@ WALK_HD void xwalk(Lds &L, int lane, double afc, double dfc) {
   const int comp = lane & 1, row = (lane >> 1) & 15, seg = lane >> 5;
   const double *lab = reinterpret_cast<const double *>(&L.lab[(row + 3) * LS + 8 * seg + 3]);
   double *T = reinterpret_cast<double *>(&L.T[row * TSTR + 8 * seg]) + comp;
-  walk_strip<DOP, DOM, 1>(lab + comp, lab, [&](int cell, double d, double lap, double centre) {
+  // (the old values of RK stage 2 are read where they are used: this variant also holds them in flight for the next
+  // quad, and eight more registers per lane spill)
+  walk_strip<DOP, DOM, 1>(lab + comp, lab, [&](int cell, double d, double lap, double centre, double adv) {
     const double old = MODE == 0 ? 0.0 : (OLDLAB ? centre : T[2 * cell]);
-    const double aa = afc * lab[2 * cell];
+    const double aa = afc * adv;
     T[2 * cell] = __builtin_fma(aa, d, MODE == 0 ? dfc * lap : __builtin_fma(dfc, lap, old));
   });
 }
 // y walk: lane = (component, column, half column); adds afc v dc/dy + dfc c_yy and writes the result.  `out` is the
 // slab (doubles); blk = the block this lane's strip lies in (quad[2 seg + (column >> 3)])
-template <bool DOP, bool DOM>
+// PRE: the x parts are read from L.T ahead of the arithmetic (eight more live values per lane)
+template <bool DOP, bool DOM, bool PRE>
 WALK_HD void ywalk(Lds &L, int lane, double afc, double dfc, double *__restrict__ out, int blk) {
   const int comp = lane & 1, col = (lane >> 1) & 15, seg = lane >> 5;
   const double *lab = reinterpret_cast<const double *>(&L.lab[(8 * seg + 3) * LS + col + 3]);
   const double *T = reinterpret_cast<const double *>(&L.T[8 * seg * TSTR + col]) + comp;
   double *o = out + ((size_t)blk * 64 + (col & 7)) * 2 + comp;
-  walk_strip<DOP, DOM, LS>(lab + comp, lab + 1, [&](int cell, double d, double lap, double) {
-    const double aa = afc * lab[2 * LS * cell + 1];
-    o[16 * cell] = __builtin_fma(aa, d, __builtin_fma(dfc, lap, T[2 * TSTR * cell]));
+  double tx[8];
+  if (PRE) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) tx[i] = T[2 * TSTR * i];
+  }
+  walk_strip<DOP, DOM, LS>(lab + comp, lab + 1, [&](int cell, double d, double lap, double, double adv) {
+    const double aa = afc * adv;
+    o[16 * cell] = __builtin_fma(aa, d, __builtin_fma(dfc, lap, PRE ? tx[cell] : T[2 * TSTR * cell]));
   });
 }
 

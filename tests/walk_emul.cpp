@@ -33,9 +33,9 @@ static void run_quad(const V2 *vel, const V2 *vold, double *out, const int *q, d
   }
   for (int lane = 0; lane < 64; lane++) {
     const int blk = q[2 * (lane >> 5) + ((lane >> 4) & 1)];
-    if (!nMy) ywalk<true, false>(L, lane, afc, dfc, out, blk);
-    else if (!nPy) ywalk<false, true>(L, lane, afc, dfc, out, blk);
-    else ywalk<true, true>(L, lane, afc, dfc, out, blk);
+    if (!nMy) ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc, out, blk);
+    else if (!nPy) ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
+    else ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
   }
 }
 

@@ -430,7 +430,10 @@ def main():
     ALGO_BYTES = {"advect_stage": 40.0, "poisson_rhs": 32.0, "sweep_A": 40.0, "sweep_B": 24.0, "sweep_C": 32.0,
                   "sweep_D": 24.0, "sweep_E": 64.0, "init_residual": 32.0, "smoother": 24.0}
     mk = "true" if args.finish == "kernel" and dist is None else "false"
-    KERNEL_OF = {"advect_stage": "k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>",
+    # FAST policy: the quad kernel (csrc/advect_walk.h; stage 1 is <1, true>, stage 2 <1, false>) unless CUP2D_ADVECT_WALK=0
+    walk = args.math == "fast" and os.environ.get("CUP2D_ADVECT_WALK", "1") != "0"
+    KERNEL_OF = {"advect_stage": "k_advect_walk<1, true|false>" if walk else
+                 ("k_advect_diffuse<WenoFast, 1>" if args.math == "fast" else "k_advect_diffuse<WenoStrict, 1>"),
                  "poisson_rhs": "k_pressure_rhs<false, true>", "sweep_A": "k_sweepA_fd", "sweep_B": "k_sweepBD<1, %s>" % mk,
                  "sweep_C": "k_sweepC_fd", "sweep_D": "k_sweepBD<2, %s>" % mk, "sweep_E": "k_sweepE<%s>" % mk,
                  "init_residual": "k_init_residual", "smoother": "k_smoother<0, false, 1>"}
@@ -493,13 +496,15 @@ def main():
     roofline = all_roof.get(dominant)
     # the north-star kernel (fused WENO5 advect-diffuse RK stage) is FP64-issue bound, not HBM bound: next to the
     # HBM fraction report the FP64 instruction rate against the measured VALU ceiling (tools/fp64_peak.hip:
-    # 32 T lane-instr/s sustained on this chip; 39.3 T at the nominal 2.4 GHz) -- DESIGN.md section 4.1
+    # 29-32 T lane-instr/s sustained on this chip -- fma 29.4, mul 31.2, add 32.1; 39.3 T at the nominal 2.4 GHz) --
+    # DESIGN.md section 4.1
     north = dict(all_roof["advect_stage"]) if "advect_stage" in all_roof else None
     if north:
         sec = north["avg_launch_ms"] * 1e-3
         # FP64 VALU instructions executed per cell in a block whose velocity components do not change sign
         # (counted in the gfx950 ISA of advect.hip; SQ_INSTS_VALU measures the VALU instructions of all kinds)
-        fp64_per_cell = 241.0 if args.math == "fast" else 565.0
+        # quad kernel: 645 FP64 instructions per lane and quad of 256 cells (two walks of 318 + the sign tests) = 161 per cell
+        fp64_per_cell = (161.0 if walk else 241.0) if args.math == "fast" else 565.0
         rate = fp64_per_cell * cells_rank / sec / 1e12
         north.update({"mcells_per_s": round(cells_rank / sec / 1e6, 1), "fp64_instr_per_cell": fp64_per_cell,
                       "fp64_T_lane_instr_per_s": round(rate, 2), "fp64_frac_of_measured_ceiling_32T": round(rate / 32.0, 4),

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG, 4) void k_advect_diffuse(const double2 *__restr
 template <int MODE, bool OLDLAB>
 __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restrict__ vel, const walk::V2 *__restrict__ vold,
                                                        double *__restrict__ out, const int *__restrict__ quads, int nq,
-                                                       int chunk, double afc, double dfc) {
+                                                       int chunk, double afc, double dfc, int prio_mode) {
   constexpr bool NEED_OLD = MODE == 1 && !OLDLAB;
   __shared__ walk::Lds lds[WPG];
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -137,7 +137,6 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
   int gp[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) gp[i] = walk::ghost_pack(lane, i);
-  const int ypos = 2 * (lane >> 5) + ((lane >> 4) & 1);  // the block the y walk of this lane writes to
   const GroupRange gr = chunk > 0 ? group_range_chunked(nq, chunk) : group_range(nq);
   int g = gr.begin;
   bool have = g < gr.end && g * WPG + wave < nq;
@@ -165,28 +164,57 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
   walk::Regs R;
   walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
   int vnext = entry_of(g + gr.stride)[tl];
+  walk::V2 *out2 = reinterpret_cast<walk::V2 *>(out);
+  int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;  // the blocks of the quad whose results wait in L.T
+  bool pending = false;
+  // VALU issue goes to the OLDEST of the three waves that share a SIMD; with equal shares of quads the oldest wave of a
+  // SIMD finishes early and the youngest computes alone at the end (average wave lifetime 74 % of the kernel).  Priority
+  // outranks age, so every wave takes the top priority for one quad in three: equal progress, a common finish.
+  const int wid = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;  // HW_ID.wave_id: the slot in the SIMD's wave buffer
+  int turn = wid;
   while (have) {
-    walk::stage<NEED_OLD>(R, L, lane, gp);
+    if (prio_mode) {
+      if (turn == 0) __builtin_amdgcn_s_setprio(2);
+      else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      turn = turn == 2 ? 0 : turn + 1;
+    }
+    walk::stage_lab(R, L, lane, gp);
     const int sg = walk::lane_signs(R);
     const bool nPx = __ballot(sg & 1) != 0ull, nMx = __ballot(sg & 2) != 0ull;
     const bool nPy = __ballot(sg & 4) != 0ull, nMy = __ballot(sg & 8) != 0ull;
-    const int blk = ypos == 0 ? E.b0 : ypos == 1 ? E.b1 : ypos == 2 ? E.b2 : E.b3;
-    wave_lds_sync();
+    const int cb0 = E.b0, cb1 = E.b1, cb2 = E.b2, cb3 = E.b3;
     // the next quad of this wave (its last one is simply fetched twice)
     g += gr.stride;
     have = g < gr.end && g * WPG + wave < nq;
-    WALK_READ(E, vnext);
-    walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
-    vnext = entry_of(g + gr.stride)[tl];
+    WALK_READ(E, vnext);  // (waits for everything issued so far: the loads of this quad, the stores of the one before last)
+#ifndef WALK_KNOCKOUT
+#define WALK_KNOCKOUT 0  // timing aid: 1 = no arithmetic (memory skeleton only), 2 = no loads / stores inside the loop
+#endif
+    if (pending && WALK_KNOCKOUT != 2) walk::flush(L, lane, out2, pb0, pb1, pb2, pb3);
+    if (NEED_OLD) walk::stage_old(R, L, lane);
+    wave_lds_sync();
+    if (WALK_KNOCKOUT != 2) {
+      walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
+      vnext = entry_of(g + gr.stride)[tl];
+    }
+    if (WALK_KNOCKOUT == 1) {
+      pb0 = cb0, pb1 = cb1, pb2 = cb2, pb3 = cb3;
+      pending = true;
+      continue;
+    }
     if (!nMx) walk::xwalk<true, false, MODE, OLDLAB>(L, lane, afc, dfc);
     else if (!nPx) walk::xwalk<false, true, MODE, OLDLAB>(L, lane, afc, dfc);
     else walk::xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
     wave_lds_sync();
-    if (!nMy) walk::ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc, out, blk);
-    else if (!nPy) walk::ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
-    else walk::ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
-    wave_lds_sync();  // the tile is overwritten by the next quad
+    if (!nMy) walk::ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc);
+    else if (!nPy) walk::ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc);
+    else walk::ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc);
+    wave_lds_sync();  // the tile is overwritten by the next quad; its results stay in L.T
+    pb0 = cb0, pb1 = cb1, pb2 = cb2, pb3 = cb3;
+    pending = true;
   }
+  walk::flush(L, lane, out2, pb0, pb1, pb2, pb3);
 #undef WALK_READ
 }
 
@@ -234,9 +262,10 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
   // FAST policy: quads of 2 x 2 blocks take the register-walk kernel, blocks without partners the per-block one
   // (CUP2D_ADVECT_WALK=0: everything per block, the round-1 kernel -- A/B timing aid)
   static const bool use_walk = [] { const char *e = getenv("CUP2D_ADVECT_WALK"); return !e || atoi(e) != 0; }();
-  static const int wchunk = [] { const char *e = getenv("CUP2D_WALK_CHUNK"); return e ? atoi(e) : 4; }();
+  static const int wchunk = [] { const char *e = getenv("CUP2D_WALK_CHUNK"); return e ? atoi(e) : 0; }();
+  static const int wprio = [] { const char *e = getenv("CUP2D_WALK_PRIO"); return e ? atoi(e) : 1; }();
   const int *list = nullptr;
-  if (c->math != CUP2D_MATH_STRICT && use_walk) {
+  if (c->math != CUP2D_MATH_STRICT && use_walk && ((size_t)c->ntotal << 10) < (1ull << 32)) {  // 32-bit byte offsets into a vector slab
     const WalkPlan *p = walk_plan(c, first, count);
     if (!p) {
       set_error("launch_advect: plan of blocks [%d, %d) could not be built", first, first + count);
@@ -249,7 +278,7 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
   hipLaunchKernelGGL((k_advect_walk<M, OL>),                                                                       \
                      dim3(wchunk > 0 ? chunked_grid(p->nquads, wchunk)                                             \
                                      : resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<M, OL>), p->nquads)), \
-                     dim3(WG), 0, c->stream, wv, wo, out, p->d_quads, p->nquads, wchunk, k * afac, k * dfac)
+                     dim3(WG), 0, c->stream, wv, wo, out, p->d_quads, p->nquads, wchunk, k * afac, k * dfac, wprio)
       if (mode == 0) LAUNCHW(0, false);
       else if (vold == vel) LAUNCHW(1, true);
       else LAUNCHW(1, false);

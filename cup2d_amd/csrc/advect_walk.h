@@ -172,11 +172,15 @@ template <bool NEED_OLD>
 WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vold, int b0, int b1, int b2, int b3, int n0,
                    int n1, int n2, int n3, int n4, int n5, int n6, int n7, int lane, const int (&gp)[3]) {
   const int b[4] = {b0, b1, b2, b3};
+  // addresses as (wave-uniform base) + (32-bit byte offset per lane): the loads take the base from scalar registers and
+  // no 64-bit vector arithmetic is spent on them (launch_advect sends slabs of 4 GiB and more to the per-block kernel)
+  const char *fb = reinterpret_cast<const char *>(f);
+  const unsigned lane16 = (unsigned)lane << 4;
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    const size_t at = (size_t)b[p] * 64 + lane;
-    R.own[p] = f[at];
-    if (NEED_OLD) R.old[p] = vold[at];
+    const size_t blk_bytes = (size_t)b[p] << 10;
+    R.own[p] = *reinterpret_cast<const V2 *>(fb + blk_bytes + lane16);
+    if (NEED_OLD) R.old[p] = *reinterpret_cast<const V2 *>(reinterpret_cast<const char *>(vold) + blk_bytes + lane16);
   }
   // ghost cell 64 i + lane lies in slot (64 i + lane) / 24
   R.nb[0] = lane < 24 ? n0 : lane < 48 ? n1 : n2;
@@ -186,9 +190,9 @@ WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vol
   for (int i = 0; i < 3; i++) {
     const int nb = R.nb[i];
     const bool wall = nb < 0;
-    const int blk = wall ? -1 - nb : nb;
-    const int cell = wall ? (gp[i] >> 6) & 63 : gp[i] & 63;  // VectorLab::applyBCface main.cpp:3131-3204: every ghost layer repeats the edge cell
-    R.gh[i] = f[(size_t)blk * 64 + cell];
+    const unsigned blk = wall ? -1 - nb : nb;
+    const unsigned cell = wall ? (gp[i] >> 6) & 63 : gp[i] & 63;  // VectorLab::applyBCface main.cpp:3131-3204: every ghost layer repeats the edge cell
+    R.gh[i] = *reinterpret_cast<const V2 *>(fb + ((blk << 10) + (cell << 4)));
   }
 }
 template <bool NEED_OLD>
@@ -196,14 +200,12 @@ WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vol
                    const int (&gp)[3]) {
   fetch<NEED_OLD>(R, f, vold, e.b0, e.b1, e.b2, e.b3, e.n0, e.n1, e.n2, e.n3, e.n4, e.n5, e.n6, e.n7, lane, gp);
 }
-template <bool NEED_OLD>
-WALK_HD void stage(const Regs &R, Lds &L, int lane, const int (&gp)[3]) {
+WALK_HD void stage_lab(const Regs &R, Lds &L, int lane, const int (&gp)[3]) {
   const int ix = lane & 7, iy = lane >> 3;
 #pragma unroll
   for (int p = 0; p < 4; p++) {
     const int px = p & 1, py = p >> 1;
     L.lab[(8 * py + iy + 3) * LS + 8 * px + ix + 3] = R.own[p];
-    if (NEED_OLD) L.T[(8 * py + iy) * TSTR + 8 * px + ix] = R.old[p];
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -213,6 +215,22 @@ WALK_HD void stage(const Regs &R, Lds &L, int lane, const int (&gp)[3]) {
     }
     L.lab[gp[i] >> 16] = v;
   }
+}
+// RK stage 2: the old values go to the hand-over buffer (after the previous quad's results have left it, flush())
+WALK_HD void stage_old(const Regs &R, Lds &L, int lane) {
+  const int ix = lane & 7, iy = lane >> 3;
+#pragma unroll
+  for (int p = 0; p < 4; p++) L.T[(8 * (p >> 1) + iy) * TSTR + 8 * (p & 1) + ix] = R.old[p];
+}
+// The results of a quad leave through the hand-over buffer: the y walk writes them to L.T, and the wave stores them with
+// four coalesced 16-byte accesses per lane AFTER it has issued the loads of the quad after the next -- the memory
+// counter is in order, so a store issued behind the prefetch would have to retire before the prefetched data may be
+// touched (measured: a fifth of a wave's cycles went to that wait).
+WALK_HD void flush(const Lds &L, int lane, V2 *__restrict__ out, int b0, int b1, int b2, int b3) {
+  const int ix = lane & 7, iy = lane >> 3;
+  const int b[4] = {b0, b1, b2, b3};
+#pragma unroll
+  for (int p = 0; p < 4; p++) out[(size_t)b[p] * 64 + lane] = L.T[(8 * (p >> 1) + iy) * TSTR + 8 * (p & 1) + ix];
 }
 // which upwind sides anybody in the tile asks for (main.cpp:5493-5496: x derivatives follow u > 0, y derivatives
 // v > 0): bit 0 some u > 0, bit 1 some u <= 0, bit 2 some v > 0, bit 3 some v <= 0 -- of this lane's four cells
@@ -315,15 +333,13 @@ WALK_HD void xwalk(Lds &L, int lane, double afc, double dfc) {
     T[2 * cell] = __builtin_fma(aa, d, MODE == 0 ? dfc * lap : __builtin_fma(dfc, lap, old));
   });
 }
-// y walk: lane = (component, column, half column); adds afc v dc/dy + dfc c_yy and writes the result.  `out` is the
-// slab (doubles); blk = the block this lane's strip lies in (quad[2 seg + (column >> 3)])
-// PRE: the x parts are read from L.T ahead of the arithmetic (eight more live values per lane)
+// y walk: lane = (component, column, half column); adds afc v dc/dy + dfc c_yy: the result replaces the x part in L.T
+// (flush() takes it to memory).  PRE: the x parts are read ahead of the arithmetic (eight more live values per lane)
 template <bool DOP, bool DOM, bool PRE>
-WALK_HD void ywalk(Lds &L, int lane, double afc, double dfc, double *__restrict__ out, int blk) {
+WALK_HD void ywalk(Lds &L, int lane, double afc, double dfc) {
   const int comp = lane & 1, col = (lane >> 1) & 15, seg = lane >> 5;
   const double *lab = reinterpret_cast<const double *>(&L.lab[(8 * seg + 3) * LS + col + 3]);
-  const double *T = reinterpret_cast<const double *>(&L.T[8 * seg * TSTR + col]) + comp;
-  double *o = out + ((size_t)blk * 64 + (col & 7)) * 2 + comp;
+  double *T = reinterpret_cast<double *>(&L.T[8 * seg * TSTR + col]) + comp;
   double tx[8];
   if (PRE) {
 #pragma unroll
@@ -331,7 +347,7 @@ WALK_HD void ywalk(Lds &L, int lane, double afc, double dfc, double *__restrict_
   }
   walk_strip<DOP, DOM, LS>(lab + comp, lab + 1, [&](int cell, double d, double lap, double, double adv) {
     const double aa = afc * adv;
-    o[16 * cell] = __builtin_fma(aa, d, __builtin_fma(dfc, lap, PRE ? tx[cell] : T[2 * TSTR * cell]));
+    T[2 * TSTR * cell] = __builtin_fma(aa, d, __builtin_fma(dfc, lap, PRE ? tx[cell] : T[2 * TSTR * cell]));
   });
 }
 

@@ -22,7 +22,8 @@ static void run_quad(const V2 *vel, const V2 *vold, double *out, const int *q, d
   }
   int signs = 0;
   for (int lane = 0; lane < 64; lane++) {
-    stage<NEED_OLD>(R[lane], L, lane, gp[lane]);
+    stage_lab(R[lane], L, lane, gp[lane]);
+    if (NEED_OLD) stage_old(R[lane], L, lane);
     signs |= lane_signs(R[lane]);
   }
   const bool nPx = signs & 1, nMx = signs & 2, nPy = signs & 4, nMy = signs & 8;
@@ -32,11 +33,11 @@ static void run_quad(const V2 *vel, const V2 *vold, double *out, const int *q, d
     else xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
   }
   for (int lane = 0; lane < 64; lane++) {
-    const int blk = q[2 * (lane >> 5) + ((lane >> 4) & 1)];
-    if (!nMy) ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc, out, blk);
-    else if (!nPy) ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
-    else ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc, out, blk);
+    if (!nMy) ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc);
+    else if (!nPy) ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc);
+    else ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc);
   }
+  for (int lane = 0; lane < 64; lane++) flush(L, lane, (V2 *)out, q[0], q[1], q[2], q[3]);
 }
 
 extern "C" {

@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
       if (OP == 2) x[i] = x[i] + b;
       if (OP == 3) x[i] = __builtin_amdgcn_rcp(x[i]);
       if (OP == 4) { x[i] = __builtin_fma(x[i], a, b); asm volatile("v_mov_b32 %0, %0" : "+v"(it)); }
+      if (OP == 5) x[i] = (double)__builtin_amdgcn_rcpf((float)x[i]);                 // cvt + rcp_f32 + cvt: 3 instructions
+      if (OP == 6) x[i] = (double)((float)x[i] + 1.0f);                               // cvt + add_f32 + cvt
+      if (OP == 7) {                                                                    // 16 fma + 1 rcp_f64 (the WENO mix)
+        x[i] = __builtin_amdgcn_rcp(x[i]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[i] = __builtin_fma(x[i], a, b);
+      }
+      if (OP == 8) {                                                                    // 16 fma + (cvt, rcp_f32, cvt)
+        x[i] = (double)__builtin_amdgcn_rcpf((float)x[i]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[i] = __builtin_fma(x[i], a, b);
+      }
     }
   }
   double s = 0;
@@ -75,12 +87,16 @@ static void rcp_accuracy() {
 
 int main() {
   rcp_accuracy();
-  for (int wgs : {1024, 2048, 4096}) {
+  for (int wgs : {2048}) {
     run<0>("fma_f64", wgs);
     run<1>("mul_f64", wgs);
     run<2>("add_f64", wgs);
     run<3>("rcp_f64", wgs);
     run<4>("fma+mov", wgs);
+    run<5>("cvt,rcp32,cvt (x3)", wgs);
+    run<6>("cvt,add32,cvt (x3)", wgs);
+    run<7>("16fma+rcp64 (x17)", wgs);
+    run<8>("16fma+3 (x19)", wgs);
   }
   return 0;
 }

@@ -471,6 +471,12 @@ def main():
         sec = t["ms_total"] / t["launches"] * 1e-3
         gbs = ALGO_BYTES[fam] * cells_rank / sec / 1e9
         tr = traffic_tab.get(KERNEL_OF[fam], {}).get("hbm_bytes") if (nx, ny) == (4096, 4096) and world == 1 else None
+        if fam == "advect_stage" and walk and (nx, ny) == (4096, 4096) and world == 1:
+            # the two RK stages are two instantiations; per launch of the family = their mean (one launch each per step)
+            both = [traffic_tab.get("k_advect_walk<1, %s>" % b, {}).get("hbm_bytes") for b in ("true", "false")]
+            if all(both):
+                tr = 0.5 * (both[0] + both[1])
+                traffic_src[KERNEL_OF[fam]] = traffic_src.get("k_advect_walk<1, true>")
         return {"kernel": KERNEL_OF[fam], "family": fam, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr,
                 "traffic_source": traffic_src.get(KERNEL_OF[fam]) if tr else None,

@@ -115,6 +115,14 @@ def run_gpu(rank, world, px, py, nbx, nby):
     sim.advect_diffuse_rk2(dt)
     ref, _ = O.rk2_advect_diffuse(vel, h, nu, dt)
     assert np.array_equal(sim.vel, ref[sl]), "rk2 mismatch on rank %d" % rank
+    # the same with the FAST policy (bench.py's): the quad kernel on the inner and the halo phase, ghost blocks as
+    # the surroundings of quads, leftovers on the per-block kernel -- round-off apart the same numbers
+    sim.set_math(False)
+    sim.vel = vel[sl]
+    sim.advect_diffuse_rk2(dt)
+    assert np.abs(sim.vel - ref[sl]).max() <= 1e-13 * np.abs(ref).max(), "FAST rk2 mismatch on rank %d" % rank
+    sim.set_math(True)
+    sim.vel = ref[sl]
     # Poisson rhs (halo-1 exchanges of vel and pold)
     rng = np.random.default_rng(5)
     pres = rng.uniform(-1, 1, (gny, gnx))

@@ -91,6 +91,25 @@ def test_rectangular_grid_and_walls(gpu_lib, oracle):
         assert np.array_equal(s.tmp, oracle.vorticity(vel, h))
 
 
+@pytest.mark.parametrize("nbx,nby,order", [(8, 6, "rowmajor"), (5, 3, "rowmajor"), (7, 7, "hilbert"), (2, 2, "hilbert"), (12, 4, "hilbert")])
+def test_fast_advect_on_quads_and_leftover_blocks(gpu_lib, oracle, nbx, nby, order):
+    """FAST policy = the quad kernel (csrc/advect_walk.h) on every 2 x 2 patch the plan finds + the per-block kernel on
+    the blocks without partners (odd block counts), any block order, walls on all sides: the oracle within the FAST
+    tolerance, functor and both RK2 stages"""
+    nx, ny = 8 * nbx, 8 * nby
+    vel = oracle.taylor_green(nx, noise=0.3, seed=nbx * nby, ny=ny)
+    h, nu = 1.0 / max(nx, ny), 1e-3
+    dt = oracle.compute_dt(h, nu, 0.5, np.abs(vel).max())
+    ref = oracle.advect_diffuse_rhs(vel, h, nu, dt)
+    ref2, _ = oracle.rk2_advect_diffuse(vel, h, nu, dt)
+    with make_sim(nx, nu, order, strict=False, ny=ny) as s:
+        s.vel = vel
+        s.advect_diffuse_rhs(dt)
+        assert np.abs(s.tmpV - ref).max() <= 2e-13 * np.abs(ref).max()
+        s.advect_diffuse_rk2(dt)
+        assert np.abs(s.vel - ref2).max() <= 1e-13 * np.abs(ref2).max()
+
+
 def test_block_pointer_upload_matches_slab(gpu_lib, oracle):
     n = 32
     vel = oracle.taylor_green(n, noise=0.1, seed=2)

@@ -180,9 +180,14 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
       turn = turn == 2 ? 0 : turn + 1;
     }
     walk::stage_lab(R, L, lane, gp);
-    const int sg = walk::lane_signs(R);
-    const bool nPx = __ballot(sg & 1) != 0ull, nMx = __ballot(sg & 2) != 0ull;
-    const bool nPy = __ballot(sg & 4) != 0ull, nMy = __ballot(sg & 8) != 0ull;
+    // which upwind sides anybody in the tile asks for: eight compares whose results are lane masks, combined in scalar registers
+    unsigned long long anyu = 0, allu = ~0ull, anyv = 0, allv = ~0ull;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const unsigned long long mu = __ballot(R.own[p][0] > 0), mv = __ballot(R.own[p][1] > 0);
+      anyu |= mu, allu &= mu, anyv |= mv, allv &= mv;
+    }
+    const bool nPx = anyu != 0ull, nMx = allu != ~0ull, nPy = anyv != 0ull, nMy = allv != ~0ull;
     const int cb0 = E.b0, cb1 = E.b1, cb2 = E.b2, cb3 = E.b3;
     // the next quad of this wave (its last one is simply fetched twice)
     g += gr.stride;

@@ -194,15 +194,16 @@ template <bool NEED_OLD>
 WALK_HD void fetch(Regs &R, const V2 *__restrict__ f, const V2 *__restrict__ vold, int b0, int b1, int b2, int b3, int n0,
                    int n1, int n2, int n3, int n4, int n5, int n6, int n7, int lane, const int (&gp)[3]) {
   const int b[4] = {b0, b1, b2, b3};
-  // addresses as (wave-uniform base) + (32-bit byte offset per lane): the loads take the base from scalar registers and
-  // no 64-bit vector arithmetic is spent on them (launch_advect sends slabs of 4 GiB and more to the per-block kernel)
+  // addresses as (slab base) + (32-bit byte offset per lane): the loads take the base from scalar registers and one
+  // 32-bit add per load is all the vector arithmetic spent on them (launch_advect sends slabs of 4 GiB and more to the
+  // per-block kernel)
   const char *fb = reinterpret_cast<const char *>(f);
   const unsigned lane16 = (unsigned)lane << 4;
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    const size_t blk_bytes = (size_t)b[p] << 10;
-    R.own[p] = *reinterpret_cast<const V2 *>(fb + blk_bytes + lane16);
-    if (NEED_OLD) R.old[p] = load_v2(reinterpret_cast<const V2 *>(reinterpret_cast<const char *>(vold) + blk_bytes + lane16), WALK_NT & 1);
+    const unsigned off = ((unsigned)b[p] << 10) + lane16;
+    R.own[p] = *reinterpret_cast<const V2 *>(fb + off);
+    if (NEED_OLD) R.old[p] = load_v2(reinterpret_cast<const V2 *>(reinterpret_cast<const char *>(vold) + off), WALK_NT & 1);
   }
   // ghost cell 64 i + lane lies in slot (64 i + lane) / 24
   R.nb[0] = lane < 24 ? n0 : lane < 48 ? n1 : n2;
@@ -252,7 +253,10 @@ WALK_HD void flush(const Lds &L, int lane, V2 *__restrict__ out, int b0, int b1,
   const int ix = lane & 7, iy = lane >> 3;
   const int b[4] = {b0, b1, b2, b3};
 #pragma unroll
-  for (int p = 0; p < 4; p++) store_v2(&out[(size_t)b[p] * 64 + lane], L.T[(8 * (p >> 1) + iy) * TSTR + 8 * (p & 1) + ix], WALK_NT & 2);
+  for (int p = 0; p < 4; p++) {
+    const unsigned off = ((unsigned)b[p] << 10) + ((unsigned)lane << 4);
+    store_v2(reinterpret_cast<V2 *>(reinterpret_cast<char *>(out) + off), L.T[(8 * (p >> 1) + iy) * TSTR + 8 * (p & 1) + ix], WALK_NT & 2);
+  }
 }
 // which upwind sides anybody in the tile asks for (main.cpp:5493-5496: x derivatives follow u > 0, y derivatives
 // v > 0): bit 0 some u > 0, bit 1 some u <= 0, bit 2 some v > 0, bit 3 some v <= 0 -- of this lane's four cells

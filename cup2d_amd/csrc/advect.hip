@@ -212,9 +212,9 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
     else if (!nPx) walk::xwalk<false, true, MODE, OLDLAB>(L, lane, afc, dfc);
     else walk::xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
     wave_lds_sync();
-    if (!nMy) walk::ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc);
-    else if (!nPy) walk::ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc);
-    else walk::ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc);
+    if (!nMy) walk::ywalk<true, false, true>(L, lane, afc, dfc);
+    else if (!nPy) walk::ywalk<false, true, true>(L, lane, afc, dfc);
+    else walk::ywalk<true, true, true>(L, lane, afc, dfc);
     wave_lds_sync();  // the tile is overwritten by the next quad; its results stay in L.T
     pb0 = cb0, pb1 = cb1, pb2 = cb2, pb3 = cb3;
     pending = true;

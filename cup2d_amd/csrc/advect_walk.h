@@ -351,10 +351,13 @@ WALK_HD void xwalk(Lds &L, int lane, double afc, double dfc) {
   const int comp = lane & 1, row = (lane >> 1) & 15, seg = lane >> 5;
   const double *lab = reinterpret_cast<const double *>(&L.lab[(row + 3) * LS + 8 * seg + 3]);
   double *T = reinterpret_cast<double *>(&L.T[row * TSTR + 8 * seg]) + comp;
-  // (the old values of RK stage 2 are read where they are used: this variant also holds them in flight for the next
-  // quad, and eight more registers per lane spill)
+  double told[8];
+  if (MODE == 1 && !OLDLAB) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) told[i] = T[2 * i];
+  }
   walk_strip<DOP, DOM, 1>(lab + comp, lab, [&](int cell, double d, double lap, double centre, double adv) {
-    const double old = MODE == 0 ? 0.0 : (OLDLAB ? centre : T[2 * cell]);
+    const double old = MODE == 0 ? 0.0 : (OLDLAB ? centre : told[cell]);
     const double aa = afc * adv;
     T[2 * cell] = __builtin_fma(aa, d, MODE == 0 ? dfc * lap : __builtin_fma(dfc, lap, old));
   });

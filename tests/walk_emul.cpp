@@ -33,9 +33,9 @@ static void run_quad(const V2 *vel, const V2 *vold, double *out, const int *q, d
     else xwalk<true, true, MODE, OLDLAB>(L, lane, afc, dfc);
   }
   for (int lane = 0; lane < 64; lane++) {
-    if (!nMy) ywalk<true, false, !NEED_OLD>(L, lane, afc, dfc);
-    else if (!nPy) ywalk<false, true, !NEED_OLD>(L, lane, afc, dfc);
-    else ywalk<true, true, !NEED_OLD>(L, lane, afc, dfc);
+    if (!nMy) ywalk<true, false, true>(L, lane, afc, dfc);
+    else if (!nPy) ywalk<false, true, true>(L, lane, afc, dfc);
+    else ywalk<true, true, true>(L, lane, afc, dfc);
   }
   for (int lane = 0; lane < 64; lane++) flush(L, lane, (V2 *)out, q[0], q[1], q[2], q[3]);
 }

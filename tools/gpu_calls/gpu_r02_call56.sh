@@ -5,7 +5,7 @@ OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 V=$PWD/cup2d_amd/variants
 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "advect or rectangular or step_matches or functors_vs_golden or consecutive" 2>&1 | tail -2
 for round in 1 2 3; do
-  for lib in default v4; do
+  for lib in default v5; do
     if [ $lib = default ]; then unset CUP2D_LIB; else export CUP2D_LIB=$V/libcup2d_hip_walk_$lib.so; fi
     timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-amr --no-verify 2>/dev/null | python -c "
 import json,sys

@@ -58,6 +58,7 @@ struct KrylovScalars {
   int x_is_best;     // the iterate held in x is the best so far (cuda.cu:535-538)
   int ycur, ybest;   // fused solver: which of its three y buffers holds the current / the best iterate
   int best_is_x0;    // fused solver: no iterate has beaten the initial guess yet (y_best = 0: its buffer is never written or read)
+  double omega_r;    // the omega sweep E formed r = s - omega t with (a restart resets omega, not this): stored-edge ring
 };
 
 struct HaloPlan {
@@ -154,6 +155,7 @@ struct cup2d_ctx {
   // tile-fused solver (krylov_fused.hip): ping-pong copies of p and nu, s = r - alpha nu, and the
   // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
   double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
+  double *d_edge[8] = {nullptr};  // stored-edge ring (krylov_fused.hip): z, P_inv nu, z2, P_inv t on block edges, two buffers each
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
   int last_solver = 0;       // what the last solve ran
   int finish_in_kernel = 1;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)

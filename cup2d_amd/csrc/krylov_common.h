@@ -49,6 +49,7 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
     break;
   case 2:
     sc->omega = red[0] / (red[1] + sc->eps);
+    sc->omega_r = sc->omega;
     break;
   case 3:
     sc->iter++;

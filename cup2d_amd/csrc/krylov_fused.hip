@@ -153,6 +153,12 @@ struct FusedArgs {
   const double *in0, *in1, *in2;  // AB: p, nu, r     CD: r, nu, -
   double *w;                      // AB: rhat (written on a restart)
   double *vout, *yout;            // AB: p', nu'      CD: s, t
+  // stored-edge ring (RE > 0), arrays of [block][side W,E,S,N][8] doubles:
+  //   AB reads  e0 = z edges of the p it reads, e1 = (P_inv nu) edges, e2 = z2 edges, e3 = (P_inv t) edges of the last CD
+  //      writes o0 = z' edges, o1 = (P_inv nu') edges
+  //   CD reads  e1 = (P_inv nu') edges AB has just written, e2, e3 as AB;  writes o0 = z2' edges, o1 = (P_inv t') edges
+  const double *e0, *e1, *e2, *e3;
+  double *o0, *o1;
 };
 
 // one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)
@@ -195,7 +201,13 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
 // ones those rows read).  Ring entries work as ever: the neighbour of a plain block is a block with p, nu, r in memory.
 // EDGES: neighbour ids >= nowned are ghost blocks whose z edges the owner rank computed (k_fused_edges; N ranks,
 // CUP2D_FUSED_GHOST=edges) -- compiled out otherwise: the path costs the one-rank kernel six spilled registers
-template <int MODE, int MERGE, bool HYB = false, bool EDGES = false>
+// RE (stored-edge ring, DESIGN.md 8a -> 4.5): P_inv is linear, so the z edge of a block outside the tile is a combination
+// of edges its OWNER had on the chip one launch earlier -- z' = beta (z - omega P_inv nu) + P_inv r with
+// P_inv r = z2 - omega_r P_inv t (sweep E's r = s - omega_r t) in AB, z2' = P_inv r - alpha P_inv nu' in CD.  RE >= 1: the
+// owner stores the edges of its tile-boundary sides (z after the tile job; P_inv y after one more 64-MFMA job on the
+// tile's y).  RE == 2: the ring entries are filled from those arrays (4 | 3 64-byte reads per entry) instead of whole
+// neighbour blocks (12 | 8 x 128 bytes) + a staging + MFMA job.  The first iteration of a solve runs RE = 1.
+template <int MODE, int MERGE, bool HYB = false, bool EDGES = false, int RE = 0>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                   int first, int count, int poff, int nowned,
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     T.is_ring = si < T.nvalid && nb >= 0 && nb < nowned && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (dbg & 1) ? 0 : __popcll(rmask);  // dbg 1: timing experiment without the ring -- WRONG results
-    T.npass = (T.nring + TB - 1) / TB;
+    T.npass = RE == 2 ? 0 : (T.nring + TB - 1) / TB;  // RE 2: no ring JOBS, the ring list feeds ring_from_edges
     T.gen = HYB && __ballot(si < T.nvalid && nb == FUSED_GENERAL) != 0ull;
     T.zm = HYB ? uniform(zmask[t]) : 0;
     if (T.is_ring) {
@@ -342,10 +354,42 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
   };
 
+  // RE 2: the ring from stored edges.  State of the tile whose edges are in flight: values, ghost-edge slot, (block, side)
+  double redge[2][4];
+  int rdst[2] = {-1, -1}, rslot[2] = {-1, -1};
+  const double momega_r = RE == 2 ? -sc->omega_r : 0.0;
+  const auto ring_value = [&](const double (&e)[4]) -> double {
+    const double re = e[2] + momega_r * e[3];  // P_inv r on the edge
+    if (MODE == 0) {
+      if (restart) return re;
+      double v = e[0] + c1 * e[1];
+      v = v * beta;
+      return v + re;
+    }
+    return re + c1 * e[1];
+  };
+  // the first 16 entries of tile X's ring list (in LDS now): 8 lanes per entry read its 8 doubles of every edge array
+  const auto fetch_ring = [&](const Tile &X) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
+      const bool on = e < X.nring;
+      const int ee = on ? e : 0;
+      const int dst = L.ring_dst[ee];
+      const size_t at = X.nring > 0 ? ((size_t)L.ring_nb[ee] * 4 + ((dst & 3) ^ 1)) * BS + q : 0;
+      if (MODE == 0) redge[h][0] = A.e0[at];
+      redge[h][1] = A.e1[at];
+      redge[h][2] = A.e2[at];
+      redge[h][3] = A.e3[at];
+      rdst[h] = on ? dst * GS + q : -1;
+      rslot[h] = on ? dst : -1;
+    }
+  };
   Raw Ra, Rb;
   Tile T;
   if (t_begin < t_end) {
     T = classify(t_begin, load_nb(t_begin));
+    if constexpr (RE == 2) fetch_ring(T);
     issue(Ra, T, 0, 0);
     if (DEEP) issue(Rb, T, 0, 1);
   }
@@ -357,6 +401,47 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = 0.0;
     }
+    // RE 2: the stored edges of this tile's first 16 ring entries were requested one tile ago (fetch_ring, issued in
+    // front of the tile's own loads: the memory counter is in order, and a value consumed between the prefetch of the next
+    // tile and its use would make the wave wait for that prefetch); they are combined and written to the ghost-edge
+    // slots here, before the tile job.  Entries beyond 16 (block orders other than the Hilbert one) are fetched and
+    // written at once -- the ring list is still this tile's.
+    int cslot[2] = {-1, -1};
+    if constexpr (RE == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        cslot[h] = rslot[h];
+        if (rdst[h] >= 0) L.GE[rdst[h]] = ring_value(redge[h]);
+      }
+      for (int j = 1; j * TB < T.nring; j++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int idx = lane + 64 * h, e = j * TB + (idx >> 3), q = idx & 7;
+          if (e < T.nring) {
+            const int dst = L.ring_dst[e];
+            const size_t at = ((size_t)L.ring_nb[e] * 4 + ((dst & 3) ^ 1)) * BS + q;
+            const double ev[4] = {MODE == 0 ? A.e0[at] : 0.0, A.e1[at], A.e2[at], A.e3[at]};
+            L.GE[dst * GS + q] = ring_value(ev);
+          }
+        }
+      }
+    }
+    // the edges of the tile-boundary sides of the staging tile -> arr.  With <= 16 such sides (every Hilbert tile) eight
+    // lanes write the eight doubles of one edge: full 64-byte lines; one lane per edge writes eight partial lines
+    const auto store_edges = [&](double *arr) {
+      if (RE == 2 && T.nring <= TB) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+          if (cslot[h] >= 0) {
+            const int d = cslot[h], q = lane & 7;
+            arr[((size_t)(b0 + (d >> 2)) * 4 + (d & 3)) * BS + q] = L.S[(d >> 2) * XS + edge_cell(d & 3, q)];
+          }
+      } else if (T.is_ring) {
+        double *dst = arr + ((size_t)(b0 + si) * 4 + ss) * BS;
+#pragma unroll
+        for (int q = 0; q < BS; q++) dst[q] = L.S[si * XS + edge_cell(ss, q)];
+      }
+    };
     // dot-product operand of the tile's cells in pair layout: s itself (CD); rhat (AB; r on a restart)
     double2 W[TB / 2];
     const auto stage = [&](const Raw &R, bool is_tile, int half) {
@@ -400,6 +485,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         // behind this tile's MFMA, edge fill and stencil
         N = classify(t + t_stride, nb_next);
         nb_next = load_nb(t + 2 * t_stride);
+        if constexpr (RE == 2) fetch_ring(N);
         issue(Ra, N, 0, 0);
         if (DEEP) issue(Rb, N, 0, 1);
       } else {
@@ -430,6 +516,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         wave_lds_sync();
       }
     }
+    if constexpr (RE >= 1) store_edges(A.o0);  // the z edges of the tile-boundary sides, for the neighbour tiles of the next launch
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
     if (HYB && T.gen) {  // rows with stored entries in this tile: k_hyb_rows applies them
@@ -472,7 +559,15 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           acc[1] = __builtin_fma(yv.x, yv.x, acc[1]);
           acc[1] = __builtin_fma(yv.y, yv.y, acc[1]);
         }
+        // RE: y takes z's place in the staging tile (every lane has read this block pair's z: one wave, in order; the
+        // blocks still to come read their own z and the ghost edges only)
+        if constexpr (RE >= 1) *reinterpret_cast<double2 *>(L.S + blk * XS + c0) = yv;
       }
+    }
+    if constexpr (RE >= 1) {  // P_inv y on the tile-boundary sides: one more job on the matrix cores
+      wave_lds_sync();
+      tile_precond(L.S, PL, PR, lane, false);
+      store_edges(A.o1);
     }
     wave_lds_sync();  // the next tile overwrites S and GE
     T = N;
@@ -668,7 +763,7 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
 template <int MODE>
-static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks) {
+static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks, int re = 0) {
   const int nb = c->nblocks;
   if (c->mat.active) {
     // hybrid assembled operator: the fused tiles in one launch; then the halo entries of z, then the rows of the general
@@ -746,6 +841,14 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
       if (mg == 1) go(k_fused<MODE, 1, false, true>);
       else if (mg == 2) go(k_fused<MODE, 2, false, true>);
       else go(k_fused<MODE, 0, false, true>);
+    } else if (re == 1) {  // stored-edge ring, first iteration of a solve: ring recomputed, edges stored
+      if (mg == 1) go(k_fused<MODE, 1, false, false, 1>);
+      else if (mg == 2) go(k_fused<MODE, 2, false, false, 1>);
+      else go(k_fused<MODE, 0, false, false, 1>);
+    } else if (re == 2) {
+      if (mg == 1) go(k_fused<MODE, 1, false, false, 2>);
+      else if (mg == 2) go(k_fused<MODE, 2, false, false, 2>);
+      else go(k_fused<MODE, 0, false, false, 2>);
     } else {
       if (mg == 1) go(k_fused<MODE, 1>);
       else if (mg == 2) go(k_fused<MODE, 2>);
@@ -772,7 +875,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const double *b = c->d_field[CUP2D_TMP];
   KrylovScalars init;
   ::memset(&init, 0, sizeof init);
-  init.alpha = init.beta = init.omega = init.rho_prev = init.rho_curr = 1.0;
+  init.alpha = init.beta = init.omega = init.omega_r = init.rho_prev = init.rho_curr = 1.0;
   init.eps = 1e-21;  // cuda.cu:409
   init.err = init.err_init = init.err_opt = 1e50;
   init.max_error = max_error; init.max_rel_error = max_rel_error;
@@ -796,7 +899,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>),
                         reinterpret_cast<const void *>(&k_fused<0, 0, false, true>), reinterpret_cast<const void *>(&k_fused<0, 1, false, true>),
                         reinterpret_cast<const void *>(&k_fused<0, 2, false, true>), reinterpret_cast<const void *>(&k_fused<1, 0, false, true>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, false, true>), reinterpret_cast<const void *>(&k_fused<1, 2, false, true>)};
+                        reinterpret_cast<const void *>(&k_fused<1, 1, false, true>), reinterpret_cast<const void *>(&k_fused<1, 2, false, true>),
+                        reinterpret_cast<const void *>(&k_fused<0, 0, false, false, 1>), reinterpret_cast<const void *>(&k_fused<0, 1, false, false, 1>),
+                        reinterpret_cast<const void *>(&k_fused<0, 2, false, false, 1>), reinterpret_cast<const void *>(&k_fused<1, 0, false, false, 1>),
+                        reinterpret_cast<const void *>(&k_fused<1, 1, false, false, 1>), reinterpret_cast<const void *>(&k_fused<1, 2, false, false, 1>),
+                        reinterpret_cast<const void *>(&k_fused<0, 0, false, false, 2>), reinterpret_cast<const void *>(&k_fused<0, 1, false, false, 2>),
+                        reinterpret_cast<const void *>(&k_fused<0, 2, false, false, 2>), reinterpret_cast<const void *>(&k_fused<1, 0, false, false, 2>),
+                        reinterpret_cast<const void *>(&k_fused<1, 1, false, false, 2>), reinterpret_cast<const void *>(&k_fused<1, 2, false, false, 2>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -815,6 +924,14 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   static const bool ghost_edges = [] { const char *e = getenv("CUP2D_FUSED_GHOST"); return e && !strcmp(e, "edges"); }();
   const bool gb = c->nghost > 0 && c->exchange && !ghost_edges && !c->mat.active;
   static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
+  // the ring of the sweeps from stored edges (k_fused RE): one rank, same-level stencil.  CUP2D_FUSED_RING=stored|blocks
+  static const bool ring_stored = [] { const char *e = getenv("CUP2D_FUSED_RING"); return e && !strcmp(e, "stored"); }();
+  const bool stored = ring_stored && !c->mat.active && !(c->nghost > 0 && c->exchange);
+  if (stored) {
+    const size_t ebytes = (size_t)c->ntotal * 4 * BS * sizeof(double);
+    for (double *&p : c->d_edge)
+      if (!p) CUP2D_HIP_CHECK(dev_malloc(&p, ebytes));
+  }
 
   int GP = 0;
   {
@@ -844,8 +961,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     double *nu_in = (k & 1) ? c->d_nu2 : c->d_nu, *nu_out = (k & 1) ? c->d_nu : c->d_nu2;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out};
-      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb));
+      const int o = k & 1, n = o ^ 1;  // edge buffers: z 0-1, P_inv nu 2-3, z2 4-5, P_inv t 6-7
+      const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out,
+                           c->d_edge[o], c->d_edge[2 + o], c->d_edge[4 + o], c->d_edge[6 + o], c->d_edge[n], c->d_edge[2 + n]};
+      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb, stored ? (k == 0 ? 1 : 2) : 0));
     }
     // CD needs the ghost nu', the next AB the ghost p': one message, in flight behind the reduction
     if (gb) CUP2D_TRY(exchange_begin_blocks2(c, nu_out, p_out));
@@ -854,8 +973,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (gb) CUP2D_TRY(exchange_end_blocks2(c, nu_out, p_out));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
-      const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t};
-      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb));
+      const int o = k & 1, n = o ^ 1;
+      const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t,
+                           nullptr, c->d_edge[2 + n], c->d_edge[4 + o], c->d_edge[6 + o], c->d_edge[4 + n], c->d_edge[6 + n]};
+      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb, stored ? (k == 0 ? 1 : 2) : 0));
     }
     if (merge == 0) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 0, 2));

@@ -128,3 +128,18 @@ def test_fused_full_steps_vs_reference_time_loop(gpu_lib, oracle):
             assert abs(r["dt"] - G["dts"][k]) < 1e-12 * r["dt"]
         assert np.abs(s.vel - G["vel"]).max() < 1e-10
         assert np.abs(s.pres - G["pres"]).max() < 1e-8
+
+
+def test_ring_from_stored_edges_matches_the_five_sweeps(gpu_lib):
+    """CUP2D_FUSED_RING=stored (k_fused RE = 1 / 2, opt-in): the z edges of blocks outside a tile come from edge arrays their
+    owners stored one launch earlier (linearity of P_inv) instead of whole-block re-reads + a staging + MFMA job.  The mode
+    is read when the library is loaded, so the check runs in its own process (tools/gpu_ring_check.py): six iterations at
+    zero tolerance equal the five sweeps to round-off, converged solves satisfy the criterion recomputed from the fields,
+    on Hilbert and row-major orders (more than 16 ring entries per tile), partial tiles, a single block, with a restart."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUP2D_FUSED_RING="stored")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_ring_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ring=stored: ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

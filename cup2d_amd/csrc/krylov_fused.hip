@@ -126,6 +126,17 @@ static __device__ __forceinline__ int edge_cell(int s, int q) {
 // registers they cost every wave 128 VGPRs -- the first version of this kernel had nothing left to keep
 // loads in flight with (2 waves per SIMD, 234 VGPRs) and ran latency-bound at 3.3 TB/s.  Same k order and
 // operands as precond_tile, so z is bit-identical to the unfused MFMA preconditioner.
+// CUP2D_FUSED_MFMA_PRIO: the two waves of a SIMD share its matrix core; per-phase clocks (-DFUSED_PHASES) show 5.2-6.5 k
+// cycles per 64-MFMA job against 2 k of MFMA issue -- the jobs of the two waves run interleaved at half rate each, and half
+// of a CD tile's time goes into its two jobs.  With the priority raised for the duration of a job the first wave to arrive
+// finishes at the full rate and the two waves drift apart: one wave's job then runs beside the other's loads and staging.
+// Measured at 4096^2: AB 162.4 -> 163.3 us, CD 121.6 -> 123.8 us -- nothing: the matrix core itself is the limit (a
+// v_mfma_f64_16x16x4_f64 takes 64 cycles on this part, tools/fp64_peak.hip; two waves x two jobs x 64 MFMAs = 16 k cycles of
+// a 23.5 k-cycle CD tile).  Off.
+#ifndef CUP2D_FUSED_MFMA_PRIO
+#define CUP2D_FUSED_MFMA_PRIO 0
+#endif
+template <bool DB = false>
 static __device__ __forceinline__ void tile_precond(double *S, const double *PL, const PinvFragments &PR, int lane, bool skip) {
   double xa[16];
   const int ablk = lane & 15, akk = lane >> 4;
@@ -135,11 +146,39 @@ static __device__ __forceinline__ void tile_precond(double *S, const double *PL,
 #pragma unroll
   for (int nt = 0; nt < 4; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
   if (!skip) {
+#if CUP2D_FUSED_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(1);  // the job of the wave that gets here first runs at the full MFMA rate (below)
+#endif
+    if constexpr (PREG || !DB) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ks++)
+      for (int ks = 0; ks < 16; ks++)
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++)
-        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PREG ? PR.b[ks][nt] : PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; nt++)
+          acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PREG ? PR.b[ks][nt] : PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+    } else {
+      // The B fragments of k-step ks + 1 are requested BEFORE the four MFMAs of k-step ks (two register sets, the order
+      // pinned with scheduling barriers).  Left to the scheduler every k-step read its fragments right in front of its
+      // MFMAs and waited out the LDS latency: per-phase clocks (-DFUSED_PHASES) show 5.2-6.5 k cycles per 64-MFMA job
+      // against 2 k of MFMA issue -- half of a CD tile's time is spent in the two jobs.
+      double bf[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) bf[0][nt] = PL[nt * 64 + lane];
+#pragma unroll
+      for (int ks = 0; ks < 16; ks++) {
+        if (ks + 1 < 16) {
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) bf[(ks + 1) & 1][nt] = PL[((ks + 1) * 4 + nt) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], bf[ks & 1][nt], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#if CUP2D_FUSED_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
   wave_lds_sync();  // every lane has read its operands before the tile is overwritten
 #pragma unroll
@@ -149,6 +188,13 @@ static __device__ __forceinline__ void tile_precond(double *S, const double *PL,
   wave_lds_sync();
 }
 
+// -DFUSED_PHASES (timing aid, tools/gpu_fused_phases.sh): every wave adds up the shader-clock cycles it spends in the
+// phases of a tile; waves 0 of the first workgroups print their sums for iteration 5
+#ifdef FUSED_PHASES
+#define PH(k) { const long long now_ = clock64(); ph[k] += now_ - tprev; tprev = now_; }
+#else
+#define PH(k) {}
+#endif
 struct FusedArgs {
   const double *in0, *in1, *in2;  // AB: p, nu, r     CD: r, nu, -
   double *w;                      // AB: rhat (written on a restart)
@@ -218,6 +264,13 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   if (sc->status != 0) return;
   constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
+  // double-buffered B fragments in the MFMA jobs (tile_precond): bit MODE of CUP2D_FUSED_DB.  Measured at 4096^2: CD
+  // 121.0 -> 122.8 / 120.3 us, AB (which spills under the eight registers more) 163 -> 168 us: the 64-MFMA job is not
+  // waiting for its fragments.  Off.
+#ifndef CUP2D_FUSED_DB
+#define CUP2D_FUSED_DB 0
+#endif
+  constexpr bool PRECOND_DB = ((CUP2D_FUSED_DB >> MODE) & 1) != 0;
   double *PL = fsm;
   PinvFragments PR;
   if constexpr (PREG) {
@@ -394,9 +447,16 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     if (DEEP) issue(Rb, T, 0, 1);
   }
   int nb_next = load_nb(t_begin + t_stride);
+#ifdef FUSED_PHASES
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+  int ntile = 0;
+#endif
   for (int t = t_begin; t < t_end; t += t_stride) {
     // invariant: T describes tile t, its ring list is in LDS, the first batch of its first job is in flight in Ra
     const int b0 = T.b0, nvalid = T.nvalid;
+#ifdef FUSED_PHASES
+    ntile++;
+#endif
     if (dbg & 1) {
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = 0.0;
@@ -480,6 +540,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         }
       }
       if (!DEEP) stage(Rb, is_tile, 1);
+      if (is_tile) PH(2) else PH(0)
       if (is_tile && t + t_stride < t_end) {
         // this tile's ring list is dead: classify the NEXT tile into it and put its first job in flight
         // behind this tile's MFMA, edge fill and stencil
@@ -491,7 +552,9 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       } else {
         wave_lds_sync();
       }
-      tile_precond(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      if (is_tile) PH(3)
+      tile_precond<PRECOND_DB>(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      if (is_tile) PH(4)
       if constexpr (HYB) {
         if (is_tile && T.zm != 0) {  // z of the blocks somebody reads from memory
 #pragma unroll
@@ -514,6 +577,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           }
         }
         wave_lds_sync();
+        PH(1)
       }
     }
     if constexpr (RE >= 1) store_edges(A.o0);  // the z edges of the tile-boundary sides, for the neighbour tiles of the next launch
@@ -536,6 +600,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       }
     }
     wave_lds_sync();
+    PH(5)
     // ---- y = A z (operand order of k_sweepBD / pressure_rhs1 main.cpp:6228) + the fused dot products: two cells per
     //      lane, eight block pairs ----
 #pragma unroll
@@ -566,12 +631,19 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
     if constexpr (RE >= 1) {  // P_inv y on the tile-boundary sides: one more job on the matrix cores
       wave_lds_sync();
-      tile_precond(L.S, PL, PR, lane, false);
+      tile_precond<PRECOND_DB>(L.S, PL, PR, lane, false);
       store_edges(A.o1);
     }
     wave_lds_sync();  // the next tile overwrites S and GE
+    PH(6)
     T = N;
   }
+#ifdef FUSED_PHASES
+  if (sc->iter == 5 && lane == 0 && blockIdx.x < 2 && (wave == 0 || wave == 5) && ntile > 0)
+    printf("PHASES mode %d re %d wg %d wave %d tiles %d cycles/tile: ring stage+wait %lld  ring mfma+edges %lld  tile stage+wait %lld  classify+issue %lld  "
+           "tile mfma %lld  edges %lld  stencil+stores(+2nd job) %lld\n", MODE, RE, (int)blockIdx.x, wave, ntile, ph[0] / ntile, ph[1] / ntile,
+           ph[2] / ntile, ph[3] / ntile, ph[4] / ntile, ph[5] / ntile, ph[6] / ntile);
+#endif
   // MERGE 1: the last workgroup finishes the reduction and runs the scalar update (one GPU).  MERGE 2: it only sums
   // this rank's partials -- those of an earlier launch of the same sweep included, poff of them -- into red; the
   // all-reduce and the scalar update follow on the stream (N GPUs).

@@ -85,8 +85,46 @@ static void rcp_accuracy() {
   hipFree(d);
 }
 
+// issue rate of v_mfma_f64_16x16x4_f64 (the block-Jacobi jobs of the fused sweeps): four independent accumulators per wave
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a) {
+  v4d acc[4];
+  for (int i = 0; i < 4; i++) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const double x = a + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i], 0, 0, 0);
+  }
+  double s = 0;
+  for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+static void mfma_rate(int wgs, int waves_per_simd) {
+  double *d;
+  hipMalloc(&d, 8);
+  const int iters = 4096;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k_mfma<<<wgs, 256>>>(d, 16, 1.0000001);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k_mfma<<<wgs, 256>>>(d, iters, 1.0000001);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double mfma_per_simd = (double)wgs * 4 * iters * 4 / 1024.0;  // wave-MFMAs per SIMD (256 CUs x 4)
+  printf("mfma_f64_16x16x4  wgs=%5d (%d waves/SIMD)  %.3f ms  %.1f cycles per MFMA per SIMD @2.4GHz  %.2f TFLOP/s\n", wgs, waves_per_simd, ms,
+         ms * 1e-3 * 2.4e9 / mfma_per_simd, (double)wgs * 4 * iters * 4 * 2048.0 / (ms * 1e-3) / 1e12);
+  hipFree(d);
+}
+
 int main() {
   rcp_accuracy();
+  mfma_rate(256, 1);
+  mfma_rate(512, 2);
+  mfma_rate(1024, 4);
   for (int wgs : {2048}) {
     run<0>("fma_f64", wgs);
     run<1>("mul_f64", wgs);

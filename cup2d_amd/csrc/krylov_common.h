@@ -114,11 +114,14 @@ static __device__ __forceinline__ double sell_row(const double *__restrict__ x, 
 // so the result does not depend on which workgroup runs it.  fused_stage >= 0: also runs the scalar
 // update of that stage.  COHERENT: read the partials with agent-scope loads (the caller is a workgroup of
 // the SAME launch that produced them, see arrive_last).
-template <bool COHERENT>
+// EXT: the 3 x WG doubles of scratch are the caller's (k_fused: its dynamic LDS is dead by then and the launch has no
+// 6 KB of static LDS to spare next to 158 KB of tiles and fragments).
+template <bool COHERENT, bool EXT = false>
 static __device__ __forceinline__ void finish_reduce(const double *partials, int G, int nsum, int with_max,
                                                      double *red, KrylovScalars *sc, int fused_stage,
-                                                     int *host_status) {
-  __shared__ double sm[3][WG];
+                                                     int *host_status, double *ext = nullptr) {
+  __shared__ double sm_own[EXT ? 1 : 3][EXT ? 1 : WG];
+  double (*sm)[WG] = EXT ? reinterpret_cast<double (*)[WG]>(ext) : reinterpret_cast<double (*)[WG]>(&sm_own[0][0]);
   const auto ld = [&](const double *p) -> double {
     if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;

@@ -113,7 +113,15 @@ struct alignas(16) FusedLds {
   int ring_nb[TB * 4];     // neighbour block of ring entry e ...
   int ring_dst[TB * 4];    // ... and the slot (block * 4 + side) it feeds
 };
-constexpr int PL_LDS_DOUBLES = PREG ? 0 : PL_DOUBLES;
+// The RING job needs one edge (8 cells) of z per entry, not the block: it multiplies with the 32 columns of P_inv that
+// produce edge cells -- [W | E] and [S | N], two 16-column tiles instead of four -- and is half a job.  The FP64 matrix
+// core is what bounds these sweeps (64 cycles per v_mfma_f64_16x16x4_f64); same k order, same numbers.
+#ifndef CUP2D_FUSED_EDGEOP
+#define CUP2D_FUSED_EDGEOP 1
+#endif
+constexpr bool EDGEOP = CUP2D_FUSED_EDGEOP != 0 && !PREG;
+constexpr int PE_DOUBLES = EDGEOP ? 16 * 2 * 64 : 0;  // the edge columns as B fragments: [k-step][n-tile][lane]
+constexpr int PL_LDS_DOUBLES = (PREG ? 0 : PL_DOUBLES) + PE_DOUBLES;
 constexpr size_t FUSED_LDS_BYTES = PL_LDS_DOUBLES * sizeof(double) + FWAVES * sizeof(FusedLds);
 
 // cell (iy*8+ix) at position q of the edge on side s (W, E, S, N) of a block
@@ -185,6 +193,31 @@ static __device__ __forceinline__ void tile_precond(double *S, const double *PL,
   for (int v = 0; v < 4; v++)
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) S[(akk + 4 * v) * XS + 16 * nt + ablk] = acc[nt][v];
+  wave_lds_sync();
+}
+
+// the ring job's product: S (v of 16 ring entries, block-major) -> S[e][8 side + q] = z of entry e on the edge cells of side
+// W, E, S, N.  PE = the 32 edge columns of P_inv as B fragments.
+static __device__ __forceinline__ void ring_precond(double *S, const double *PE, int lane, bool skip) {
+  double xa[16];
+  const int ablk = lane & 15, akk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
+  v4f64 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (!skip) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PE[(ks * 2 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+  }
+  wave_lds_sync();  // every lane has read its operands before the tile is overwritten
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) S[(akk + 4 * v) * XS + 16 * nt + ablk] = acc[nt][v];
   wave_lds_sync();
 }
 
@@ -279,6 +312,12 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     for (int idx = threadIdx.x; idx < PL_DOUBLES; idx += FWG) {
       const int l = idx & 63, nt = (idx >> 6) & 3, ks = idx >> 8;
       PL[idx] = Pinv[(4 * ks + (l >> 4)) * BC + 16 * nt + (l & 15)];
+    }
+    if constexpr (EDGEOP) {
+      for (int idx = threadIdx.x; idx < PE_DOUBLES; idx += FWG) {
+        const int l = idx & 63, nt = (idx >> 6) & 1, ks = idx >> 7, col = 16 * nt + (l & 15);
+        PL[PL_DOUBLES + idx] = Pinv[(4 * ks + (l >> 4)) * BC + edge_cell(col >> 3, col & 7)];
+      }
     }
     __syncthreads();
   }
@@ -553,7 +592,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         wave_lds_sync();
       }
       if (is_tile) PH(3)
-      tile_precond<PRECOND_DB>(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
+      if (EDGEOP && !is_tile) ring_precond(L.S, PL + PL_DOUBLES, lane, (dbg & 2) != 0);
+      else tile_precond<PRECOND_DB>(L.S, PL, PR, lane, (dbg & (is_tile ? 4 : 2)) != 0);
       if (is_tile) PH(4)
       if constexpr (HYB) {
         if (is_tile && T.zm != 0) {  // z of the blocks somebody reads from memory
@@ -573,7 +613,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
           if (e < ne) {
             const int dst = L.ring_dst[j * TB + e];
-            L.GE[dst * GS + q] = L.S[e * XS + edge_cell((dst & 3) ^ 1, q)];
+            L.GE[dst * GS + q] = L.S[e * XS + (EDGEOP ? 8 * ((dst & 3) ^ 1) + q : edge_cell((dst & 3) ^ 1, q))];
           }
         }
         wave_lds_sync();
@@ -648,8 +688,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   // this rank's partials -- those of an earlier launch of the same sweep included, poff of them -- into red; the
   // all-reduce and the scalar update follow on the stream (N GPUs).
   fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
-  if (MERGE && arrive_last(ticket))
-    finish_reduce<true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr);
+  if (MERGE && arrive_last(ticket))  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
+    finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
 }
 
 // ---- z on the faces other ranks need (multi-GPU) ---------------------------------------------------

@@ -5,13 +5,14 @@
 // (4 own centres + the block's rim) although consecutive centres of a grid line share four of their five inputs.
 // Here a LANE owns one component on a STRIP of 8 cells of one grid line and visits the strip's centres in order:
 //   * first differences D, second differences e, 13/3 e^2 + eps and e/3, -e/2 are formed ONCE per cell and stay in
-//     registers for the three centres that use them (a centre costs 33 issue slots instead of 45);
+//     registers for the three centres that use them (a centre costs 31 FP64 instructions instead of 41);
 //   * the face value of centre c-1 is the previous iterate: no hand-off through LDS, and a strip of 8 cells needs
 //     9 centres (one-sided upwinding) -- the "rim" of the per-block form (one extra reconstruction per cell) is gone;
 //   * the 5-point Laplacian of a line IS the second difference e the smoothness indicators need anyway.
-// A 16x16 tile x 2 components = 512 strips cells per direction = 64 lanes x 8: the x walk runs with lane =
+// A 16x16 tile x 2 components = 512 strip cells per direction = 64 lanes x 8: the x walk runs with lane =
 // (component, row, half row), leaves old + c (afac u dc/dx + dfac c_xx) in an LDS buffer, the y walk runs with lane =
-// (component, column, half column), adds its part and writes the result.  ~165 FP64 slots per cell against 277.
+// (component, column, half column), adds its part in place, and the buffer goes to memory with coalesced 16-byte
+// stores.  161 FP64 / 195 VALU instructions per cell against 241 / 306 (measured: SQ_INSTS_VALU).
 //
 // The arithmetic is the WenoFast policy (weno.h) on the same differences, with the common factors moved:
 //   plus (c) = s_c + D1/2 + [W1 e1/3 + 2 W2 e2 + W3 (3/2 e2 - e3/2)] / (W1 + 6 W2 + 3 W3)

@@ -135,9 +135,9 @@ static __device__ __forceinline__ int edge_cell(int s, int q) {
 // loads in flight with (2 waves per SIMD, 234 VGPRs) and ran latency-bound at 3.3 TB/s.  Same k order and
 // operands as precond_tile, so z is bit-identical to the unfused MFMA preconditioner.
 // CUP2D_FUSED_MFMA_PRIO: the two waves of a SIMD share its matrix core; per-phase clocks (-DFUSED_PHASES) show 5.2-6.5 k
-// cycles per 64-MFMA job against 2 k of MFMA issue -- the jobs of the two waves run interleaved at half rate each, and half
-// of a CD tile's time goes into its two jobs.  With the priority raised for the duration of a job the first wave to arrive
-// finishes at the full rate and the two waves drift apart: one wave's job then runs beside the other's loads and staging.
+// cycles per 64-MFMA job, and half of a CD tile's time goes into its two jobs.  With the priority raised for the duration of
+// a job the first wave to arrive would finish at the full rate and the two waves drift apart: one wave's job beside the
+// other's loads and staging.
 // Measured at 4096^2: AB 162.4 -> 163.3 us, CD 121.6 -> 123.8 us -- nothing: the matrix core itself is the limit (a
 // v_mfma_f64_16x16x4_f64 takes 64 cycles on this part, tools/fp64_peak.hip; two waves x two jobs x 64 MFMAs = 16 k cycles of
 // a 23.5 k-cycle CD tile).  Off.
@@ -146,14 +146,14 @@ static __device__ __forceinline__ int edge_cell(int s, int q) {
 #endif
 template <bool DB = false>
 static __device__ __forceinline__ void tile_precond(double *S, const double *PL, const PinvFragments &PR, int lane, bool skip) {
-  double xa[16];
   const int ablk = lane & 15, akk = lane >> 4;
-#pragma unroll
-  for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
   v4f64 acc[4];
 #pragma unroll
   for (int nt = 0; nt < 4; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
   if (!skip) {
+    double xa[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
 #if CUP2D_FUSED_MFMA_PRIO
     __builtin_amdgcn_s_setprio(1);  // the job of the wave that gets here first runs at the full MFMA rate (below)
 #endif
@@ -165,9 +165,8 @@ static __device__ __forceinline__ void tile_precond(double *S, const double *PL,
           acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], PREG ? PR.b[ks][nt] : PL[(ks * 4 + nt) * 64 + lane], acc[nt], 0, 0, 0);
     } else {
       // The B fragments of k-step ks + 1 are requested BEFORE the four MFMAs of k-step ks (two register sets, the order
-      // pinned with scheduling barriers).  Left to the scheduler every k-step read its fragments right in front of its
-      // MFMAs and waited out the LDS latency: per-phase clocks (-DFUSED_PHASES) show 5.2-6.5 k cycles per 64-MFMA job
-      // against 2 k of MFMA issue -- half of a CD tile's time is spent in the two jobs.
+      // pinned with scheduling barriers); left to the scheduler every k-step reads its fragments right in front of its
+      // MFMAs.  No gain (CUP2D_FUSED_DB above): the four MFMAs of a k-step take 256 cycles, the read is hidden either way.
       double bf[2][4];
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) bf[0][nt] = PL[nt * 64 + lane];

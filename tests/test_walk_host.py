@@ -154,3 +154,16 @@ def test_quad_walk_with_ghost_blocks_and_phases(emul, oracle):
     out[:] = np.nan
     run(emul, quads, slab, slab, out, 0, 0, -dt * h, nu * dt)
     assert np.abs(g.from_blocks(out, 2) - ref).max() <= 2e-13 * np.abs(ref).max()
+
+
+def test_fused_sweep_index_logic_emulation(oracle):
+    """tools/emulate_fused.py: the index logic of k_fused (ring classification, staging tile, the MFMA fragment maps, the
+    ring job on the 32 edge columns of P_inv and its compact write-back, edge gathers, stencil) lane by lane in numpy
+    against the oracle's y = A P_inv v, on Hilbert and row-major grids incl. partial tiles -- a wrong index shows up here
+    without a GPU"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("emulate_fused", os.path.join(ROOT, "tools", "emulate_fused.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0

@@ -42,6 +42,34 @@ def tile_precond(S, Pt):
                 S[((l >> 4) + 4 * v) * XS + 16 * nt + (l & 15)] = D[(l >> 4) + 4 * v, 16 * nt + (l & 15)]
 
 
+def ring_precond(S, Pt):
+    """the ring job of the kernel since the end of round 2 (krylov_fused.hip ring_precond): the product with the 32 EDGE
+    columns of P_inv only -- B fragments PE[(ks*2+nt)*64 + l] = Pt[4ks + l/16][edge_cell(col >> 3, col & 7)], col = 16 nt +
+    l%16 -- written back as S[e*XS + 8*side + q]"""
+    lanes = np.arange(64)
+    ablk, akk = lanes & 15, lanes >> 4
+    X = np.zeros((16, 64))
+    for ks in range(16):
+        xa = S[ablk * XS + 4 * ks + akk]
+        for l in range(64):
+            X[l & 15, 4 * ks + (l >> 4)] = xa[l]
+    cols = [edge_cell(c >> 3, c & 7) for c in range(32)]
+    PE = np.empty((16, 2, 64))
+    for ks in range(16):
+        for nt in range(2):
+            for l in range(64):
+                PE[ks, nt, l] = Pt[4 * ks + (l >> 4), cols[16 * nt + (l & 15)]]
+    D = np.zeros((16, 32))
+    for ks in range(16):
+        for nt in range(2):
+            for l in range(64):  # D[i][16 nt + j] += sum_kk A[i][4ks+kk] B[kk][j]: lane l holds B[kk = l/16][j = l%16]
+                D[:, 16 * nt + (l & 15)] += X[:, 4 * ks + (l >> 4)] * PE[ks, nt, l]
+    for v in range(4):
+        for nt in range(2):
+            for l in range(64):
+                S[((l >> 4) + 4 * v) * XS + 16 * nt + (l & 15)] = D[(l >> 4) + 4 * v, 16 * nt + (l & 15)]
+
+
 def fused(vin, nbr, Pt, count):
     """y[b][cell] = (A P_inv v) via the kernel's tile logic; vin[b][cell]"""
     y = np.zeros_like(vin)
@@ -68,14 +96,14 @@ def fused(vin, nbr, Pt, count):
             for e in range(TB):
                 blk = ring_nb[base + min(e, ne - 1)]
                 S[e * XS + lanes] = vin[blk]
-            tile_precond(S, Pt)
+            ring_precond(S, Pt)
             for h in range(2):
                 for l in range(64):
                     idx = l + 64 * h
                     e, q = idx >> 3, idx & 7
                     if e < ne:
                         dst = ring_dst[base + e]
-                        GE[dst * BS + q] = S[e * XS + edge_cell((dst & 3) ^ 1, q)]
+                        GE[dst * BS + q] = S[e * XS + 8 * ((dst & 3) ^ 1) + q]
         for i in range(TB):
             S[i * XS + lanes] = vin[b0 + min(i, nvalid - 1)]
         tile_precond(S, Pt)

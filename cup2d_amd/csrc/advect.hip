@@ -138,17 +138,16 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
 #pragma unroll
   for (int i = 0; i < 3; i++) gp[i] = walk::ghost_pack(lane, i);
   const GroupRange gr = chunk > 0 ? group_range_chunked(nq, chunk) : group_range(nq);
-  int g = gr.begin;
-  bool have = g < gr.end && g * WPG + wave < nq;
-  if (!have) return;
+  // cur: the wave's position in its workgroup's groups (ranges.h).  A read-ahead past the wave's last quad is redirected
+  // to that last quad -- never to `cur.g`, which runs one stride past the end on the final iteration.
+  WaveCursor cur;
+  cur.init(gr, wave, WPG, nq);
+  if (!cur.have) return;
   // The plan entry of a quad (12 ints) is read by lanes 0..11 with ONE vector load, two quads ahead of its use, and
   // handed out with v_readlane: the block ids are wave-uniform values by the time the loads that depend on them are
   // issued (a per-lane load of the table in front of the ghost loads stalled every quad for a memory round trip).
   const int tl = lane < walk::QINTS ? lane : 0;
-  auto entry_of = [&](int gg) {  // the quad of this wave in group gg, or its last one
-    const bool ok = gg < gr.end && gg * WPG + wave < nq;
-    return quads + (size_t)((ok ? gg : g) * WPG + wave) * walk::QINTS;
-  };
+  auto entry_ahead = [&](int ahead) { return quads + (size_t)cur.item(ahead) * walk::QINTS; };
   // (no copy of a loaded register anywhere: a v_mov of `vnext` is a use, and the wait it brings covers every load and
   // store issued before it)
 #define WALK_READ(E, v)                                                                                             \
@@ -158,12 +157,12 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
   E.n5 = __builtin_amdgcn_readlane(v, 9), E.n6 = __builtin_amdgcn_readlane(v, 10), E.n7 = __builtin_amdgcn_readlane(v, 11)
   walk::Entry E;
   {
-    const int v0 = entry_of(g)[tl];
+    const int v0 = entry_ahead(0)[tl];
     WALK_READ(E, v0);
   }
   walk::Regs R;
   walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
-  int vnext = entry_of(g + gr.stride)[tl];
+  int vnext = entry_ahead(1)[tl];
   walk::V2 *out2 = reinterpret_cast<walk::V2 *>(out);
   int pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;  // the blocks of the quad whose results wait in L.T
   bool pending = false;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
   // outranks age, so every wave takes the top priority for one quad in three: equal progress, a common finish.
   const int wid = __builtin_amdgcn_s_getreg((3 << 11) | 4) % 3;  // HW_ID.wave_id: the slot in the SIMD's wave buffer
   int turn = wid;
-  while (have) {
+  while (cur.have) {
     if (prio_mode) {
       if (turn == 0) __builtin_amdgcn_s_setprio(2);
       else if (turn == 1) __builtin_amdgcn_s_setprio(1);
@@ -190,8 +189,7 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
     const bool nPx = anyu != 0ull, nMx = allu != ~0ull, nPy = anyv != 0ull, nMy = allv != ~0ull;
     const int cb0 = E.b0, cb1 = E.b1, cb2 = E.b2, cb3 = E.b3;
     // the next quad of this wave (its last one is simply fetched twice)
-    g += gr.stride;
-    have = g < gr.end && g * WPG + wave < nq;
+    cur.advance();
     WALK_READ(E, vnext);  // (waits for everything issued so far: the loads of this quad, the stores of the one before last)
 #ifndef WALK_KNOCKOUT
 #define WALK_KNOCKOUT 0  // timing aid: 1 = no arithmetic (memory skeleton only), 2 = no loads / stores inside the loop
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
     wave_lds_sync();
     if (WALK_KNOCKOUT != 2) {
       walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
-      vnext = entry_of(g + gr.stride)[tl];
+      vnext = entry_ahead(1)[tl];
     }
     if (WALK_KNOCKOUT == 1) {
       pb0 = cb0, pb1 = cb1, pb2 = cb2, pb3 = cb3;
@@ -234,15 +232,20 @@ static const WalkPlan *walk_plan(cup2d_ctx *c, int first, int count) {
   p.count = count;
   p.nquads = (int)(quads.size() / walk::QINTS);
   p.nsingles = (int)singles.size();
+  const auto fail = [&]() -> const WalkPlan * {  // nothing has been launched on these tables: they go straight back
+    dev_free(p.d_quads);
+    dev_free(p.d_singles);
+    return nullptr;
+  };
   if (p.nquads) {
     if (dev_malloc(&p.d_quads, quads.size() * sizeof(int32_t)) != hipSuccess ||
         hipMemcpy(p.d_quads, quads.data(), quads.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-      return nullptr;
+      return fail();
   }
   if (p.nsingles) {
     if (dev_malloc(&p.d_singles, singles.size() * sizeof(int32_t)) != hipSuccess ||
         hipMemcpy(p.d_singles, singles.data(), singles.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-      return nullptr;
+      return fail();
   }
   c->walk_plans.push_back(p);
   return &c->walk_plans.back();

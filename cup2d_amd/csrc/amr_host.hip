@@ -6,6 +6,7 @@
 // statement of the same algorithm and require the two to agree bit for bit.)
 #include <algorithm>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -38,8 +39,18 @@ void parallel_chunks(long long n, long long grain, F fn) {
     fn(0LL, n, 0);
     return;
   }
+  // a thread that cannot be created (std::system_error: the process is out of threads) must not take the process down from
+  // inside a C ABI call: the chunks that found no thread run here, serially
   std::vector<std::thread> th;
-  for (long long t = 0; t < nt; t++) th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
+  long long started = 0;
+  try {
+    for (; started < nt; started++) {
+      const long long t = started;
+      th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
+    }
+  } catch (const std::system_error &) {
+  }
+  for (long long t = started; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, (int)t);
   for (auto &x : th) x.join();
 }
 
@@ -202,12 +213,9 @@ void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, c
   const int nchunks = chunk_count(nowned, 512);
   std::vector<std::vector<int32_t>> ccol((size_t)nchunks);
   std::vector<std::vector<double>> cval((size_t)nchunks);
-  std::vector<long long> clo((size_t)nchunks + 1, 0);
   std::vector<int> cplain((size_t)nchunks, 0);
   std::vector<long long> width((size_t)nowned, 0);
   parallel_chunks(nowned, 512, [&](long long lo, long long hi, int t) {
-    clo[t] = lo;
-    clo[t + 1] = hi;
     std::vector<std::pair<long long, double>> sorted;
     std::vector<Row> rows(64);
     std::vector<int32_t> &oc = ccol[t];
@@ -256,7 +264,7 @@ void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, c
   for (int b = 0; b < nowned; b++) ptr[b + 1] = ptr[b] + width[b] * 64;
   ecol.reserve((size_t)ptr[nowned]);
   eval.reserve((size_t)ptr[nowned]);
-  for (int t = 0; t < nchunks; t++) {  // chunk t covers blocks [clo[t], clo[t+1]): in block order
+  for (int t = 0; t < nchunks; t++) {  // chunk t covers blocks [nowned t / nchunks, nowned (t + 1) / nchunks): in block order
     ecol.insert(ecol.end(), ccol[t].begin(), ccol[t].end());
     eval.insert(eval.end(), cval[t].begin(), cval[t].end());
     nreg += cplain[t];

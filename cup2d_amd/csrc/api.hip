@@ -425,6 +425,25 @@ static int check_block_list(const cup2d_ctx *c, int n, const int32_t *blocks, co
     if (blocks[k] < 0 || blocks[k] >= c->nblocks) { set_error("%s: block %d of %d", what, blocks[k], c->nblocks); return CUP2D_ERR_ARG; }
   return CUP2D_OK;
 }
+// A pooled temporary of one call.  The pool hands a freed buffer to the next dev_malloc at once and fills it with zeros on
+// the null stream, which the (non-blocking) context streams do not wait for: whatever the context has enqueued on the
+// buffer must be done before it goes back -- on the error returns as well.
+namespace {
+struct DevTmp {
+  cup2d_ctx *c;
+  void *p = nullptr;
+  explicit DevTmp(cup2d_ctx *c_) : c(c_) {}
+  DevTmp(const DevTmp &) = delete;
+  DevTmp &operator=(const DevTmp &) = delete;
+  ~DevTmp() {
+    if (!p) return;
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(p);
+  }
+  hipError_t alloc(size_t bytes) { return dev_malloc(&p, bytes); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+}  // namespace
 int cup2d_download_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, double *host) {
   CUP2D_CHECK_CTX(c);
   CHECK_FIELD(field);
@@ -433,17 +452,16 @@ int cup2d_download_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks,
   if (!host) return CUP2D_ERR_ARG;
   const int per = dim_of(field);
   const size_t bytes = (size_t)n * BC * per * sizeof(double);
-  int32_t *d_idx = nullptr;
-  double *d_buf = nullptr;
-  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)n * sizeof(int32_t)));
-  CUP2D_HIP_CHECK(dev_malloc(&d_buf, bytes));
+  DevTmp t_idx(c), t_buf(c);
+  CUP2D_HIP_CHECK(t_idx.alloc((size_t)n * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(t_buf.alloc(bytes));
+  int32_t *d_idx = t_idx.as<int32_t>();
+  double *d_buf = t_buf.as<double>();
   CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_blocks_gather, dim3(blocks_grid(n)), dim3(WG), 0, c->stream, c->d_field[field], d_idx, d_buf, n, per);
   CUP2D_HIP_CHECK(hipGetLastError());
   CUP2D_HIP_CHECK(hipMemcpyAsync(host, d_buf, bytes, hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  dev_free(d_idx);
-  dev_free(d_buf);
   return CUP2D_OK;
 }
 int cup2d_upload_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, const double *host) {
@@ -454,18 +472,17 @@ int cup2d_upload_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, c
   if (!host) return CUP2D_ERR_ARG;
   const int per = dim_of(field);
   const size_t bytes = (size_t)n * BC * per * sizeof(double);
-  int32_t *d_idx = nullptr;
-  double *d_buf = nullptr;
-  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)n * sizeof(int32_t)));
-  CUP2D_HIP_CHECK(dev_malloc(&d_buf, bytes));
+  DevTmp t_idx(c), t_buf(c);
+  CUP2D_HIP_CHECK(t_idx.alloc((size_t)n * sizeof(int32_t)));
+  CUP2D_HIP_CHECK(t_buf.alloc(bytes));
+  int32_t *d_idx = t_idx.as<int32_t>();
+  double *d_buf = t_buf.as<double>();
   CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   CUP2D_HIP_CHECK(hipMemcpyAsync(d_buf, host, bytes, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_blocks_scatter, dim3(blocks_grid(n)), dim3(WG), 0, c->stream, c->d_field[field], d_idx, d_buf,
                      (const int32_t *)nullptr, n, per);
   CUP2D_HIP_CHECK(hipGetLastError());
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  dev_free(d_idx);
-  dev_free(d_buf);
   return CUP2D_OK;
 }
 int cup2d_copy_blocks(cup2d_ctx *c, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks) {
@@ -475,8 +492,9 @@ int cup2d_copy_blocks(cup2d_ctx *c, cup2d_ctx *src, int field, int n, const int3
   CUP2D_TRY(check_block_list(c, n, dst_blocks, "copy_blocks (destination)"));
   CUP2D_TRY(check_block_list(src, n, src_blocks, "copy_blocks (source)"));
   if (n == 0) return CUP2D_OK;
-  int32_t *d_idx = nullptr;
-  CUP2D_HIP_CHECK(dev_malloc(&d_idx, (size_t)2 * n * sizeof(int32_t)));
+  DevTmp t_idx(c);
+  CUP2D_HIP_CHECK(t_idx.alloc((size_t)2 * n * sizeof(int32_t)));
+  int32_t *d_idx = t_idx.as<int32_t>();
   CUP2D_HIP_CHECK(hipStreamSynchronize(src->stream));  // what the source context has enqueued is done
   CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx, dst_blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   CUP2D_HIP_CHECK(hipMemcpyAsync(d_idx + n, src_blocks, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -484,7 +502,6 @@ int cup2d_copy_blocks(cup2d_ctx *c, cup2d_ctx *src, int field, int n, const int3
                      (const double *)src->d_field[field], (const int32_t *)(d_idx + n), n, dim_of(field));
   CUP2D_HIP_CHECK(hipGetLastError());
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  dev_free(d_idx);
   return CUP2D_OK;
 }
 int cup2d_field_ptr(cup2d_ctx *c, int field, void **p) {
@@ -1111,6 +1128,10 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
   for (int i = 0; i < nrecv; i++)
     if (rb[i] < c->nblocks || rb[i] >= c->ntotal || rf[i] < 0 || rf[i] > 3) { set_error("halo_plan: recv entry %d", i); return CUP2D_ERR_ARG; }
   HaloPlan &p = c->plan;
+  // cup2d_halo_exchange is asynchronous: pack / unpack kernels of the OLD plan may still read these tables, and the pool
+  // would hand them to the next dev_malloc (zero fill on the null stream) at once.  (The communicator's second stream hands
+  // back to c->stream through an event before unpack: waiting for c->stream covers it.)
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   dev_free(p.d_send_block); dev_free(p.d_send_face); dev_free(p.d_recv_block); dev_free(p.d_recv_face);
   p = HaloPlan();
   p.nsend = nsend; p.nrecv = nrecv;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ctx.h"
+#include "ranges.h"
 
 namespace cup2d {
 
@@ -12,25 +13,9 @@ namespace cup2d {
 // XCD (workgroup id % 8, MI355X_MICROARCH.md "block b runs on XCD b % 8") a contiguous range of
 // groups, so the blocks whose ghost cells a wave reads were fetched by a neighbour on the SAME
 // L2.  Purely a speed choice: any placement computes the same result.
-struct GroupRange {
-  int begin, end, stride;
-};
+// (ranges.h: host+device, replayed on the CPU by tests/walk_emul.cpp)
 static __device__ __forceinline__ GroupRange group_range(int count) {
-  const int groups = (count + WPG - 1) / WPG;
-  const int G = gridDim.x, w = blockIdx.x;
-  GroupRange r;
-  if (G >= 8 && (G % 8) == 0) {
-    const int xcd = w & 7, slot = w >> 3, per = G >> 3;
-    const long long lo = (long long)groups * xcd / 8, hi = (long long)groups * (xcd + 1) / 8;
-    r.begin = (int)lo + slot;
-    r.end = (int)hi;
-    r.stride = per;
-  } else {
-    r.begin = w;
-    r.end = groups;
-    r.stride = G;
-  }
-  return r;
+  return group_range_of(count, WPG, gridDim.x, blockIdx.x);
 }
 // Chunked variant for the FP64-issue-bound kernels: the grid has MORE workgroups than fit on the chip
 // and each one walks `chunk` consecutive groups (stride 1) of its XCD's contiguous range.  VALU issue
@@ -39,14 +24,7 @@ static __device__ __forceinline__ GroupRange group_range(int count) {
 // 72 % of the kernel time); short-lived workgroups are replaced as they retire, which keeps four waves
 // per SIMD until the end.  launch with chunked_grid().
 static __device__ __forceinline__ GroupRange group_range_chunked(int count, int chunk) {
-  const int groups = (count + WPG - 1) / WPG;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const long long lo = (long long)groups * xcd / 8, hi = (long long)groups * (xcd + 1) / 8;
-  GroupRange r;
-  r.begin = (int)lo + slot * chunk;
-  r.end = min((int)hi, r.begin + chunk);
-  r.stride = 1;
-  return r;
+  return group_range_chunked_of(count, WPG, chunk, blockIdx.x);
 }
 static __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -15,6 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "walk_emul.cpp")
 HDR = os.path.join(ROOT, "cup2d_amd", "csrc", "advect_walk.h")
+HDR2 = os.path.join(ROOT, "cup2d_amd", "csrc", "ranges.h")
 SO = os.path.join(ROOT, "tests", "_walk_emul.so")
 _i32 = ctypes.POINTER(ctypes.c_int32)
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -22,12 +23,41 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 @pytest.fixture(scope="module")
 def emul():
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", SO, SRC])
     lib = ctypes.CDLL(SO)
     lib.walk_emul_plan.argtypes = [_i32, ctypes.c_int, ctypes.c_int, _i32, _i32, ctypes.POINTER(ctypes.c_int)]
     lib.walk_emul_run.argtypes = [_i32, ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    lib.walk_emul_cursor.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32]
+    lib.walk_emul_cursor.restype = ctypes.c_longlong
     return lib
+
+
+def _chunked_grid(count, chunk, wpg=4):   # ctx.h chunked_grid
+    groups = (count + wpg - 1) // wpg
+    return 8 * (((groups + 7) // 8 + chunk - 1) // chunk)
+
+
+def _persistent_grid(count, per_cu, wpg=4, cus=256):   # api.hip resident_grid
+    groups = (count + wpg - 1) // wpg
+    g = min(per_cu * cus, groups)
+    if g >= 8:
+        g -= g % 8
+    return max(g, 1)
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 31, 33, 64, 100, 767 * 4 + 1, 4096, 65536, 262144])
+def test_quad_loop_never_leaves_the_plan_table(emul, nq):
+    """The index sequence of k_advect_walk's loop (ranges.h WaveCursor, the code the kernel runs) for every workgroup and
+    wave of a launch: every quad exactly once, and no table read -- the read-ahead past a wave's last quad included -- at
+    or beyond entry nq.  nq = 65 536 / 262 144 are the plans of 4096^2 / 8192^2 (round 2's kernel read up to
+    stride * 192 bytes past the table there)."""
+    visits = np.zeros(nq, dtype=np.int32)
+    grids = {(_persistent_grid(nq, pc), 0) for pc in (1, 3, 4, 8)} | {(1, 0), (7, 0), (13, 0)}
+    grids |= {(_chunked_grid(nq, ch), ch) for ch in (1, 3, 16)}
+    for G, chunk in sorted(grids):
+        worst = emul.walk_emul_cursor(nq, 4, G, chunk, visits.ctypes.data_as(_i32))
+        assert 0 <= worst < nq, (nq, G, chunk, worst)
 
 
 def plan(lib, nbr, first, count):

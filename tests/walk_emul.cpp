@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../cup2d_amd/csrc/advect_walk.h"
+#include "../cup2d_amd/csrc/ranges.h"
 
 using namespace cup2d::walk;
 
@@ -60,5 +61,40 @@ void walk_emul_run(const int32_t *quads, int nquads, const double *vel, const do
     else if (oldlab) run_quad<1, true>(v, vo, out, q, afc, dfc);
     else run_quad<1, false>(v, vo, out, q, afc, dfc);
   }
+}
+
+// The loop of k_advect_walk over a wave's quads, replayed for EVERY workgroup of a launch with the kernel's own cursor
+// (ranges.h): init, the plan entry of the first quad and the read-ahead of the second, then per iteration advance() and the
+// read-ahead of the quad after next.  G workgroups of wpg waves; chunk > 0 = the chunked grid (G must be
+// chunked_grid(nq, chunk)), 0 = the persistent one.  Returns the largest table index any wave touched (must be < nq), or
+// -1 - (a quad that was not visited exactly once).  visits: scratch of nq ints.
+long long walk_emul_cursor(int nq, int wpg, int G, int chunk, int *visits) {
+  long long worst = -1;
+  for (int i = 0; i < nq; i++) visits[i] = 0;
+  for (int w = 0; w < G; w++) {
+    const cup2d::GroupRange gr = chunk > 0 ? cup2d::group_range_chunked_of(nq, wpg, chunk, w) : cup2d::group_range_of(nq, wpg, G, w);
+    for (int wave = 0; wave < wpg; wave++) {
+      cup2d::WaveCursor cur;
+      cur.init(gr, wave, wpg, nq);
+      if (!cur.have) continue;
+      long long i0 = cur.item(0), i1 = cur.item(1);
+      if (i0 > worst) worst = i0;
+      if (i1 > worst) worst = i1;
+      if (i0 < 0 || i1 < 0) return -1 - (long long)nq;
+      int current = (int)i0, next = (int)i1;  // the entry in E and the one in flight (vnext)
+      while (cur.have) {
+        if (current >= 0 && current < nq) visits[current]++;
+        cur.advance();
+        current = next;  // WALK_READ(E, vnext): valid also past the end (the last quad again, fetched and dropped)
+        const long long ia = cur.item(1);
+        if (ia > worst) worst = ia;
+        if (ia < 0) return -1 - (long long)nq;
+        next = (int)ia;
+      }
+    }
+  }
+  for (int i = 0; i < nq; i++)
+    if (visits[i] != 1) return -1 - (long long)i;
+  return worst;
 }
 }

@@ -181,6 +181,24 @@ void dev_free(void *q) {
   P.idle_bytes += it->second.second;
 }
 
+// A pooled temporary of one call.  The pool hands a freed buffer to the next dev_malloc at once and fills it with zeros on
+// the null stream, which the (non-blocking) context streams do not wait for: whatever the context has enqueued on the
+// buffer must be done before it goes back -- on the error returns as well.
+struct DevTmp {
+  cup2d_ctx *c;
+  void *p = nullptr;
+  explicit DevTmp(cup2d_ctx *c_) : c(c_) {}
+  DevTmp(const DevTmp &) = delete;
+  DevTmp &operator=(const DevTmp &) = delete;
+  ~DevTmp() {
+    if (!p) return;
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(p);
+  }
+  hipError_t alloc(size_t bytes) { return dev_malloc(&p, bytes); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 }  // namespace cup2d
 
 using namespace cup2d;
@@ -425,25 +443,6 @@ static int check_block_list(const cup2d_ctx *c, int n, const int32_t *blocks, co
     if (blocks[k] < 0 || blocks[k] >= c->nblocks) { set_error("%s: block %d of %d", what, blocks[k], c->nblocks); return CUP2D_ERR_ARG; }
   return CUP2D_OK;
 }
-// A pooled temporary of one call.  The pool hands a freed buffer to the next dev_malloc at once and fills it with zeros on
-// the null stream, which the (non-blocking) context streams do not wait for: whatever the context has enqueued on the
-// buffer must be done before it goes back -- on the error returns as well.
-namespace {
-struct DevTmp {
-  cup2d_ctx *c;
-  void *p = nullptr;
-  explicit DevTmp(cup2d_ctx *c_) : c(c_) {}
-  DevTmp(const DevTmp &) = delete;
-  DevTmp &operator=(const DevTmp &) = delete;
-  ~DevTmp() {
-    if (!p) return;
-    (void)hipStreamSynchronize(c->stream);
-    dev_free(p);
-  }
-  hipError_t alloc(size_t bytes) { return dev_malloc(&p, bytes); }
-  template <class T> T *as() const { return static_cast<T *>(p); }
-};
-}  // namespace
 int cup2d_download_blocks(cup2d_ctx *c, int field, int n, const int32_t *blocks, double *host) {
   CUP2D_CHECK_CTX(c);
   CHECK_FIELD(field);
@@ -783,6 +782,20 @@ int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   return CUP2D_OK;
 }
 static bool scalar_field(int f) { return field_ok(f) && dim_of(f) == 1; }
+int cup2d_solver_keep_last(cup2d_ctx *c, int on) {
+  CUP2D_CHECK_CTX(c);
+  c->keep_last = on != 0;
+  if (!on) c->have_last = false;
+  return CUP2D_OK;
+}
+int cup2d_solver_last_iterate(cup2d_ctx *c, int dst) {
+  CUP2D_CHECK_CTX(c);
+  if (!scalar_field(dst)) { set_error("solver_last_iterate: field %d is not a scalar field", dst); return CUP2D_ERR_ARG; }
+  if (!c->have_last) { set_error("solver_last_iterate: no iterate kept (cup2d_solver_keep_last before the solve)"); return CUP2D_ERR_ARG; }
+  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[dst], c->d_z, (size_t)c->nblocks * BC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return CUP2D_OK;
+}
 int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {
   CUP2D_CHECK_CTX(c);
   if (!scalar_field(dst) || !scalar_field(src) || dst == src) { set_error("apply_A: fields"); return CUP2D_ERR_ARG; }

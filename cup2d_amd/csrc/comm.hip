@@ -20,7 +20,9 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "krylov_common.h"
@@ -39,6 +41,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string path;  // the file the symbols came from (dladdr), for cup2d_comm_selftest's report
 };
 
 static RcclApi *rccl_api() {
@@ -102,6 +105,10 @@ static RcclApi *rccl_api() {
   if (!ok) {
     dlclose(h);
     return nullptr;
+  }
+  {
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void *>(api.Send), &di) && di.dli_fname) api.path = di.dli_fname;
   }
   api.handle = h;
   return &api;
@@ -240,6 +247,13 @@ int cup2d_comm_unique_id(void *id_bytes) {
   return CUP2D_OK;
 }
 
+// COLLECTIVE over the nranks processes: ncclCommInitRank below blocks until every rank has arrived.  The argument and plan
+// checks in front of it are functions of the decomposition, which every rank derives from the same numbers -- ranks must
+// validate identically (a rank that returns early leaves the others in the rendezvous; callers bound that wait with their
+// own watchdog, as bench.py and cup2d_run_mpi do, and run cup2d_comm_selftest right after a successful init).  The two
+// communicators are used from two streams with no ordering between ranks; RCCL documents concurrent communicators as safe
+// only while every rank issues the operations of EACH communicator in the same order -- which holds here: the exchange
+// stream carries only the plan's send/recv groups, the compute stream only the solver's reductions, both in program order.
 int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
                     const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips, const int32_t *nstrips_recv) {
   CUP2D_CHECK_CTX(c);
@@ -288,6 +302,80 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     return CUP2D_ERR_COMM;
   }
   return cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red);
+}
+
+// One round of everything the time loop will ask of the communicator, with known values and a deadline: the strips of the
+// halo plan between every pair of peers (ncclSend / ncclRecv on the communication stream, as cup2d_halo_exchange issues them),
+// an all-reduce and an all-gather on the compute stream's communicator.  Collective: every rank of the communicator calls
+// it, right after cup2d_comm_init.  A rank whose operations do not complete within timeout_s returns CUP2D_ERR_COMM with
+// the stage it was waiting for (the caller should then end the process: the collective cannot be cancelled); wrong values
+// are reported the same way.  info (may be NULL): "rccl=<library file> ranks=N rank=r peers=a,b,.. exchange_us=.. reduce_us=..".
+int cup2d_comm_selftest(cup2d_ctx *c, double timeout_s, char *info, int info_bytes) {
+  CUP2D_CHECK_CTX(c);
+  RcclComm *rc = c->rccl;
+  if (!rc || c->comm_user != rc) { set_error("comm_selftest: no in-library communicator (cup2d_comm_init)"); return CUP2D_ERR_ARG; }
+  if (timeout_s <= 0) timeout_s = 20.0;
+  const int ns = c->plan.nsend, nr = c->plan.nrecv;
+  std::vector<double> hs((size_t)(ns > 0 ? ns : 1), (double)(rc->rank + 1)), hr((size_t)(nr > 0 ? nr : 1), -1.0);
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  CUP2D_HIP_CHECK(hipMemcpy(rc->d_send, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+  CUP2D_HIP_CHECK(hipMemcpy(rc->d_recv, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice));
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto wait_stream = [&](const char *stage) -> int {  // bounded wait: poll, never block inside the runtime
+    for (;;) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) return CUP2D_OK;
+      if (q != hipErrorNotReady) { set_error("comm_selftest: %s -> %s", stage, hipGetErrorString(q)); return CUP2D_ERR_HIP; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+        set_error("comm_selftest: rank %d of %d still waiting for '%s' after %.0f s (librccl %s) -- a peer is missing or the "
+                  "links are down", rc->rank, rc->nranks, stage, timeout_s, rc->api->path.c_str());
+        return CUP2D_ERR_COMM;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  };
+  // 1. the strips of the plan, one double each
+  if (rccl_exchange(rc, rc->d_send, rc->d_recv, 1, c->stream) != 0 || rccl_wait(rc, c->stream) != 0) return CUP2D_ERR_COMM;
+  CUP2D_TRY(wait_stream("send/recv of the halo plan's strips"));
+  const double us_x = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
+  CUP2D_HIP_CHECK(hipMemcpy(hr.data(), rc->d_recv, hr.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < rc->peer.size(); i++)
+    for (int k = 0; k < rc->rcnt[i]; k++)
+      if (hr[(size_t)rc->roff[i] + k] != (double)(rc->peer[i] + 1)) {
+        set_error("comm_selftest: rank %d received %g in strip %d from rank %d (expected %d)", rc->rank, hr[(size_t)rc->roff[i] + k],
+                  rc->roff[i] + k, rc->peer[i], rc->peer[i] + 1);
+        return CUP2D_ERR_COMM;
+      }
+  // 2. all-reduce (sum) and all-gather on the compute stream's communicator
+  const auto t1 = std::chrono::steady_clock::now();
+  double three[3] = {(double)(rc->rank + 1), 2.0 * (rc->rank + 1), (double)rc->rank};
+  CUP2D_HIP_CHECK(hipMemcpy(c->d_red, three, sizeof three, hipMemcpyHostToDevice));
+  CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, 3, ncclDouble, rc->red, c->stream));
+  if (rccl_allreduce(rc, c->d_red, 1, 0, c->stream) != 0) return CUP2D_ERR_COMM;
+  CUP2D_TRY(wait_stream("all-gather / all-reduce"));
+  const double us_r = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() * 1e6;
+  std::vector<double> g((size_t)3 * rc->nranks);
+  double sum = 0;
+  CUP2D_HIP_CHECK(hipMemcpy(g.data(), rc->d_gather, g.size() * sizeof(double), hipMemcpyDeviceToHost));
+  CUP2D_HIP_CHECK(hipMemcpy(&sum, c->d_red, sizeof sum, hipMemcpyDeviceToHost));
+  for (int r = 0; r < rc->nranks; r++)
+    if (g[3 * r] != r + 1 || g[3 * r + 1] != 2.0 * (r + 1) || g[3 * r + 2] != r) {
+      set_error("comm_selftest: all-gather slot %d holds (%g, %g, %g)", r, g[3 * r], g[3 * r + 1], g[3 * r + 2]);
+      return CUP2D_ERR_COMM;
+    }
+  if (sum != 0.5 * rc->nranks * (rc->nranks + 1)) {
+    set_error("comm_selftest: all-reduce gave %g, expected %g", sum, 0.5 * rc->nranks * (rc->nranks + 1));
+    return CUP2D_ERR_COMM;
+  }
+  CUP2D_HIP_CHECK(hipMemset(c->d_red, 0, sizeof(double) * 8));
+  rc->n_exchange = rc->n_allreduce = rc->n_allgather = 0;  // the counters describe the time loop
+  if (info && info_bytes > 0) {
+    std::string peers;
+    for (size_t i = 0; i < rc->peer.size(); i++) peers += (i ? "," : "") + std::to_string(rc->peer[i]);
+    snprintf(info, (size_t)info_bytes, "rccl=%s ranks=%d rank=%d peers=%s exchange_us=%.0f reduce_us=%.0f", rc->api->path.c_str(),
+             rc->nranks, rc->rank, peers.empty() ? "-" : peers.c_str(), us_x, us_r);
+  }
+  return CUP2D_OK;
 }
 
 int cup2d_comm_finalize(cup2d_ctx *c) {

@@ -165,6 +165,7 @@ struct cup2d_ctx {
   cup2d::KrylovScalars *d_sc = nullptr;
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned
   static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)
+  bool keep_last = false, have_last = false;  // cup2d_solver_keep_last: the solve leaves its LAST iterate in d_z
   bool x0_is_zero = false;               // set by cup2d_step around its solve: the initial guess is zero, PRES is not read
   // max|u| of the velocity a cup2d_step leaves behind: its projection kernel writes per-workgroup maxima (slot 3 of
   // d_partials) and the NEXT cup2d_step takes its dt from them instead of reading the field again -- valid only if that

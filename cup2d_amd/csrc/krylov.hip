@@ -883,6 +883,11 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   c->prof_sample = true;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->have_last = false;
+  if (c->keep_last) {  // the last iterate (x is updated in place), for cup2d_solver_last_iterate
+    CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_z, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->have_last = true;
+  }
   // cuda.cu:546-547: return x_opt (with the synchronisation the reference omits)
   if (!c->h_sc->x_is_best)
     CUP2D_HIP_CHECK(hipMemcpyAsync(x, c->d_xopt, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

@@ -1116,6 +1116,20 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
   const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];
+  c->have_last = false;
+  if (c->keep_last) {  // the last iterate x0 + P_inv y, for cup2d_solver_last_iterate (before x0 in PRES is overwritten)
+    const double *ylast = ybuf[c->h_sc->ycur];
+    if (c->h_sc->iter == 0) {
+      if (x0_zero) CUP2D_TRY(launch_zero(c, c->d_z, n));
+      else CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_z, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else if (x0_zero) {
+      CUP2D_TRY(launch_precond(c, ylast, c->d_z, 0, nb));
+    } else {
+      CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_z, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      CUP2D_TRY(launch_precond_add(c, ylast, c->d_z, c->d_s));
+    }
+    c->have_last = true;
+  }
   if (c->h_sc->best_is_x0) {  // the initial guess is the answer: x = x0
     if (x0_zero) CUP2D_TRY(launch_zero(c, x, n));
   } else if (x0_zero) {

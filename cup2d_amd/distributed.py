@@ -230,6 +230,9 @@ class DistributedSimulation(Simulation):
             cols = [np.ascontiguousarray(peers[:, k]) for k in range(4)]
             _l.check(self.L.cup2d_comm_init(self._ctx, world, rank, box[0], len(t.peers), *[c.ctypes.data_as(vp) for c in cols], None),
                      "comm_init")
+            # one checked round of everything the time loop will ask of the communicator (strips between all peers, an
+            # all-gather, an all-reduce), bounded in time: a broken link or a missing peer ends HERE with a message
+            self.comm_report = self.comm_selftest()
             return
         self.comm = TorchComm(self.topo, mode, device, group=group)
         self.set_stream(self.comm.compute_stream.cuda_stream)
@@ -263,6 +266,16 @@ class DistributedSimulation(Simulation):
         self._cb = (_l.EXCHANGE_FN(_exchange), _l.WAIT_FN(_wait), _l.ALLREDUCE_FN(_allreduce))  # keep alive
         _l.check(self.L.cup2d_set_comm(self._ctx, self._cb[0], self._cb[1], self._cb[2], None,
                                        vp(comm.send.data_ptr()), vp(comm.recv.data_ptr()), vp(red_base)), "set_comm")
+
+    def comm_selftest(self, timeout_s=20.0):
+        """cup2d_comm_selftest: collective; returns the report string parsed into a dict"""
+        buf = ctypes.create_string_buffer(1024)
+        _l.check(self.L.cup2d_comm_selftest(self._ctx, float(timeout_s), buf, len(buf)), "comm_selftest")
+        rep = {}
+        for tok in buf.value.decode().split():
+            k, _, v = tok.partition("=")
+            rep[k] = v
+        return rep
 
     def comm_stats(self):
         """ranks, peers of this rank and the collectives issued so far by the in-library communicator"""

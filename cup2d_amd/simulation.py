@@ -190,6 +190,14 @@ class Simulation(BodyOps):
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)),
                  "set_solver")
 
+    def keep_last_iterate(self, on=True):
+        """diagnostic (cup2d_solver_keep_last): the next solves also keep their LAST iterate"""
+        _l.check(self.L.cup2d_solver_keep_last(self._ctx, int(on)), "solver_keep_last")
+
+    def last_iterate_to(self, field):
+        """the last iterate of the previous solve -> a scalar field (cup2d_solver_last_iterate)"""
+        _l.check(self.L.cup2d_solver_last_iterate(self._ctx, int(field)), "solver_last_iterate")
+
     def last_solver(self):
         """'fused' or 'sweeps': what the last poisson_solve ran"""
         k = ctypes.c_int()

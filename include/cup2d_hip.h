@@ -178,6 +178,12 @@ typedef enum { CUP2D_SOLVER_SWEEPS = 0, CUP2D_SOLVER_FUSED = 1 } cup2d_solver_ki
 int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
 /* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
+/* Diagnostic: the reference returns the BEST iterate in the max norm (cuda.cu:535-547), which within a capped number of
+ * iterations may still be the initial guess -- nothing of the iterations is then visible in PRES.  With keep_last on, a
+ * solve also keeps its LAST iterate (x0 + P_inv y for the fused organisation) in a solver scratch vector;
+ * cup2d_solver_last_iterate copies it to a scalar field.  bench.py compares the two organisations on it. */
+int cup2d_solver_keep_last(cup2d_ctx *ctx, int on);
+int cup2d_solver_last_iterate(cup2d_ctx *ctx, int dst_field);
 
 /* ---------------------------------------------------------------- assembled operator ----- */
 /* The seam the reference itself crosses (cuda.h LocalSpMatDnVec): instead of the 5-point stencil on
@@ -391,6 +397,13 @@ int cup2d_comm_unique_id(void *id_bytes /* [CUP2D_COMM_ID_BYTES] */);
 int cup2d_comm_init(cup2d_ctx *ctx, int nranks, int rank, const void *id_bytes, int npeers, const int32_t *peer_rank,
                     const int32_t *send_offset, const int32_t *recv_offset, const int32_t *nstrips,
                     const int32_t *nstrips_recv /* NULL: as many come in as go out (same-level faces); adapted grids differ */);
+/* One round of everything the time loop asks of the communicator, with known values and a deadline (default 20 s when
+ * timeout_s <= 0): the plan's strips between every pair of peers (ncclSend / ncclRecv on the communication stream), an
+ * all-gather and an all-reduce on the compute stream.  Collective; call it right after cup2d_comm_init.  Returns
+ * CUP2D_ERR_COMM with the stage and the RCCL library in cup2d_last_error() when an operation does not complete in time
+ * or delivers wrong values.  info (may be NULL) receives "rccl=<file> ranks=N rank=r peers=.. exchange_us=.. reduce_us=..".
+ * Replaces nothing in the reference (its MPI calls are unchecked, main.cpp:2040-2047, cuda.cu:445-449). */
+int cup2d_comm_selftest(cup2d_ctx *ctx, double timeout_s, char *info, int info_bytes);
 int cup2d_comm_finalize(cup2d_ctx *ctx);
 int cup2d_comm_stats(cup2d_ctx *ctx, int *nranks, int *npeers, long long *exchanges, long long *allreduces,
                      long long *allgathers);

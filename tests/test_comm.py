@@ -28,6 +28,7 @@ def test_comm_argument_checks_without_a_gpu():
     assert lib.cup2d_comm_init(None, 1, 0, ids, 0, None, None, None, None, None) == -1  # null context
     assert b"null context" in lib.cup2d_last_error()
     assert lib.cup2d_comm_finalize(None) == -1
+    assert lib.cup2d_comm_selftest(None, 1.0, None, 0) == -1
     assert lib.cup2d_halo_exchange(None, L.VEL, 3) == -1
     assert lib.cup2d_comm_stats(None, None, None, None, None, None) == -1
     del vp, one
@@ -78,6 +79,11 @@ def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib):
     hip = _hip()
     rng = np.random.default_rng(3)
     with s:
+        # the checked round the N-rank callers run right after cup2d_comm_init (strips between all peers, all-gather, all-reduce)
+        info = ctypes.create_string_buffer(512)
+        L.check(s.L.cup2d_comm_selftest(s.ctx, 20.0, info, len(info)), "comm_selftest")
+        rep = dict(t.partition("=")[::2] for t in info.value.decode().split())
+        assert rep["ranks"] == "1" and rep["rank"] == "0" and rep["peers"] == "0,0" and "librccl" in rep["rccl"], rep
         for field, dim, width in ((L.VEL, 2, 3), (L.PRES, 1, 1), (L.TMP, 1, 8)):
             a = rng.uniform(-1, 1, (g.ny, g.nx, dim) if dim > 1 else (g.ny, g.nx))
             s.set_field(field, a)

@@ -336,6 +336,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   double *fv[] = {c->d_p2, c->d_nu2, c->d_s, c->d_y, c->d_yopt};
   for (double *p : fv) dev_free(p);
   for (double *p : c->d_edge) dev_free(p);
+  dev_free(c->d_fault);
   dev_free(c->d_ticket);
   dev_free(c->d_sc);
   (void)hipHostFree(c->h_sc);

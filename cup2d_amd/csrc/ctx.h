@@ -155,6 +155,8 @@ struct cup2d_ctx {
   // tile-fused solver (krylov_fused.hip): ping-pong copies of p and nu, s = r - alpha nu, and the
   // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
   double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
+  int *d_fault = nullptr;    // k_edge's fault word (krylov_edge.h)
+  int edge_share = -1;       // k_edge: sibling waves share z edges (-1: not yet decided from the neighbour table)
   double *d_edge[8] = {nullptr};  // stored-edge ring (krylov_fused.hip): z, P_inv nu, z2, P_inv t on block edges, two buffers each
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
   int last_solver = 0;       // what the last solve ran

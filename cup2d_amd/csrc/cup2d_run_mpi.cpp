@@ -287,6 +287,9 @@ int main(int argc, char **argv) {
     if (g_rank == 0) RUN(cup2d_comm_unique_id(token));
     MPI_Bcast(token, sizeof token, MPI_BYTE, 0, MPI_COMM_WORLD);
     RUN(cup2d_comm_init(ctx, world, g_rank, token, (int)P.peer.size(), P.peer.data(), P.soff.data(), P.roff.data(), P.cnt.data(), nullptr));
+    char report[512] = "";
+    RUN(cup2d_comm_selftest(ctx, 20.0, report, (int)sizeof report));  // strips between all peers + reductions, checked, 20 s deadline
+    if (g_rank == 0) fprintf(stderr, "cup2d_run_mpi: communicator ok: %s\n", report);
   } else {
     T.init(P);
     RUN(cup2d_set_comm(ctx, &MpiTransport::exchange, &MpiTransport::wait, &MpiTransport::allreduce, &T, T.d_send, T.d_recv, T.d_red));

@@ -1,0 +1,358 @@
+// krylov_edge.h -- the EDGE form of the tile-fused BiCGSTAB sweeps (included by krylov_fused.hip, which holds the full form).
+//
+// Reference: BiCGSTABSolver::main cuda.cu:478-509 -- nu = A (P_inv p), t = A (P_inv s) -- with P_inv the block-Jacobi
+// matrix main.cpp:6451-6488 builds: P_inv = -(A_loc)^-1, A_loc = 4 on the diagonal, -1 between in-block neighbours.
+//
+// Identity.  Write the Poisson matrix of a same-level grid (main.cpp:7034-7112) as A = L + C + W: L the block-diagonal part
+// with -4 on EVERY diagonal (L = -A_loc, blockwise), C the +1 couplings between edge cells of neighbouring blocks, W the +1
+// on the diagonal of a cell per domain wall it touches (Neumann: the ghost is the edge cell, main.cpp:3210-3255).  L P_inv =
+// I, so for any v
+//     A P_inv v = v + (C + W) z,   z = P_inv v:
+// the operator is the IDENTITY on the 36 interior cells of a block, and on its 28 edge cells it adds ghost values that are
+// edge cells of z -- the own block's at a wall, the neighbour block's otherwise.  Only the 32 edge entries (4 sides x 8) of
+// z are ever needed: the dense 64 x 64 product per block shrinks to 64 x 32 (half the MFMAs), the 5-point stencil over the
+// tile disappears, and the result differs from the full form by the round-off of L (P_inv v) - v, a few 1e-15 |v|
+// (tests/test_solver_variants_gpu.py pins both forms to the oracle and to each other).  Needs the built-in P_inv
+// (!custom_Pinv); any other preconditioner takes the full form.
+//
+// Sharing.  A tile still needs the z edges of the blocks around it.  The full form recomputes every one of them from the
+// neighbour's inputs (16 re-read blocks + a job on the matrix cores per 16-block tile; the re-reads are what keeps its HBM
+// traffic at 1.3x the algorithmic bytes).  Here the 8 waves of a workgroup work on 8 CONSECUTIVE tiles in the same round
+// (in the reference's Hilbert order an aligned run of 128 blocks: a 16 x 8 patch), every wave EXPORTS the z edges of its
+// tile's perimeter sides to LDS, and a wave whose neighbour block belongs to a sibling's tile takes the edge from there:
+// 48 of the 128 perimeter sides of the 8 tiles are left to recompute (-62 % of the re-reads).  No workgroup barrier: per-wave
+// round counters in LDS (pub[w] = rounds wave w has published), a consumer waits for the one sibling it needs, a producer
+// for every sibling to be at most one round behind before it reuses an export buffer (two buffers, round parity).
+#pragma once
+// (a fragment of krylov_fused.hip: included INSIDE its namespace cup2d, after FusedArgs, ld2 / st2, ring_precond and
+// fused_reduce_store)
+
+constexpr int EXP_SLOTS = 16;  // perimeter sides a tile may export (host check edge_share_ok: every tile has <= 16)
+constexpr int PE2_DOUBLES = 16 * 2 * 64;  // the 32 edge columns of P_inv as MFMA B fragments: [k-step][n-tile][lane]
+constexpr int EDGE_HDR_DOUBLES = PE2_DOUBLES + 16;  // + the 8 round counters (padded to 128 bytes)
+struct alignas(16) EdgeLds {
+  double S[TB * XS];            // v of 16 blocks (A operand of the job), then the z edges of those blocks: S[b*XS + 8*side + q]
+  double GE[TB * 4 * GS];       // ghost edges of the tile's blocks: [block][W,E,S,N][q]
+  double X[2][EXP_SLOTS * BS];  // exported z edges of this tile's perimeter sides, in slot order; [round parity]
+  unsigned long long xmask[2];  // which (block, side) slots X holds: slot of bit i = popcount of the bits below i
+  int ring_nb[TB * 4];          // neighbour block of ring entry e (to recompute) ...
+  int ring_dst[TB * 4];         // ... and the slot (block * 4 + side) it feeds
+};
+constexpr size_t EDGE_LDS_BYTES = EDGE_HDR_DOUBLES * sizeof(double) + FWAVES * sizeof(EdgeLds);
+static_assert(EDGE_LDS_BYTES <= 156 * 1024, "k_edge: LDS budget (160 KiB per workgroup, some of it static)");
+constexpr int EDGE_SPIN_LIMIT = 1 << 22;  // a wave that waits longer than this for a sibling reports a fault instead of hanging
+
+// wave-uniform wait until sibling u has published `need` rounds
+static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int *fault) {
+  int spins = 0;
+  while (__hip_atomic_load(pub + u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > EDGE_SPIN_LIMIT) {
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
+// MODE 0 (sweeps A+B): v = p' = beta (p - omega nu) + r   (cuda.cu:478-483; restart: p' = rhat = r, 461-476)
+//                      y = nu' = p' + ghosts(P_inv p') ; partial(rhat . nu')             (484-488)
+// MODE 1 (sweeps C+D): v = s  = r - alpha nu'                                            (499-502)
+//                      y = t  = s + ghosts(P_inv s)   ; partial(t . s, t . t)           (503-509)
+// Jobs, batches, load schedule and cache policy as in k_fused (krylov_fused.hip); what differs is the job's product (edge
+// columns only, for the tile's own blocks too), where a ghost edge comes from, and the epilogue.
+template <int MODE, int MERGE>
+__global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__restrict__ Pinv,
+                                                 const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
+                                                 int first, int count, int poff, int share, double *red, unsigned *ticket,
+                                                 int *fault) {
+  extern __shared__ __attribute__((aligned(16))) double fsm[];
+  if (sc->status != 0) return;
+  constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
+  double *PE = fsm;
+  int *pub = reinterpret_cast<int *>(fsm + PE2_DOUBLES);
+  for (int idx = threadIdx.x; idx < PE2_DOUBLES; idx += FWG) {
+    const int l = idx & 63, nt = (idx >> 6) & 1, ks = idx >> 7, col = 16 * nt + (l & 15);
+    PE[idx] = Pinv[(4 * ks + (l >> 4)) * BC + edge_cell(col >> 3, col & 7)];
+  }
+  if (threadIdx.x < FWAVES) pub[threadIdx.x] = 0;
+  __syncthreads();
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  EdgeLds *LL = reinterpret_cast<EdgeLds *>(fsm + EDGE_HDR_DOUBLES);
+  EdgeLds &L = LL[wave];
+  // pair layout of the 16-byte accesses: this lane holds cells c0 = 2 hl, c0 + 1 of block 2 i + hf
+  const int hf = lane >> 5, hl = lane & 31, c0 = 2 * hl, px = c0 & 7, py = hl >> 2;
+  const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
+  const double beta = sc->beta;
+  const bool fresh = MODE == 0 && sc->iter == 0;            // p = nu = 0 (cuda.cu:436-437): not read
+  const bool restart = MODE == 0 && sc->restart_flag != 0;  // p' = rhat = r (cuda.cu:461-476)
+  constexpr int NDOT = MODE == 0 ? 1 : 2;
+  double acc[NDOT];
+#pragma unroll
+  for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
+
+  // v at one cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
+  const auto form_v = [&](double a, double b, double c) -> double {
+    if (MODE == 0) {
+      if (restart || fresh) return c;
+      double v = a + c1 * b;
+      v = v * beta;
+      return v + c;
+    }
+    return a + c1 * b;
+  };
+  struct Raw {  // one batch = 8 blocks = 4 block pairs
+    double2 a[4], b[4], c[4];
+  };
+
+  // tiles of 16 blocks; the 8 waves of a workgroup take 8 consecutive tiles per round, contiguous ranges per XCD
+  const int ntiles = (count + TB - 1) / TB;
+  int t_begin, t_end, t_stride;
+  {
+    const int G = gridDim.x, w = blockIdx.x;
+    if (G >= 8 && (G % 8) == 0) {
+      const int xcd = w & 7, slot = w >> 3, per = G >> 3;
+      const long long lo = (long long)ntiles * xcd / 8, hi = (long long)ntiles * (xcd + 1) / 8;
+      t_begin = (int)lo + slot * FWAVES + wave;
+      t_end = (int)hi;
+      t_stride = per * FWAVES;
+    } else {
+      t_begin = w * FWAVES + wave;
+      t_end = ntiles;
+      t_stride = G * FWAVES;
+    }
+  }
+  const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
+  const int last = first + count;
+  const auto load_nb = [&](int t) -> int {
+    const int b = first + t * TB + si;
+    return (t < t_end && b < last) ? nbr[4 * b + ss] : CUP2D_WALL;
+  };
+  struct Tile {
+    int b0, nvalid, nb, nring, npass, sib;  // sib: the sibling wave whose tile holds this slot's neighbour, or -1
+    unsigned long long pmask;               // the tile's perimeter slots (neighbour = a block outside the tile)
+    bool is_ring;                           // ... of which the ones to recompute
+  };
+  // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the previous tile's)
+  const auto classify = [&](int t, int nb) -> Tile {
+    Tile T;
+    T.b0 = first + t * TB;
+    T.nvalid = min(TB, last - T.b0);
+    T.nb = nb;
+    const bool outside = si < T.nvalid && nb >= 0 && (nb < T.b0 || nb >= T.b0 + T.nvalid);
+    // a sibling: another tile this workgroup holds in the same round (tiles t - wave .. t - wave + 7 below t_end)
+    const int nt = (nb - first) / TB, t0 = t - wave;
+    const bool sibling = share != 0 && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
+    T.sib = sibling ? nt - t0 : -1;
+    T.pmask = __ballot(outside);
+    T.is_ring = outside && !sibling;
+    const unsigned long long rmask = __ballot(T.is_ring);
+    T.nring = __popcll(rmask);
+    T.npass = (T.nring + TB - 1) / TB;
+    if (T.is_ring) {
+      const int slot = __popcll(rmask & ((1ull << lane) - 1ull));
+      L.ring_nb[slot] = nb;
+      L.ring_dst[slot] = lane;
+    }
+    wave_lds_sync();
+    return T;
+  };
+  // the 4 block pairs of batch `half` of job j of tile T (ring entries, or for the last job the tile's blocks), branch-free
+  const auto issue = [&](Raw &R, const Tile &T, int j, int half) {
+    const bool tile_job = j >= T.npass;
+    const int ne = max(1, min(TB, T.nring - j * TB));
+    size_t off[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int idx = 8 * half + 2 * p + hf;  // per half-wave
+      const int rb = L.ring_nb[min(j * TB + min(idx, ne - 1), TB * 4 - 1)];
+      const int blk = tile_job ? T.b0 + min(idx, T.nvalid - 1) : rb;
+      off[p] = ((size_t)blk * BC + c0) >> 1;  // in double2 units
+    }
+    const double2 *in0 = reinterpret_cast<const double2 *>(A.in0), *in1 = reinterpret_cast<const double2 *>(A.in1);
+    const double2 *in2 = reinterpret_cast<const double2 *>(A.in2);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const size_t o = off[p];
+      if (MODE == 0 && tile_job && (POL & 0x3000)) {
+        R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
+        R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
+        R.c[p] = in2[o];
+      } else {
+        R.a[p] = in0[o];
+        R.b[p] = in1[o];
+        if (MODE == 0) R.c[p] = in2[o];
+      }
+    }
+  };
+
+  Raw Ra, Rb;
+  Tile T;
+  if (t_begin < t_end) {
+    T = classify(t_begin, load_nb(t_begin));
+    issue(Ra, T, 0, 0);
+    if (DEEP) issue(Rb, T, 0, 1);
+  }
+  int nb_next = load_nb(t_begin + t_stride);
+  int round = 0;
+  for (int t = t_begin; t < t_end; t += t_stride, round++) {
+    // invariant: T describes tile t, its ring list is in LDS, the first batch of its first job is in flight in Ra
+    const int b0 = T.b0, nvalid = T.nvalid, par = round & 1;
+    double2 V[TB / 2];  // v of the tile's cells in pair layout
+    double2 W[TB / 2];  // dot-product operand: rhat (AB; r on a restart); CD uses V
+    const auto stage = [&](const Raw &R, bool is_tile, int half) {
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int idx = 8 * half + 2 * p + hf;
+        double2 v;
+        v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
+        v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
+        *reinterpret_cast<double2 *>(L.S + idx * XS + c0) = v;
+        if (is_tile) {
+          V[4 * half + p] = v;
+          if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
+          if (MODE == 0 && idx < nvalid) {  // CD does not store s: sweep E forms it again from r and nu'
+            const size_t o = ((size_t)(b0 + idx) * BC + c0) >> 1;
+            st2<(POL & 0x001) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
+            if (restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
+          }
+        }
+      }
+    };
+    Tile N = T;  // the next tile, once classified
+    for (int j = 0; j <= T.npass; j++) {
+      const bool is_tile = j == T.npass;
+      if (!DEEP) issue(Rb, T, j, 1);
+      stage(Ra, is_tile, 0);
+      if (DEEP) stage(Rb, is_tile, 1);
+      if (!is_tile) {
+        issue(Ra, T, j + 1, 0);
+        if (DEEP) issue(Rb, T, j + 1, 1);
+      } else if (MODE == 0 && !restart) {
+#pragma unroll
+        for (int i = 0; i < TB / 2; i++) {
+          const double2 *pw = reinterpret_cast<const double2 *>(A.w) + (((size_t)(b0 + min(2 * i + hf, nvalid - 1)) * BC + c0) >> 1);
+          W[i] = ld2<(POL & 0x800) != 0>(pw);
+        }
+      }
+      if (!DEEP) stage(Rb, is_tile, 1);
+      if (is_tile && t + t_stride < t_end) {
+        // this tile's ring list is dead: classify the NEXT tile into it and put its first job in flight behind this
+        // tile's job, edge traffic and epilogue
+        N = classify(t + t_stride, nb_next);
+        nb_next = load_nb(t + 2 * t_stride);
+        issue(Ra, N, 0, 0);
+        if (DEEP) issue(Rb, N, 0, 1);
+      } else {
+        wave_lds_sync();
+      }
+      ring_precond(L.S, PE, lane, false);  // S[e * XS + 8 * side + q] = z of entry (block) e on its four edges
+      if (!is_tile) {
+        // entry e feeds slot dst = block * 4 + side with the OPPOSITE edge of the neighbour block
+        const int ne = min(TB, T.nring - j * TB);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
+          if (e < ne) {
+            const int dst = L.ring_dst[j * TB + e];
+            L.GE[dst * GS + q] = L.S[e * XS + 8 * ((dst & 3) ^ 1) + q];
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+    // ---- export the z edges of the perimeter sides for the siblings ----
+    if (share) {
+      // this buffer held round - 2: every sibling has read it once it has published round - 1
+      if (round >= 2) {
+        for (int u = 0; u < FWAVES; u++)
+          if (u != wave) edge_wait(pub, u, round, fault);
+      }
+      if ((T.pmask >> lane) & 1ull) {
+        const int slot = __popcll(T.pmask & ((1ull << lane) - 1ull));
+        if (slot < EXP_SLOTS) {
+#pragma unroll
+          for (int q = 0; q < BS; q++) L.X[par][slot * BS + q] = L.S[si * XS + 8 * ss + q];
+        }
+      }
+      if (lane == 0) L.xmask[par] = T.pmask;
+      wave_lds_sync();
+      if (lane == 0) __hip_atomic_store(pub + wave, round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // ---- ghost edges from the own tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost = edge cell) ----
+    if (si < nvalid && !((T.pmask >> lane) & 1ull)) {
+      const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
+#pragma unroll
+      for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + 8 * sside + q];
+    }
+    // ---- ghost edges a sibling wave exported ----
+    if (share) {
+      for (int u = 0; u < FWAVES; u++) {
+        const bool mine = T.sib == u;
+        if (__ballot(mine) == 0ull) continue;
+        edge_wait(pub, u, round + 1, fault);
+        if (mine) {
+          const EdgeLds &O = LL[u];
+          const unsigned long long m = O.xmask[par];
+          const int bit = (T.nb - (b0 + (u - wave) * TB)) * 4 + (ss ^ 1);  // the slot of the neighbour block that faces this one
+          const int slot = min(__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);
+#pragma unroll
+          for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[par][slot * BS + q];
+        }
+      }
+    }
+    wave_lds_sync();
+    // ---- y = v + ghosts on the block edges (A P_inv v = v + (C + W) z), the fused dot products: two cells per lane, eight
+    //      block pairs ----
+#pragma unroll
+    for (int i = 0; i < TB / 2; i++) {
+      const int blk = 2 * i + hf;
+      if (blk < nvalid) {
+        const double *ge = L.GE + blk * 4 * GS;
+        double2 yv = V[i];
+        if (px == 0) yv.x += ge[0 * GS + py];        // west of cell c0
+        if (px == BS - 2) yv.y += ge[1 * GS + py];   // east of cell c0 + 1
+        if (py == 0) {
+          const double2 g = *reinterpret_cast<const double2 *>(ge + 2 * GS + px);
+          yv.x += g.x;
+          yv.y += g.y;
+        }
+        if (py == BS - 1) {
+          const double2 g = *reinterpret_cast<const double2 *>(ge + 3 * GS + px);
+          yv.x += g.x;
+          yv.y += g.y;
+        }
+        st2<(POL & (MODE == 0 ? 0x002 : 0x008)) != 0>(reinterpret_cast<double2 *>(A.yout) + (((size_t)(b0 + blk) * BC + c0) >> 1), yv);
+        const double2 wv = MODE == 0 ? W[i] : V[i];
+        acc[0] = __builtin_fma(yv.x, wv.x, acc[0]);
+        acc[0] = __builtin_fma(yv.y, wv.y, acc[0]);
+        if constexpr (NDOT == 2) {
+          acc[1] = __builtin_fma(yv.x, yv.x, acc[1]);
+          acc[1] = __builtin_fma(yv.y, yv.y, acc[1]);
+        }
+      }
+    }
+    wave_lds_sync();  // the next tile overwrites S and GE
+    T = N;
+  }
+  // this wave publishes nothing more: nobody may wait for it
+  if (lane == 0) __hip_atomic_store(pub + wave, 1 << 30, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
+  if (MERGE && arrive_last(ticket))  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
+    finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
+}
+
+// every tile of [first, first + count) has at most EXP_SLOTS perimeter sides: the export buffers hold them all
+static bool edge_share_ok(const int32_t *nbr, int first, int count) {
+  for (int b0 = first; b0 < first + count; b0 += TB) {
+    const int nv = std::min(TB, first + count - b0);
+    int n = 0;
+    for (int b = b0; b < b0 + nv; b++)
+      for (int s = 0; s < 4; s++) {
+        const int nb = nbr[4 * b + s];
+        n += nb >= 0 && (nb < b0 || nb >= b0 + nv);
+      }
+    if (n > EXP_SLOTS) return false;
+  }
+  return true;
+}
+

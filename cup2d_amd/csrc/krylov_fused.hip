@@ -691,6 +691,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
 }
 
+#include "krylov_edge.h"
+
 // ---- z on the faces other ranks need (multi-GPU) ---------------------------------------------------
 // For every (block, face) strip of the halo plan's send list: v of that block (the sweep's own formula),
 // z = P_inv v on the matrix cores, written to the block's place in zg.  The regular pack / exchange / unpack
@@ -845,6 +847,7 @@ bool fused_supported(const cup2d_ctx *c) {
 }
 
 static int ensure_fused_buffers(cup2d_ctx *c) {
+  if (!c->d_fault) CUP2D_HIP_CHECK(dev_malloc(&c->d_fault, sizeof(int)));  // (zero-filled)
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
   double **v[] = {&c->d_p2, &c->d_nu2, &c->d_s, &c->d_y, &c->d_yopt, &c->d_z};
   for (double **p : v)
@@ -873,9 +876,37 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // other ranks need first (k_fused_edges -> zg = the otherwise unused z vector), its width-1 halo exchange
 // overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
+// The edge form (krylov_edge.h; opt-in: CUP2D_FUSED_FORM=edge) applies with the built-in preconditioner on the same-level
+// stencil: one rank, or N ranks in the ghost-block form.  CUP2D_EDGE_SHARE=0 switches the sharing between sibling waves off
+// (every perimeter edge recomputed).  Measured at 4096^2 (tools/gpu_edge_check.py, round 3): full form AB 175 / CD 105 us,
+// edge form 178 / 109, edge form with sharing 175 / 116 -- half the MFMAs and 62 % fewer ring re-reads buy nothing: the
+// sweeps are bound by the memory system at the traffic the OUT-of-workgroup ring misses leave (the in-workgroup ring reads
+// sharing removes were the L2 hits), and the hand-over costs CD what a barrier did in round 2.  DESIGN.md 4.5.
+static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
+  static const bool on = [] { const char *e = getenv("CUP2D_FUSED_FORM"); return e && strcmp(e, "edge") == 0; }();
+  const bool ghosts = c->nghost > 0 && c->exchange;
+  return on && !c->custom_Pinv && !c->mat.active && re == 0 && dbg == 0 && (!ghosts || ghost_blocks);
+}
 template <int MODE>
 static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks, int re = 0) {
   const int nb = c->nblocks;
+  if (edge_form(c, ghost_blocks, re, dbg)) {
+    if (c->edge_share < 0) {
+      static const bool share_on = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return !e || atoi(e) != 0; }();
+      c->edge_share = share_on && edge_share_ok(c->h_nbr.data(), 0, nb) ? 1 : 0;
+    }
+    const int g = fused_grid(c, nb);
+    const auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, 0, nb,
+                         0, c->edge_share, c->d_red, c->d_ticket, c->d_fault);
+    };
+    if (merge == 1) go(k_edge<MODE, 1>);
+    else if (merge == 2) go(k_edge<MODE, 2>);
+    else go(k_edge<MODE, 0>);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    *GP = g;
+    return CUP2D_OK;
+  }
   if (c->mat.active) {
     // hybrid assembled operator: the fused tiles in one launch; then the halo entries of z, then the rows of the general
     // tiles, whose last workgroup finishes the reduction of both launches
@@ -1019,6 +1050,11 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_fused<1, 1, false, false, 2>), reinterpret_cast<const void *>(&k_fused<1, 2, false, false, 2>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
+    const void *ke[] = {reinterpret_cast<const void *>(&k_edge<0, 0>), reinterpret_cast<const void *>(&k_edge<0, 1>),
+                        reinterpret_cast<const void *>(&k_edge<0, 2>), reinterpret_cast<const void *>(&k_edge<1, 0>),
+                        reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>)};
+    for (const void *k : ke)
+      CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
   }
   // in-kernel finish.  1: one GPU -- one launch per sweep, the last workgroup also runs the scalar update.
@@ -1112,7 +1148,14 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   }
   c->prof_sample = true;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
+  int edge_fault = 0;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(&edge_fault, c->d_fault, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (edge_fault) {  // k_edge: a wave gave up waiting for a sibling's export (never seen; the result would be wrong)
+    CUP2D_HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));
+    set_error("poisson_solve: the edge-form sweep lost a hand-over between sibling waves (CUP2D_EDGE_SHARE=0 avoids the path)");
+    return CUP2D_ERR_HIP;
+  }
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
   const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];

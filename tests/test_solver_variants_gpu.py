@@ -143,3 +143,60 @@ def test_ring_from_stored_edges_matches_the_five_sweeps(gpu_lib):
     env = dict(os.environ, CUP2D_FUSED_RING="stored")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_ring_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ring=stored: ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+_EDGE_CHILD = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import cup2d_amd
+from cup2d_amd import lib as L
+from cup2d_amd.grid import BlockGrid
+from oracle import oracle as O
+out = {}
+rng = np.random.default_rng(5)
+for order, nbx, nby in (("hilbert", 8, 8), ("hilbert", 32, 32), ("rowmajor", 5, 3), ("hilbert", 6, 5), ("hilbert", 64, 32), ("rowmajor", 16, 16)):
+    g = BlockGrid(nbx, nby, order=order)
+    b = rng.uniform(-1, 1, (g.ny, g.nx)); b -= b.mean()
+    last = {}
+    for fused in (True, False):
+        with cup2d_amd.Simulation(nbx, nby, grid=g) as s:
+            s.set_precond(L.PRECOND_MFMA)
+            s.set_solver(fused=fused, finish_in_kernel=True)
+            s.keep_last_iterate(True)
+            s.tmp = b; s.fill(L.PRES, 0.0)
+            info = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=4)
+            s.last_iterate_to(L.POLD)
+            last[fused] = (s.pold.copy(), info, s.last_solver())
+    with cup2d_amd.Simulation(nbx, nby, grid=g) as s:
+        s.set_solver(fused=True, finish_in_kernel=True)
+        s.tmp = b; s.fill(L.PRES, 0.0)
+        conv = s.poisson_solve(tol=1e-9, max_restarts=100)
+        res = float(np.abs(b - O.apply_A(s.pres)).max())
+    out["%%s %%dx%%d" %% (order, nbx, nby)] = {
+        "rel4": float(np.abs(last[True][0] - last[False][0]).max() / np.abs(last[False][0]).max()),
+        "iters4": [last[True][1]["iters"], last[False][1]["iters"]], "ran": last[True][2], "conv_err": conv["err"], "conv_res": res}
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("share", ["1", "0"])
+def test_edge_form_of_the_fused_sweeps(gpu_lib, share):
+    """csrc/krylov_edge.h (opt-in, CUP2D_FUSED_FORM=edge; the switch is read once per process, hence the child): A P_inv v =
+    v + ghost edges of z, with the z edges of sibling tiles handed over through LDS (share 1) or every perimeter edge
+    recomputed (0).  Four iterations at zero tolerance equal the five sweeps to round-off on every block order (grids whose
+    tiles have more than 16 perimeter sides fall back to recomputation by themselves), and a converged solve satisfies the
+    reference's criterion against the oracle's operator."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CUP2D_FUSED_FORM="edge", CUP2D_EDGE_SHARE=share)
+    r = subprocess.run([sys.executable, "-c", _EDGE_CHILD % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    txt = r.stdout.decode()
+    lines = [l for l in txt.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, txt[-3000:]
+    for name, v in json.loads(lines[0][7:]).items():
+        assert v["ran"] == "fused" and v["iters4"] == [4, 4], (name, v)
+        assert v["rel4"] <= 1e-12, (name, v)
+        assert v["conv_err"] <= 1e-9 and v["conv_res"] <= 1.05e-9, (name, v)

@@ -197,3 +197,15 @@ def test_fused_sweep_index_logic_emulation(oracle):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_edge_form_index_logic_emulation(oracle):
+    """tools/emulate_edge.py: the index logic of k_edge (csrc/krylov_edge.h: rounds of 8 sibling tiles, slot classification,
+    export slots by prefix popcount, the consumers' look-up in a sibling's export, edge products, epilogue y = v + ghosts)
+    lane by lane in numpy against the oracle's y = A P_inv v, sharing on and off, Hilbert and row-major grids incl. partial
+    tiles and rounds"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emulate_edge", os.path.join(ROOT, "tools", "emulate_edge.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0

@@ -205,21 +205,23 @@ class Runner:
     def verify(self):
         """Post-run check on the fields the timed steps left.  (1) Set up the next step's Poisson system, run the capped
         solve, and recompute max|b - A x| from the fields (cup2d_poisson_residual): it must be the residual the solver
-        reported for the iterate it returned, everything finite, not above the initial residual.  (2) The reference returns
-        the best iterate in the max norm (cuda.cu:535-547); within the capped iterations that may still be the initial guess,
-        and (1) then says nothing about the sweeps.  So the same system is solved once more by the five-sweep organisation
-        (krylov.hip, the round-1 solver every test pins to the oracle) and the LAST iterates of the two organisations --
-        what the timed iterations actually computed -- must agree to 1e-8 of max|x| (they differ by the round-off of
-        different preconditioner arithmetic and summation orders, amplified over the iterations)."""
+        reported for the iterate it returned, everything finite, not above the initial residual.  The reference returns the
+        best iterate in the max norm (cuda.cu:535-547); within the capped iterations that may still be the initial guess, and
+        (1) then says nothing about the iterations.  So, on one GPU: (2) the LAST iterate of that solve -- what the timed
+        iterations computed -- is taken from the solver (cup2d_solver_last_iterate), max|b - A x_last| is recomputed from
+        the field and must agree with the max norm of the recurrence residual r the solver carried through all iterations
+        (they drift apart only by accumulated round-off: 1e-6 relative).  (3) The same system is solved for 8 iterations by the
+        timed organisation and by the five-sweep one (krylov.hip, the solver every test pins to the oracle) and the two last
+        iterates must agree to 1e-10 of max|x| (zero-tolerance BiCGSTAB amplifies round-off differences from iteration to
+        iteration: at 50 iterations two correct organisations differ visibly, at 8 they do not)."""
         from cup2d_amd import lib as L
         s = self.sim
         dt = s.compute_dt()
         s.advect_diffuse_rk2(dt)
         s.fill(L.PRES, 0.0)
         s.poisson_rhs(dt)
-        last = {}
-        can_compare = self.dist is None
-        if can_compare:
+        one_gpu = self.dist is None
+        if one_gpu:
             s.keep_last_iterate(True)
         r = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=self.args.iters)
         true = s.poisson_residual()
@@ -227,42 +229,49 @@ class Runner:
         best_is_x0 = bool(r["err"] == r["err_init"])
         ok = bool(np.isfinite([dt, r["err"], r["err_init"], true, umax]).all() and r["err"] <= r["err_init"]
                   and abs(true - r["err"]) <= 1e-6 * r["err"] + 1e-9)
-        if can_compare:
+        last = None
+        if one_gpu:
             try:
                 kind = s.last_solver()
-                s.last_iterate_to(L.POLD)
-                xa = s.get_field(L.POLD) if hasattr(s, "get_field") else s.pold
-                s.set_solver(fused=False, finish_in_kernel=True)
-                s.fill(L.PRES, 0.0)
-                r2 = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=self.args.iters)
-                s.last_iterate_to(L.POLD)
-                xb = s.get_field(L.POLD) if hasattr(s, "get_field") else s.pold
+                rec = s.last_iterate_to(L.POLD)       # recurrence max|r| after the last iteration
+                lib_ = s.L
+                L.check(lib_.cup2d_copy_field(s.ctx, L.PRES, L.POLD), "copy_field")  # PRES <- x_last
+                res_last = s.poisson_residual()       # max|b - A x_last| from the field (overwrites POLD)
+                xs = {}
+                for fused in (kind == "fused", False):
+                    s.set_solver(fused=fused, finish_in_kernel=self.args.finish == "kernel" if fused else True)
+                    s.fill(L.PRES, 0.0)
+                    r8 = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=8)
+                    s.last_iterate_to(L.POLD)
+                    xs[fused] = (s.pold, r8["iters"], s.last_solver())
                 s.set_solver(fused=(kind == "fused"), finish_in_kernel=self.args.finish == "kernel")
                 s.keep_last_iterate(False)
-                scale = float(np.abs(xb).max())
-                diff = float(np.abs(xa - xb).max())
-                # the last iterate's own residual, recomputed from the field
-                s.pres = xa
-                res_last = s.poisson_residual()
-                last = {"organisations": [kind, "sweeps"], "max_abs_last_iterate": scale, "max_abs_difference": diff,
-                        "relative": diff / scale if scale > 0 else None, "tolerance": 1e-8,
-                        "residual_of_last_iterate_recomputed": res_last, "iters": [r["iters"], r2["iters"]],
-                        "ok": bool(np.isfinite([scale, diff, res_last]).all() and scale > 0 and diff <= 1e-8 * scale
-                                   and r["iters"] == r2["iters"])}
+                xa, xb = xs[kind == "fused"], xs[False]
+                scale = float(np.abs(xb[0]).max())
+                diff = float(np.abs(xa[0] - xb[0]).max())
+                last = {"iterations_checked": r["iters"], "recurrence_residual_after_last_iteration": rec,
+                        "residual_of_last_iterate_recomputed": res_last,
+                        "relative_gap": abs(res_last - rec) / rec if rec > 0 else None,
+                        "eight_iterations": {"organisations": [xa[2], xb[2]], "iters": [xa[1], xb[1]], "max_abs_x": scale,
+                                             "max_abs_difference": diff, "relative": diff / scale if scale > 0 else None,
+                                             "tolerance": 1e-10}}
+                last["ok"] = bool(np.isfinite([rec, res_last, scale, diff]).all() and rec > 0 and scale > 0
+                                  and abs(res_last - rec) <= 1e-6 * rec and diff <= 1e-10 * scale and xa[1] == xb[1] == 8)
                 ok = ok and last["ok"]
             except Exception as e:
                 last = {"error": str(e)[:300], "ok": False}
                 ok = False
         return {"ok": ok, "residual_reported": r["err"], "residual_recomputed": true, "residual_initial": r["err_init"],
                 "best_iterate_is_initial_guess": best_is_x0,
-                "iters": r["iters"], "max_abs_vel": umax, "last_iterates": last,
+                "iters": r["iters"], "max_abs_vel": umax, "last_iterate": last,
                 "check": "max|b - A x| recomputed from the fields (cup2d_poisson_residual) == the solver's reported Linf "
-                         "residual within 1e-6 relative, not above the initial residual, all finite; AND the last iterate of "
-                         "the timed organisation == the last iterate of the five-sweep solver on the same system to 1e-8 of "
-                         "max|x| (one GPU)",
-                "note": "best_iterate_is_initial_guess true: no iterate beat x0 = 0 in the max norm within the capped "
-                        "iterations, so every timed solve RETURNS x0 as the reference would (cuda.cu:535-547) -- the iterations "
-                        "are computed in full and the last_iterates block is what checks them" if best_is_x0 else None}
+                         "residual within 1e-6 relative, not above the initial residual, all finite; one GPU: max|b - A x_last| "
+                         "recomputed from the LAST iterate == the recurrence residual after the last iteration within 1e-6 "
+                         "relative, and 8 iterations of the timed organisation == 8 iterations of the five-sweep solver to "
+                         "1e-10 of max|x|",
+                "note": ("best_iterate_is_initial_guess: no iterate beat x0 = 0 in the max norm within the capped iterations, so "
+                         "every timed solve RETURNS x0 as the reference would (cuda.cu:535-547) -- the iterations are computed in "
+                         "full, and the last_iterate block is what checks them") if best_is_x0 else None}
 
     def close(self):
         self.sim.close()

@@ -789,12 +789,13 @@ int cup2d_solver_keep_last(cup2d_ctx *c, int on) {
   if (!on) c->have_last = false;
   return CUP2D_OK;
 }
-int cup2d_solver_last_iterate(cup2d_ctx *c, int dst) {
+int cup2d_solver_last_iterate(cup2d_ctx *c, int dst, double *linf_recurrence) {
   CUP2D_CHECK_CTX(c);
   if (!scalar_field(dst)) { set_error("solver_last_iterate: field %d is not a scalar field", dst); return CUP2D_ERR_ARG; }
   if (!c->have_last) { set_error("solver_last_iterate: no iterate kept (cup2d_solver_keep_last before the solve)"); return CUP2D_ERR_ARG; }
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[dst], c->d_z, (size_t)c->nblocks * BC * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (linf_recurrence) *linf_recurrence = c->h_sc->err;  // max|r| of the recurrence after the last iteration (cuda.cu:525-534)
   return CUP2D_OK;
 }
 int cup2d_apply_A(cup2d_ctx *c, int dst, int src) {

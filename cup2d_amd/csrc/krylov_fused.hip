@@ -878,10 +878,16 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
 // The edge form (krylov_edge.h; opt-in: CUP2D_FUSED_FORM=edge) applies with the built-in preconditioner on the same-level
 // stencil: one rank, or N ranks in the ghost-block form.  CUP2D_EDGE_SHARE=0 switches the sharing between sibling waves off
-// (every perimeter edge recomputed).  Measured at 4096^2 (tools/gpu_edge_check.py, round 3): full form AB 175 / CD 105 us,
-// edge form 178 / 109, edge form with sharing 175 / 116 -- half the MFMAs and 62 % fewer ring re-reads buy nothing: the
-// sweeps are bound by the memory system at the traffic the OUT-of-workgroup ring misses leave (the in-workgroup ring reads
-// sharing removes were the L2 hits), and the hand-over costs CD what a barrier did in round 2.  DESIGN.md 4.5.
+// (every perimeter edge recomputed).  Measured at 4096^2 (tools/gpu_edge_check.py, tools/gpu_calls/gpu_r03_call3.sh, round 3;
+// AB / CD in us, L2-miss traffic per launch from FETCH_SIZE / WRITE_SIZE):
+//   full form (k_fused)            175 / 105     998 MB / 505 MB
+//   edge form, no sharing          178 / 109    1032 MB / 525 MB
+//   edge form, sharing             175 / 116     896 MB / 456 MB   (reads 763 -> 627 MB: the sibling ring is gone)
+//   + three batch buffers, every batch requested a job ahead (ring passes of 8 entries): CD 109, AB spills (251)
+// Half the MFMAs, 13 % less traffic and loads requested earlier each buy nothing: neither the matrix core, nor HBM, nor the
+// lead time of the loads is what a tile's 20 us consist of -- it is the chain of short dependent phases of ONE wave
+// (classification, staging, LDS gathers, epilogue; two waves per SIMD cannot overlap much of it), and the hand-over adds
+// to that chain what a barrier did in round 2.  The full form stays the default.  DESIGN.md 4.5.
 static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
   static const bool on = [] { const char *e = getenv("CUP2D_FUSED_FORM"); return e && strcmp(e, "edge") == 0; }();
   const bool ghosts = c->nghost > 0 && c->exchange;

@@ -102,7 +102,7 @@ def load_library():
     L.cup2d_set_solver.argtypes = [vp, i, i]
     L.cup2d_get_last_solver.argtypes = [vp, ctypes.POINTER(i)]
     L.cup2d_solver_keep_last.argtypes = [vp, i]
-    L.cup2d_solver_last_iterate.argtypes = [vp, i]
+    L.cup2d_solver_last_iterate.argtypes = [vp, i, ctypes.POINTER(d)]
     L.cup2d_set_amr.argtypes = [vp, d, vp, vp, vp, vp]
     L.cup2d_amr_poisson_coo.argtypes = [i, vp, vp, vp, ctypes.c_longlong, vp, vp, vp]
     L.cup2d_amr_poisson_coo.restype = ctypes.c_longlong

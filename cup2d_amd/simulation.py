@@ -195,8 +195,11 @@ class Simulation(BodyOps):
         _l.check(self.L.cup2d_solver_keep_last(self._ctx, int(on)), "solver_keep_last")
 
     def last_iterate_to(self, field):
-        """the last iterate of the previous solve -> a scalar field (cup2d_solver_last_iterate)"""
-        _l.check(self.L.cup2d_solver_last_iterate(self._ctx, int(field)), "solver_last_iterate")
+        """the last iterate of the previous solve -> a scalar field; returns max|r| of the recurrence after the last
+        iteration (cup2d_solver_last_iterate)"""
+        e = ctypes.c_double()
+        _l.check(self.L.cup2d_solver_last_iterate(self._ctx, int(field), ctypes.byref(e)), "solver_last_iterate")
+        return e.value
 
     def last_solver(self):
         """'fused' or 'sweeps': what the last poisson_solve ran"""

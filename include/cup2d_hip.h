@@ -181,9 +181,11 @@ int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 /* Diagnostic: the reference returns the BEST iterate in the max norm (cuda.cu:535-547), which within a capped number of
  * iterations may still be the initial guess -- nothing of the iterations is then visible in PRES.  With keep_last on, a
  * solve also keeps its LAST iterate (x0 + P_inv y for the fused organisation) in a solver scratch vector;
- * cup2d_solver_last_iterate copies it to a scalar field.  bench.py compares the two organisations on it. */
+ * cup2d_solver_last_iterate copies it to a scalar field and reports the max norm of the RECURRENCE residual r after the
+ * last iteration (may be NULL): recomputing max|b - A x_last| from the field and comparing is a check of every iteration
+ * the solve ran (bench.py "verified"). */
 int cup2d_solver_keep_last(cup2d_ctx *ctx, int on);
-int cup2d_solver_last_iterate(cup2d_ctx *ctx, int dst_field);
+int cup2d_solver_last_iterate(cup2d_ctx *ctx, int dst_field, double *linf_recurrence);
 
 /* ---------------------------------------------------------------- assembled operator ----- */
 /* The seam the reference itself crosses (cuda.h LocalSpMatDnVec): instead of the 5-point stencil on

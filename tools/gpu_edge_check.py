@@ -69,7 +69,7 @@ def run(what, env):
             return json.loads(line[7:])
     return {"rc": r.returncode, "tail": txt[-1500:]}
 
-variants = {"edge+share": {}, "edge": {"CUP2D_EDGE_SHARE": "0"}, "full": {"CUP2D_FUSED_FORM": "full"}}
+variants = {"edge+share": {"CUP2D_FUSED_FORM": "edge"}, "edge": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "0"}, "full": {"CUP2D_FUSED_FORM": "full"}}
 which = sys.argv[1:] or ["check", "time"]
 for what in which:
     for name, env in variants.items():

@@ -358,6 +358,51 @@ def regrid(blocks, states, fields, level_max, bpdx=1, bpdy=1):
     return new_blocks.astype(np.int64), dict(zip(names, dst))
 
 
+def regrid_local_plan(blocks, states, level_max, new_lo, new_hi, bpdx=1, bpdy=1, n_new=None):
+    """cup2d_amr_regrid_local, plan part, for the new blocks at positions [new_lo, new_hi): (new_blocks (n, 3) -- the whole
+    new leaf list --, src_of_new (n,), needed_old (nb,) bool: what the prolonged / restricted blocks OF THE RANGE are
+    computed from).  new_lo = new_hi = 0 with n_new None: the count only (returns n)."""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, dtype=np.int32)
+    L, nb = _l.load_library(), len(b32)
+    if n_new is None:
+        n = L.cup2d_amr_regrid_local(nb, _p(b32), bpdx, bpdy, level_max, _p(st), 0, 0, 0, None, None, None, 0, None, None, None, None, None)
+        if n < 0:
+            _l.check(int(n), "amr_regrid_local")
+        return int(n)
+    n = int(n_new)
+    new_blocks, src, needed = np.empty((n, 3), dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(nb, dtype=np.int32)
+    got = L.cup2d_amr_regrid_local(nb, _p(b32), bpdx, bpdy, level_max, _p(st), int(new_lo), int(new_hi), n, _p(new_blocks), _p(src),
+                                   _p(needed), 0, None, None, None, None, None)
+    if got != n:
+        _l.check(int(min(got, -1)), "amr_regrid_local")
+    return new_blocks.astype(np.int64), src, needed.astype(bool)
+
+
+def regrid_local_compute(blocks, states, level_max, new_lo, new_hi, n_new, slot_of_old, fields, bpdx=1, bpdy=1):
+    """cup2d_amr_regrid_local, compute part: fields {name: (compact array (nslots, 64 * dim), dim, is_vector)} hold old block k at
+    row slot_of_old[k]; returns {name: array (new_hi - new_lo, 64 * dim)} with the prolonged / restricted blocks of the range
+    written (the rows of unchanged copies are left as NaN: the caller moves those)."""
+    b32 = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 3)
+    st = np.ascontiguousarray(states, dtype=np.int32)
+    slot = np.ascontiguousarray(slot_of_old, dtype=np.int32)
+    L, nb = _l.load_library(), len(b32)
+    names = list(fields)
+    src = [np.ascontiguousarray(fields[k][0], dtype=np.float64) for k in names]
+    dims = np.array([fields[k][1] for k in names], dtype=np.int32)
+    vec = np.array([1 if fields[k][2] else 0 for k in names], dtype=np.int32)
+    vp = ctypes.c_void_p
+    srcp = (vp * max(len(names), 1))(*[a.ctypes.data for a in src])
+    dst = [np.full((int(new_hi - new_lo), BS * BS * int(d)), np.nan) for d in dims]
+    dstp = (vp * max(len(names), 1))(*[a.ctypes.data for a in dst])
+    new_blocks = np.empty((int(n_new), 3), dtype=np.int32)
+    got = L.cup2d_amr_regrid_local(nb, _p(b32), bpdx, bpdy, level_max, _p(st), int(new_lo), int(new_hi), int(n_new), _p(new_blocks),
+                                   None, None, len(names), srcp, _p(slot), _p(dims), _p(vec), dstp)
+    if got != n_new:
+        _l.check(int(min(got, -1)), "amr_regrid_local")
+    return dict(zip(names, dst))
+
+
 def regrid_plan(blocks, states, level_max, bpdx=1, bpdy=1):
     """cup2d_amr_regrid_plan: (new_blocks (n,3), src_of_new (n,) old block of an unchanged copy or -1, needed_old (nb,) bool:
     the old blocks the prolonged / restricted blocks are computed from)"""

@@ -13,9 +13,10 @@ coarse-fine labs 2582-2684, flux faces 1819-1825).  Here the same partition is p
                  global leaf list (no negotiation round: the lists are deterministic), as the reference's Setup() does
                  from its tree.
   DistributedAmrSimulation   the device context of one rank on that plan; same block operators as AmrSimulation on
-                 the owned blocks.  Regridding gathers the fields of all ranks (regrid-time work, every AdaptSteps
-                 steps), regrids the global list on every rank with the library's host routines and re-partitions:
-                 the new ranges ARE the load balance, a block that changes range has migrated.
+                 the owned blocks.  Regridding (every AdaptSteps steps): tags and the leaf list are replicated (8 + 12 bytes
+                 per block), the FIELDS are not -- the new list is cut into contiguous ranges (the load balance: a block
+                 whose range changes has migrated) and every rank fetches what its new range is made of from the old
+                 owners and computes its own prolonged / restricted blocks (fetch_new_range, cup2d_amr_regrid_local).
 
 The device side needs nothing AMR-specific for the exchange: ghost blocks travel whole through the face-strip kernels
 (a strip of width 8 is the block), the kernels of csrc/amr.hip read them through the same tables as owned blocks.
@@ -235,14 +236,50 @@ class DistributedAmrSimulation(AmrSimulation):
         """per-block array of the owned blocks -> the same array for all leaves, on every rank"""
         import torch.distributed as dist
         parts = [None] * self.world
-        dist.all_gather_object(parts, np.ascontiguousarray(a))
+        dist.all_gather_object(parts, np.ascontiguousarray(a), group=self._ctl_group())
         return np.concatenate(parts, axis=0)
 
-    def adapt(self, rtol, ctol, level_max):
-        """adapt() of main.cpp:4657-5440 on N ranks: tags from this rank's blocks (vorticity on the GPU), gathered; the
-        validated states, prolongation / restriction and the new leaf list are computed on every rank from the gathered
-        fields with the library's host routines (regrid-time work); the new contiguous ranges re-balance the load --
-        blocks that change range have migrated (main.cpp:5055-5424).  Returns True if the grid changed."""
+    def _ctl_group(self):
+        """host-side messages of a regrid (tags, block requests, migrating blocks): a gloo group -- the default one, or a
+        second group next to an nccl default (created once, collectively: every rank regrids at the same step)"""
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":
+            return None
+        if _CTL.get("group") is None:
+            _CTL["group"] = dist.new_group(backend="gloo")
+        return _CTL["group"]
+
+    FIELDS = (("chi", _l.CHI), ("vel", _l.VEL), ("vold", _l.VOLD), ("pres", _l.PRES), ("pold", _l.POLD))
+    UNIT = 64 * (1 + 2 + 2 + 1 + 1)  # doubles of one migrating block: 448 (the reference moves 1040-byte
+    #                                                      MPI_Blocks per field, main.cpp:5198-5424; here one message unit)
+
+    def _download_units(self, local_blocks):
+        """[n][UNIT]: the five fields of the listed owned blocks, field after field"""
+        n = len(local_blocks)
+        out = np.empty((n, self.UNIT))
+        idx = np.ascontiguousarray(local_blocks, dtype=np.int32)
+        o = 0
+        for _, f in self.FIELDS:
+            w = 64 * _l.FIELD_DIM[f]
+            buf = np.empty((n, w))
+            if n:
+                _l.check(self.L.cup2d_download_blocks(self._ctx, f, n, idx.ctypes.data_as(ctypes.c_void_p), buf.ctypes.data_as(ctypes.c_void_p)),
+                         "download_blocks")
+            out[:, o:o + w] = buf
+            o += w
+        return out
+
+    def adapt(self, rtol, ctol, level_max, gather_all=False):
+        """adapt() of main.cpp:4657-5440 on N ranks.  Tags: max|vorticity| of this rank's blocks (GPU), one double per block
+        gathered; the states are validated and the new leaf list is derived on every rank from the (replicated, 12 bytes per
+        block) leaf list -- deterministic, no negotiation rounds.  The FIELDS are not gathered: the new list is cut into
+        contiguous ranges again (the load balance: a block whose range changes has migrated, main.cpp:5055-5424), and a rank
+        fetches exactly what its new range is made of -- the unchanged blocks it did not own before (whole blocks from their old
+        owners) and the old blocks its prolonged / restricted blocks are computed from (cup2d_amr_regrid_local's needed_old:
+        refined parents with their 3 x 3 neighbourhood, compressing siblings -- the reference gathers siblings on one rank the
+        same way, 5120-5130).  Unchanged blocks that stay on the rank move between the old and the new context on the device.
+        gather_all: the round-2 form (every field of every rank to every rank) -- the cross-check of the tests.
+        Returns True if the grid changed; self.regrid_stats says what moved."""
         self.vorticity()
         linf = np.empty(self.part.nowned)
         _l.check(self.L.cup2d_block_linf(self._ctx, _l.TMP, linf.ctypes.data_as(ctypes.c_void_p)), "block_linf")
@@ -251,18 +288,125 @@ class DistributedAmrSimulation(AmrSimulation):
         st = validate_states(G.blocks, tag_states(linf, G.level, rtol, ctol, level_max), level_max, G.bpdx, G.bpdy)
         if not (st != LEAVE).any():
             return False
-        names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
-        fields = {}
-        for k, f in names.items():
-            a = self._allgather_blocks(self.get_field(f).reshape(self.part.nowned, -1))
-            fields[k] = (a, _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2)
-        blocks, data = regrid(G.blocks, st, fields, level_max, G.bpdx, G.bpdy)
-        new_grid = AmrBlockGrid(blocks, G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
-        self.close()
-        self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, comm=self._comm_kind, mode=self._comm_mode,
-                      group=self._group, adapt_steps=self.adapt_steps)
-        lo, hi = self.part.lo, self.part.hi
-        for k, f in names.items():
-            self.set_field(f, data[k][lo:hi])
+        names = dict(self.FIELDS)
+        if gather_all:
+            fields = {}
+            for k, f in names.items():
+                a = self._allgather_blocks(self.get_field(f).reshape(self.part.nowned, -1))
+                fields[k] = (a, _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2)
+            blocks, data = regrid(G.blocks, st, fields, level_max, G.bpdx, G.bpdy)
+            new_grid = AmrBlockGrid(blocks, G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
+            self.close()
+            self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, comm=self._comm_kind, mode=self._comm_mode,
+                          group=self._group, adapt_steps=self.adapt_steps)
+            lo, hi = self.part.lo, self.part.hi
+            for k, f in names.items():
+                self.set_field(f, data[k][lo:hi])
+            self.install_poisson_matrix()
+            return True
+        # ---- what this rank's new range is made of: fetched from the old owners, the changed blocks computed ----
+        old, rank = self.part, self.rank
+        R = fetch_new_range(G, old, st, level_max, rank, self.world, lambda ids: self._download_units(ids), self._ctl_group(),
+                            self.FIELDS)
+        new_blocks, n_new, lo, hi, my_src, kept, slot, comp, data = (R[k] for k in ("new_blocks", "n_new", "lo", "hi", "my_src", "kept",
+                                                                                   "slot", "comp", "data"))
+        self.regrid_stats = R["stats"]
+        # ---- the new context; what stays on this rank unchanged moves on the device ----
+        new_grid = AmrBlockGrid(new_blocks, G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
+        old_ctx, old_lo = self._ctx, old.lo
+        old_owner_of_src = R["old_owner_of_src"]
+        self._ctx = ctypes.c_void_p()  # (the old context lives on until its blocks have been copied over)
+        vp = ctypes.c_void_p
+        try:
+            self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, comm=self._comm_kind, mode=self._comm_mode,
+                          group=self._group, adapt_steps=self.adapt_steps)
+            stay = kept & (old_owner_of_src == rank)
+            dst_dev = np.ascontiguousarray(np.flatnonzero(stay), dtype=np.int32)
+            src_dev = np.ascontiguousarray(my_src[stay] - old_lo, dtype=np.int32)
+            up_idx = np.ascontiguousarray(np.flatnonzero(~stay), dtype=np.int32)
+            for k, f in self.FIELDS:
+                if len(dst_dev):
+                    _l.check(self.L.cup2d_copy_blocks(self._ctx, old_ctx, f, len(dst_dev), dst_dev.ctypes.data_as(vp), src_dev.ctypes.data_as(vp)),
+                             "copy_blocks")
+                if len(up_idx):
+                    rows = data[k][up_idx]
+                    moved = kept[up_idx]                       # unchanged blocks that migrated here: their received copy
+                    if moved.any():
+                        rows[moved] = comp[k][0][slot[my_src[up_idx[moved]]]]
+                    if np.isnan(rows).any():
+                        raise RuntimeError("regrid: field %s of a new block was not produced (plan and data disagree)" % k)
+                    rows = np.ascontiguousarray(rows)
+                    _l.check(self.L.cup2d_upload_blocks(self._ctx, f, len(up_idx), up_idx.ctypes.data_as(vp), rows.ctypes.data_as(vp)),
+                             "upload_blocks")
+        finally:
+            self.L.cup2d_destroy(old_ctx)
         self.install_poisson_matrix()
         return True
+
+
+FIELDS = (("chi", _l.CHI), ("vel", _l.VEL), ("vold", _l.VOLD), ("pres", _l.PRES), ("pold", _l.POLD))
+
+
+def fetch_new_range(G, old, st, level_max, rank, world, download_units, group, fields=FIELDS):
+    """The data side of a regrid on N ranks (main.cpp:5055-5424) for ONE rank: the new leaf list is cut into contiguous
+    ranges; this rank fetches exactly what its new range [lo, hi) is made of -- unchanged blocks it did not own (whole
+    blocks from their old owners: migration) and the old blocks its prolonged / restricted blocks are computed from
+    (cup2d_amr_regrid_local's needed_old) -- and computes its changed blocks.  G: the old global grid (leaf list on every
+    rank), old: this rank's AmrPartition of it, st: the validated states (the same on every rank), download_units(local old
+    block indices) -> [n][UNIT] the rank's own block data, field after field (the device in production, numpy in the CPU
+    tests), group: a gloo process group (or None: the default one).  Nothing outside `want` is read or received."""
+    import torch
+    import torch.distributed as dist
+    from .amr import regrid_local_plan, regrid_local_compute
+    unit = sum(64 * _l.FIELD_DIM[f] for _, f in fields)
+    nb_old = G.nblocks
+    n_new = regrid_local_plan(G.blocks, st, level_max, 0, 0, G.bpdx, G.bpdy)
+    nbounds = partition_bounds(n_new, world)
+    lo, hi = int(nbounds[rank]), int(nbounds[rank + 1])
+    new_blocks, src, needed = regrid_local_plan(G.blocks, st, level_max, lo, hi, G.bpdx, G.bpdy, n_new=n_new)
+    my_src = src[lo:hi]
+    kept = my_src >= 0
+    want = np.union1d(np.flatnonzero(needed), my_src[kept]).astype(np.int64)  # old blocks (global ids) this rank reads
+    owner = old.owner[want]
+    remote = want[owner != rank]
+    # ---- who needs what from whom: the request lists travel (ids only), then the blocks ----
+    reqs = [None] * world
+    dist.all_gather_object(reqs, remote, group=group)
+    send_ids = [np.asarray([g for g in reqs[p] if old.lo <= g < old.hi], dtype=np.int64) if p != rank else np.zeros(0, np.int64)
+                for p in range(world)]
+    recv_ids = [remote[old.owner[remote] == p] for p in range(world)]
+    ops, keep, recv_buf = [], [], {}
+    for p in range(world):
+        if len(send_ids[p]):
+            t = torch.from_numpy(np.ascontiguousarray(download_units(send_ids[p] - old.lo)))
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, p, group=group))
+        if len(recv_ids[p]):
+            recv_buf[p] = torch.empty((len(recv_ids[p]), unit), dtype=torch.float64)
+            ops.append(dist.P2POp(dist.irecv, recv_buf[p], p, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    # ---- compact arrays of what this rank holds now: needed blocks of its own + everything that arrived ----
+    local_need = want[owner == rank]
+    local_need = local_need[needed[local_need]]          # own blocks that are only COPIED stay where they are
+    held = np.concatenate([local_need] + [recv_ids[p] for p in range(world) if len(recv_ids[p])]).astype(np.int64)
+    units = np.concatenate([download_units(local_need - old.lo).reshape(-1, unit)] +
+                           [recv_buf[p].numpy() for p in range(world) if len(recv_ids[p])])
+    slot = -np.ones(nb_old, dtype=np.int32)
+    slot[held] = np.arange(len(held), dtype=np.int32)
+    comp, o = {}, 0
+    for k, f in fields:
+        w = 64 * _l.FIELD_DIM[f]
+        comp[k] = (np.ascontiguousarray(units[:, o:o + w]), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2)
+        o += w
+    data = regrid_local_compute(G.blocks, st, level_max, lo, hi, n_new, slot, comp, G.bpdx, G.bpdy)
+    stats = dict(old_blocks=nb_old, new_blocks=int(n_new), owned_before=old.nowned, owned_after=hi - lo,
+                 blocks_received=int(sum(len(r) for r in recv_ids)), blocks_sent=int(sum(len(x) for x in send_ids)),
+                 own_blocks_downloaded=int(len(local_need)), changed_blocks_computed=int((~kept).sum()),
+                 host_blocks_held=int(len(held)))
+    return dict(new_blocks=new_blocks, n_new=n_new, lo=lo, hi=hi, my_src=my_src, kept=kept, slot=slot, comp=comp, data=data,
+                stats=stats, old_owner_of_src=old.owner[np.maximum(my_src, 0)])
+
+
+_CTL = {}

@@ -384,18 +384,21 @@ bool bad_grid_args(int nblocks, const int32_t *blocks, int bpdx, int bpdy, const
 enum { LEAVE = 0, REFINE = 1, COMPRESS = 2 };
 
 // the tensorial halo-1 tile (10 x 10 x dim, row-major, components interleaved) of block b
-void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, double *T) {
+// slot (may be NULL): block k's data lie at f + slot[k] * 64 * dim -- a rank that holds only the blocks it needs keeps them
+// in a compact array (cup2d_amr_regrid_local); without it block k is at index k
+void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, double *T, const int32_t *slot = nullptr) {
   constexpr int BS = CUP2D_BS, W = BS + 2;
+  const auto SL = [&](int k) -> size_t { return (size_t)(slot ? slot[k] : k); };
   const double nan = std::numeric_limits<double>::quiet_NaN();
   const int l = L.level(b), i0 = L.bi(b), j0 = L.bj(b);
   const auto at = [&](int ix, int iy, int d) -> double & { return T[((iy + 1) * W + ix + 1) * dim + d]; };
   for (int c = 0; c < BC; c++)
-    for (int d = 0; d < dim; d++) at(c & 7, c >> 3, d) = f[((size_t)b * BC + c) * dim + d];
+    for (int d = 0; d < dim; d++) at(c & 7, c >> 3, d) = f[(SL(b) * BC + c) * dim + d];
   // sides: the closed forms the kernels use
   for (int s = 0; s < 4; s++) {
     const Side S = side_of(L, b, s);
     for (int d = 0; d < dim; d++) {
-      const auto get = [&](int blk, int cell) { return f[((size_t)blk * BC + cell) * dim + d]; };
+      const auto get = [&](int blk, int cell) { return f[(SL(blk) * BC + cell) * dim + d]; };
       const double sign = (vector && d == (s < 2 ? 0 : 1)) ? -1.0 : 1.0;
       for (int q = 0; q < BS; q++) {
         const int gx = s == 0 ? -1 : s == 1 ? BS : q, gy = s == 2 ? -1 : s == 3 ? BS : q;
@@ -409,11 +412,11 @@ void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, d
   // a leaf of that level, or the 2 x 2 mean of a leaf of level l (UseCoarseStencil0 / FillCoarseVersion 2934-2996)
   const auto coarse0 = [&](int GX, int GY) -> double {
     int k = L.find(l - 1, GX >> 3, GY >> 3);
-    if (k >= 0) return f[((size_t)k * BC + (GY & 7) * BS + (GX & 7)) * dim];
+    if (k >= 0) return f[(SL(k) * BC + (GY & 7) * BS + (GX & 7)) * dim];
     k = L.find(l, GX >> 2, GY >> 2);
     if (k < 0) return nan;
     const int x = 2 * (GX & 3), y = 2 * (GY & 3);
-    const auto q = [&](int yy, int xx) { return f[((size_t)k * BC + yy * BS + xx) * dim]; };
+    const auto q = [&](int yy, int xx) { return f[(SL(k) * BC + yy * BS + xx) * dim]; };
     return (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
   };
   const int NX = L.bpdx << l, NY = L.bpdy << l;
@@ -434,7 +437,7 @@ void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, d
       int k = L.find(l, ni, nj);
       if (k >= 0) {
         const int cell = (cy < 0 ? BS - 1 : 0) * BS + (cx < 0 ? BS - 1 : 0);
-        for (int d = 0; d < dim; d++) at(gx, gy, d) = f[((size_t)k * BC + cell) * dim + d];
+        for (int d = 0; d < dim; d++) at(gx, gy, d) = f[(SL(k) * BC + cell) * dim + d];
       } else if (l > 0 && L.find(l - 1, ni >> 1, nj >> 1) >= 0) {
         // second-order Taylor expansion about the coarse cell under the ghost (TestInterp 2219-2230); the reference
         // hands it component 0 for every component (2753-2763) -- kept
@@ -454,7 +457,7 @@ void halo1_tile(const Leaves &L, const double *f, int dim, bool vector, int b, d
         k = L.find(l + 1, 2 * i0 + (cx > 0 ? 2 : -1), 2 * j0 + (cy > 0 ? 2 : -1));
         const int x = cx < 0 ? BS - 2 : 0, y = cy < 0 ? BS - 2 : 0;
         for (int d = 0; d < dim; d++) {
-          const auto q = [&](int yy, int xx) { return f[((size_t)k * BC + yy * BS + xx) * dim + d]; };
+          const auto q = [&](int yy, int xx) { return f[(SL(k < 0 ? b : k) * BC + yy * BS + xx) * dim + d]; };
           at(gx, gy, d) = k < 0 ? nan : (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
         }
       }
@@ -613,10 +616,14 @@ extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int
 // the coarse cells TestInterp looks at), the compressing siblings.  changed_only: unchanged copies are NOT written to
 // new_fields and of `fields` only the needed blocks are read (a host that keeps the fields on the device moves the
 // unchanged blocks there, cup2d_copy_blocks).
+// Ranged form (cup2d_amr_regrid_local): only the new blocks at positions [new_lo, new_hi) of the new leaf list count --
+// needed_old names what THEY are computed from, only they are written, to new_fields[f] + (position - new_lo) * 64 * dim, and
+// `fields` are compact arrays addressed through slot_of_old (halo1_tile).  new_hi < 0: everything, positions as indices.
 static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *st,
                              int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
                              long long cap, int32_t *new_blocks, double *const *new_fields, int32_t *src_of_new,
-                             int32_t *needed_old, bool changed_only) {
+                             int32_t *needed_old, bool changed_only, long long new_lo = 0, long long new_hi = -1,
+                             const int32_t *slot_of_old = nullptr) {
   if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid")) return CUP2D_ERR_ARG;
   if (!st || nfields < 0 || (nfields && (!fields || !dims || !is_vector))) {
     cup2d::set_error("amr_regrid: bad argument");
@@ -684,12 +691,23 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
     new_blocks[3 * p + 2] = b.j;
     if (src_of_new) src_of_new[p] = b.part == -1 ? b.src : -1;
   }
+  const bool ranged = new_hi >= 0;
+  if (ranged && (new_lo < 0 || new_hi > n_new || new_lo > new_hi)) {
+    cup2d::set_error("amr_regrid: range [%lld, %lld) of %lld new blocks", new_lo, new_hi, n_new);
+    return CUP2D_ERR_ARG;
+  }
+  const auto in_range = [&](size_t produced) { return !ranged || (where[produced] >= new_lo && where[produced] < new_hi); };
   if (needed_old) {
     std::fill(needed_old, needed_old + nblocks, 0);
-    for (int k = 0; k < nblocks; k++) {
-      if (st[k] == COMPRESS) needed_old[k] = 1;
-      if (st[k] != REFINE) continue;
-      const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+    for (size_t p = 0; p < nb.size(); p++) {
+      const New &b = nb[p];
+      if (b.part == -1 || !in_range(p)) continue;
+      const int k = b.src, l = L.level(k), i = L.bi(k), j = L.bj(k);
+      if (b.part == 4) {  // the parent of four compressing siblings
+        for (int a = 0; a < 4; a++) needed_old[L.find(l, i + (a & 1), j + (a >> 1))] = 1;
+        continue;
+      }
+      // a child of the refined block k: k and every leaf overlapping its 3 x 3 block neighbourhood
       for (int dj = -1; dj <= 1; dj++)
         for (int di = -1; di <= 1; di++) {
           const int x = i + di, y = j + dj;
@@ -714,17 +732,20 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
     const double *f = fields[fi];
     double *g = new_fields[fi];
     const size_t bsz = (size_t)BC * dim;
+    const auto SL = [&](int k) -> size_t { return (size_t)(slot_of_old ? slot_of_old[k] : k); };
+    const auto out = [&](size_t produced) { return g + (size_t)(where[produced] - (ranged ? new_lo : 0)) * bsz; };
     parallel_chunks((long long)nb.size(), 256, [&](long long p_lo, long long p_hi, int) {
     for (long long p = p_lo; p < p_hi; p++) {
       const New &b = nb[p];
       if (b.part == -1) {
-        if (!changed_only) std::copy(f + b.src * bsz, f + (b.src + 1) * bsz, g + where[p] * bsz);
+        if (!changed_only && in_range(p)) std::copy(f + SL(b.src) * bsz, f + (SL(b.src) + 1) * bsz, out(p));
       } else if (b.part == 4) {  // mean of the 2 x 2 cells of the four siblings (main.cpp:5149-5166)
+        if (!in_range(p)) continue;
         const int l = L.level(b.src), i = L.bi(b.src), j = L.bj(b.src);
-        double *o = g + where[p] * bsz;
+        double *o = out(p);
         for (int J = 0; J < 2; J++)
           for (int I = 0; I < 2; I++) {
-            const double *kid = f + (size_t)L.find(l, i + I, j + J) * bsz;
+            const double *kid = f + SL(L.find(l, i + I, j + J)) * bsz;
             for (int y = 0; y < BS / 2; y++)
               for (int x = 0; x < BS / 2; x++)
                 for (int d = 0; d < dim; d++) {
@@ -734,10 +755,12 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
                 }
           }
       } else if (b.part == 0) {  // the four children are produced consecutively: prolong once
+        if (!(in_range(p) || in_range(p + 1) || in_range(p + 2) || in_range(p + 3))) continue;
         double T[(BS + 2) * (BS + 2) * 2], kids[4 * BC * 2];
-        halo1_tile(L, f, dim, is_vector[fi] != 0, b.src, T);
+        halo1_tile(L, f, dim, is_vector[fi] != 0, b.src, T, slot_of_old);
         prolong(T, dim, kids);
-        for (int c = 0; c < 4; c++) std::copy(kids + c * bsz, kids + (c + 1) * bsz, g + where[p + c] * bsz);
+        for (int c = 0; c < 4; c++)
+          if (in_range(p + c)) std::copy(kids + c * bsz, kids + (c + 1) * bsz, out(p + c));
       }
     }
     });
@@ -757,6 +780,22 @@ extern "C" long long cup2d_amr_regrid_plan(int nblocks, const int32_t *blocks, i
                                            int32_t *needed_old) {
   return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, 0, nullptr, nullptr, nullptr, cap, new_blocks, nullptr, src_of_new,
                      needed_old, true);
+}
+extern "C" long long cup2d_amr_regrid_local(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
+                                            const int32_t *st, long long new_lo, long long new_hi, long long cap,
+                                            int32_t *new_blocks, int32_t *src_of_new, int32_t *needed_old, int nfields,
+                                            const double *const *fields, const int32_t *slot_of_old, const int32_t *dims,
+                                            const int32_t *is_vector, double *const *new_fields) {
+  if (new_hi < 0) {
+    cup2d::set_error("amr_regrid_local: range [%lld, %lld)", new_lo, new_hi);
+    return CUP2D_ERR_ARG;
+  }
+  if (nfields > 0 && !slot_of_old) {
+    cup2d::set_error("amr_regrid_local: slot_of_old is required with fields");
+    return CUP2D_ERR_ARG;
+  }
+  return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, nfields, fields, dims, is_vector, cap, new_blocks, new_fields,
+                     src_of_new, needed_old, true, new_lo, new_hi, slot_of_old);
 }
 extern "C" long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max,
                                               const int32_t *st, int nfields, const double *const *fields,

@@ -12,7 +12,7 @@
 // edge cells of z -- the own block's at a wall, the neighbour block's otherwise.  Only the 32 edge entries (4 sides x 8) of
 // z are ever needed: the dense 64 x 64 product per block shrinks to 64 x 32 (half the MFMAs), the 5-point stencil over the
 // tile disappears, and the result differs from the full form by the round-off of L (P_inv v) - v, a few 1e-15 |v|
-// (tests/test_solver_variants_gpu.py pins both forms to the oracle and to each other).  Needs the built-in P_inv
+// (tests/test_solver_variants_gpu.py pins both forms to the CPU restatement of the reference and to each other).  Needs the built-in P_inv
 // (!custom_Pinv); any other preconditioner takes the full form.
 //
 // Sharing.  A tile still needs the z edges of the blocks around it.  The full form recomputes every one of them from the

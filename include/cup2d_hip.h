@@ -309,6 +309,19 @@ long long cup2d_amr_regrid_plan(int nblocks, const int32_t *blocks, int bpdx, in
 long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
                                    int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
                                    long long cap, int32_t *new_blocks, double *const *new_fields);
+/* The same for ONE RANK of a partitioned leaf list (a contiguous range of the new list per rank, main.cpp:6494-6504): only the
+ * new blocks at positions [new_lo, new_hi) count.  Plan outputs (each may be NULL): new_blocks[cap][3] -- the whole new leaf
+ * list, every rank derives the same one --, src_of_new[cap] as above, needed_old[nblocks] = 1 for the old blocks the prolonged /
+ * restricted blocks OF THE RANGE are computed from.  With nfields > 0 the changed blocks of the range are computed:
+ * fields[f] are COMPACT arrays holding just the blocks this rank fetched -- old block k at fields[f] + slot_of_old[k] * 64 *
+ * dims[f] -- and new_fields[f][new_hi - new_lo][64 * dims[f]] receives the prolonged / restricted blocks at (position -
+ * new_lo); unchanged copies are not written (src_of_new says where they come from: the caller moves them, on the device or
+ * between ranks).  Replaces the per-rank refine / compress of main.cpp:5055-5130 and the data side of its block migration
+ * (5198-5424): no rank reads a block outside its needed_old and src_of_new sets. */
+long long cup2d_amr_regrid_local(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
+                                 long long new_lo, long long new_hi, long long cap, int32_t *new_blocks, int32_t *src_of_new,
+                                 int32_t *needed_old, int nfields, const double *const *fields, const int32_t *slot_of_old,
+                                 const int32_t *dims, const int32_t *is_vector, double *const *new_fields);
 int cup2d_download_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, double *host);
 int cup2d_upload_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, const double *host);
 int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks);

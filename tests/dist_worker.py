@@ -293,6 +293,60 @@ def run_amr_cpu(rank, world):
     dist.barrier()
 
 
+def run_amr_regrid_cpu(rank, world):
+    """The data side of a regrid on N ranks without a device (cup2d_amd/amr_dist.py fetch_new_range; gloo): the fields of a
+    4 084-block grid live in numpy arrays of the OWNED blocks only; every rank fetches what its new range is made of from
+    the old owners (requests by id, whole blocks back), computes its prolonged / restricted blocks with
+    cup2d_amr_regrid_local on compact arrays, and ends up with exactly the blocks of the single-process regrid on its new
+    range, bit for bit -- and nobody ever held more than its own share plus what the plan names."""
+    import torch.distributed as dist
+    from cup2d_amd import lib as L
+    from cup2d_amd import amr as A
+    from cup2d_amd.amr_dist import AmrPartition, fetch_new_range, FIELDS, partition_bounds
+    G = A.circle_band_grid(7)
+    nb = G.nblocks
+    rng = np.random.default_rng(5)          # the same global fields on every rank (only the owned slice is "on the device")
+    glob = {k: rng.uniform(-1, 1, (nb, 64 * L.FIELD_DIM[f])) for k, f in FIELDS}
+    for seed, frac in ((1, 0.1), (2, 0.5)):
+        tag = np.random.default_rng(seed)
+        st = np.where(tag.uniform(0, 1, nb) < frac, A.REFINE, np.where(tag.uniform(0, 1, nb) < 0.5, A.COMPRESS, A.LEAVE)).astype(np.int32)
+        st = A.validate_states(G.blocks, st, 9, G.bpdx, G.bpdy)
+        assert (st == A.REFINE).any()
+        P = AmrPartition(G, world, rank)
+        fetched = []
+
+        def download_units(ids, P=P, fetched=fetched):
+            ids = np.asarray(ids, dtype=np.int64)
+            assert ((ids >= 0) & (ids < P.nowned)).all(), "a block this rank does not own was asked of it"
+            fetched.append(len(ids))
+            return np.concatenate([glob[k][P.lo + ids] for k, _ in FIELDS], axis=1) if len(ids) else np.zeros((0, 448))
+
+        R = fetch_new_range(G, P, st, 9, rank, world, download_units, None)
+        full_blocks, full = A.regrid(G.blocks, st, {k: (glob[k], L.FIELD_DIM[f], L.FIELD_DIM[f] == 2) for k, f in FIELDS}, 9, G.bpdx, G.bpdy)
+        lo, hi = R["lo"], R["hi"]
+        assert np.array_equal(R["new_blocks"], full_blocks)
+        assert np.array_equal(partition_bounds(len(full_blocks), world)[rank:rank + 2], [lo, hi])
+        src, kept, slot = R["my_src"], R["kept"], R["slot"]
+        for k, _ in FIELDS:
+            rows = R["data"][k].copy()
+            for q in np.flatnonzero(kept):
+                o = int(src[q])
+                rows[q] = glob[k][o] if P.lo <= o < P.hi else R["comp"][k][0][slot[o]]   # stays on the device | migrated here
+            assert np.array_equal(rows, full[k][lo:hi]), (k, rank, seed)
+        stt = R["stats"]
+        assert stt["host_blocks_held"] == stt["blocks_received"] + stt["own_blocks_downloaded"]
+        tot = [None] * world
+        dist.all_gather_object(tot, stt)
+        moved = sum(t["blocks_received"] for t in tot)
+        assert moved == sum(t["blocks_sent"] for t in tot)
+        if frac < 0.2:  # a regrid that touches a tenth of the grid moves a fraction of it
+            assert moved < 0.6 * nb and max(t["host_blocks_held"] for t in tot) < 0.6 * nb, tot
+        if rank == 0:
+            print("amr_regrid_cpu: %d -> %d blocks on %d ranks, %d blocks moved between ranks, at most %d held on a host"
+                  % (nb, len(full_blocks), world, moved, max(t["host_blocks_held"] for t in tot)), flush=True)
+    dist.barrier()
+
+
 def run_amr_big_gpu(rank, world):
     """the same on a grid of 4 084 blocks (three levels, a band around a circle, Hilbert order): the single context on the
     whole grid is the reference here -- every block operator on a rank's owned blocks bit for bit, a step to the solve
@@ -349,10 +403,14 @@ def run_amr_big_gpu(rank, world):
         rt, ct = float(np.quantile(om, 0.9)), float(np.quantile(om, 0.3))
         changed_ref = ref.adapt(rt, ct, 8)
         blocks_ref, vel_ref = ref.grid.blocks.copy(), ref.get_field(L.VEL)
-        changed = s.adapt(rt, ct, 8)
+        changed = s.adapt(rt, ct, 8)   # per-rank regrid + block migration (fetch_new_range)
         assert changed and changed_ref
         assert np.array_equal(s.global_grid.blocks, blocks_ref)
         assert np.array_equal(s.get_field(L.VEL), vel_ref[s.part.lo:s.part.hi])
+        stt = s.regrid_stats
+        assert stt["host_blocks_held"] < 0.6 * nb, stt   # nobody gathered the grid
+        if rank == 0:
+            print("amr_big regrid stats (rank 0):", stt, flush=True)
         counts = [None] * world
         dist.all_gather_object(counts, s.part.nowned)
         assert max(counts) - min(counts) <= 1 and sum(counts) == len(blocks_ref)
@@ -370,8 +428,8 @@ def main():
     px, py, nbx, nby = (int(a) for a in sys.argv[2:6])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode in ("amr", "amr_big", "amr_cpu"):
-        {"amr": run_amr_gpu, "amr_big": run_amr_big_gpu, "amr_cpu": run_amr_cpu}[mode](rank, world)
+    if mode in ("amr", "amr_big", "amr_cpu", "amr_regrid_cpu"):
+        {"amr": run_amr_gpu, "amr_big": run_amr_big_gpu, "amr_cpu": run_amr_cpu, "amr_regrid_cpu": run_amr_regrid_cpu}[mode](rank, world)
         if rank == 0:
             print("DIST_OK mode=%s world=%d" % (mode, world))
         dist.destroy_process_group()

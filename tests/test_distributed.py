@@ -92,6 +92,14 @@ def test_amr_whole_block_exchange_cpu_gloo(world):
     launch("amr_cpu", world, 0, 0, 0, 0, 29851 + world)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_amr_regrid_on_n_ranks_moves_only_what_the_plan_names_cpu_gloo(world):
+    """per-rank regrid + block migration (amr_dist.fetch_new_range, cup2d_amr_regrid_local) with numpy standing in for the
+    device: every rank's new range equals the single-process regrid bit for bit; no rank is asked for a block it does not
+    own, and a regrid that touches a tenth of a 4 084-block grid moves a fraction of it"""
+    launch("amr_regrid_cpu", world, 0, 0, 0, 0, 29871 + world)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("px,py,comm", [(2, 1, "mpi"), (1, 2, "mpi"), (2, 2, "mpi"), (1, 1, "rccl")])
 def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py, comm):

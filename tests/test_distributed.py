@@ -168,7 +168,7 @@ def test_cpp_mpi_driver_amr_matches_the_single_rank_driver_gpu(tmp_path, world, 
     sn = [l.split() for l in out.splitlines() if l.startswith("step ")]
     assert len(s1) == len(sn) == 5
     for a, b in zip(s1, sn):
-        assert abs(float(a[5]) - float(b[5])) <= 1e-10 * float(a[5]) and a[11] == b[11], (a, b)   # dt, blocks
+        assert abs(float(a[5]) - float(b[5])) <= 1e-8 * float(a[5]) and a[11] == b[11], (a, b)   # dt (follows max|u| of the solves), blocks
     b1 = np.fromfile(tmp_path / "one.blocks.i32", dtype=np.int32).reshape(-1, 3)
     bn = np.fromfile(tmp_path / "n.blocks.i32", dtype=np.int32).reshape(-1, 3)
     assert len(b1) > 64 and set(map(tuple, b1.tolist())) == set(map(tuple, bn.tolist()))

@@ -607,6 +607,11 @@ def main():
                 best = max(sweep, key=lambda t: sweep[t][0])
                 r = sweep[best][1]
                 cpu = {"value": sweep[best][0], "unit": "Mcell-updates/s", "cores": r.get("threads", best), "kind": "reference",
+                       "thread_scaling_note": "the reference loop gets SLOWER beyond ~16 threads: its functors scale (OpenMP over blocks), "
+                                              "but the Poisson solve has no CPU path in the reference (cuda.cu is its only solver) and is "
+                                              "timed here as the serial CPU port of cuda.cu; with every hardware thread spinning in "
+                                              "OpenMP barriers around that serial part (and the per-thread BlockLab allocations of "
+                                              "computeA) the step time grows -- the best point of the sweep is the reported baseline",
                        "host_hardware_threads": cores, "thread_sweep_mcell_updates_per_s": {str(t): sweep[t][0] for t in sweep},
                        "sample": "reference main.cpp time loop (OpenMP functors; Poisson = CPU port of cuda.cu, %d iters) "
                                  "at %d^2, median of %d steps, best of the thread sweep" % (args.iters, args.cpu_n, r.get("timed_steps", 0))}

@@ -9,12 +9,14 @@
 //   (3) sets tmpV = sum of udef of the shapes that dominate a cell (the u_def of pressure_rhs) main.cpp:6979-7006
 // (collisions between shapes, main.cpp:6703-6943, are host logic on a handful of scalars and stay with the caller).
 // Here the bodies' block lists live on the device next to the fields; (2) and (3) are one kernel launch per body;
-// for (1) a kernel writes the seven integrands of every cell of the body's blocks and the HOST adds them up in the
-// reference's order (block by block, row by row) -- a few hundred blocks per body, and the sums, the 3 x 3 LU solve and
-// therefore u, v, omega are then bit-identical to the reference's single-threaded loop, whatever the GPU's reduction
-// order would have been.  No FMA contraction in this translation unit (-ffp-contract=off): every expression below keeps
+// for (1) a kernel writes the seven integrands of every cell of the body's blocks and a one-wave kernel adds them up in the
+// reference's order (block by block, row by row, one serial chain per integral: k_body_sums) -- a few hundred blocks per
+// body, and the sums, the 3 x 3 LU solve and therefore u, v, omega are bit-identical to the reference's single-threaded
+// loop; seven doubles per body cross PCIe (round 2 downloaded every integrand and summed on the host: CUP2D_BODY_SUM=host).  No FMA contraction in this translation unit (-ffp-contract=off): every expression below keeps
 // the reference's operation order.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -78,6 +80,31 @@ __global__ __launch_bounds__(WG) void k_body_terms(const double2 *__restrict__ v
 #pragma unroll
     for (int q = 0; q < 7; q++) dst[q] = t[q];
   }
+}
+
+// (1), the sums: the seven integrals of one body in the REFERENCE'S order -- block by block, row by row, one serial chain of
+// additions per integral (main.cpp:6649-6680) -- on the device.  One wave: a block's 64 x 7 integrands are staged in LDS with
+// coalesced loads (the next block's are in flight meanwhile), lanes 0..6 each add up one integral over the 64 cells in cell
+// order.  The order, and with it every bit of the sums, is the reference's single-threaded loop's; seven doubles leave the
+// device instead of seven per cell of every body block.
+__global__ __launch_bounds__(64) void k_body_sums(const double *__restrict__ terms, int nblk, double *__restrict__ sums) {
+  __shared__ double t[BC * 7];
+  const int lane = threadIdx.x;
+  double acc = 0.0, nxt[7];
+#pragma unroll
+  for (int q = 0; q < 7; q++) nxt[q] = nblk > 0 ? terms[q * BC + lane] : 0.0;
+  for (int k = 0; k < nblk; k++) {
+#pragma unroll
+    for (int q = 0; q < 7; q++) t[q * BC + lane] = nxt[q];  // t[j] = integrand (7 i + quantity) of cell i = j / 7
+    wave_lds_sync();
+    const int kn = k + 1 < nblk ? k + 1 : k;
+#pragma unroll
+    for (int q = 0; q < 7; q++) nxt[q] = terms[(size_t)kn * BC * 7 + q * BC + lane];
+    if (lane < 7)
+      for (int i = 0; i < BC; i++) acc += t[7 * i + lane];
+    wave_lds_sync();
+  }
+  if (lane < 7) sums[lane] = acc;
 }
 
 // (2) main.cpp:6944-6978 for one body: V = alpha V + (1 - alpha) (u_s - omega p_y + udef_x, v_s + omega p_x + udef_y)
@@ -217,18 +244,25 @@ int cup2d_body_momentum(cup2d_ctx *c, int body, double lambda, double dt, double
                        B.d_origin, B.d_chi, (const double2 *)B.d_udef, B.d_terms, B.nblk, B.cx, B.cy, lambda * dt, c->h, c->amr.h0,
                        c->amr.active ? c->amr.d_level : nullptr);
     CUP2D_HIP_CHECK(hipGetLastError());
-    CUP2D_HIP_CHECK(hipMemcpyAsync(B.h_terms.data(), B.d_terms, B.h_terms.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-    const double *t = B.h_terms.data();
-    for (size_t i = 0; i < (size_t)B.nblk * BC; i++)  // the reference's order: block by block, iy, ix (main.cpp:6649-6680)
-      for (int k = 0; k < 7; k++) q[k] += t[7 * i + k];
+    static const bool host_sum = [] { const char *e = getenv("CUP2D_BODY_SUM"); return e && !strcmp(e, "host"); }();
+    if (host_sum) {  // the round-2 form (cross-check): every integrand to the host, added up there in the same order
+      CUP2D_HIP_CHECK(hipMemcpyAsync(B.h_terms.data(), B.d_terms, B.h_terms.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+      const double *t = B.h_terms.data();
+      for (size_t i = 0; i < (size_t)B.nblk * BC; i++)  // the reference's order: block by block, iy, ix (main.cpp:6649-6680)
+        for (int k = 0; k < 7; k++) q[k] += t[7 * i + k];
+      CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_red, q, 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+      hipLaunchKernelGGL(k_body_sums, dim3(1), dim3(64), 0, c->stream, (const double *)B.d_terms, B.nblk, c->d_red);
+      CUP2D_HIP_CHECK(hipGetLastError());
+    }
+  } else {
+    CUP2D_HIP_CHECK(hipMemsetAsync(c->d_red, 0, 7 * sizeof(double), c->stream));
   }
-  if (c->allreduce) {  // MPI_Allreduce of the seven sums (main.cpp:6682-6684)
-    CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_red, q, 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (c->allreduce(c->comm_user, c->d_red, 7, 0, c->stream) != 0) return CUP2D_ERR_COMM;
-    CUP2D_HIP_CHECK(hipMemcpyAsync(q, c->d_red, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  }
+  // MPI_Allreduce of the seven sums (main.cpp:6682-6684): straight from the device buffer they were formed in
+  if (c->allreduce && c->allreduce(c->comm_user, c->d_red, 7, 0, c->stream) != 0) return CUP2D_ERR_COMM;
+  CUP2D_HIP_CHECK(hipMemcpyAsync(q, c->d_red, 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   const double PM = q[0], PJ = q[1], PX = q[2], PY = q[3];
   double A[3][3] = {{PM, 0, -PY}, {0, PM, PX}, {-PY, PX, PJ}};
   const double b[3] = {q[4], q[5], q[6]};

@@ -801,7 +801,13 @@ __global__ __launch_bounds__(WG) void k_sweepE_y(double2 *y0, double2 *y1, doubl
                                                  const double2 *__restrict__ t, const double2 *__restrict__ rhat,
                                                  KrylovScalars *sc, double *partials, size_t n2, double *red,
                                                  unsigned *ticket, int *host_status) {
-  if (sc->status != 0) return;
+  if (sc->status != 0) {
+    // the solve ended in an iteration that did not report to the host (solve_fused_impl: one report per GROUP of
+    // iterations): the group's last sweep E does, also when there is nothing left for it to compute
+    if (MERGE == 1 && host_status && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   const double alpha = sc->alpha, omega = sc->omega, momega = -sc->omega, malpha = -sc->alpha;
   const int cur = sc->ycur, out = y_out_buffer(cur, sc->ybest);
   const double2 *__restrict__ yin = cur == 0 ? y0 : (cur == 1 ? y1 : y2);
@@ -1102,13 +1108,23 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     const int v = e ? atoi(e) : 4;
     return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
   }();
+  // One GPU, finish in the kernel (merge 1): the host looks at the solve once per GROUP of iterations -- the event record and
+  // the system-scope store of the status word cost the stream 6 us of idle time between sweep E and the next AB
+  // (tools/kernel_gaps.py), per iteration in round 2.  The last sweep E of a group reports (also when the
+  // solve ended earlier in the group and its kernels returned at once); the host stays at most AHEAD groups in front, so at
+  // most AHEAD * GROUP iterations of early-returning kernels are wasted behind a solve that has ended.  CUP2D_SOLVE_GROUP.
+  static const int GROUP_ENV = [] { const char *e = getenv("CUP2D_SOLVE_GROUP"); return e ? atoi(e) : 4; }();
+  const int GROUP = merge == 1 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
+  const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
-  for (int k = 0; k <= max_iter + AHEAD; k++) {
-    const int slot = k % AHEAD;
-    if (k >= AHEAD) {
+  for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
+    const int grp = k / GROUP, slot = grp % AHEAD_G;
+    const bool first_of_group = k % GROUP == 0, last_of_group = k % GROUP == GROUP - 1;
+    if (first_of_group && grp >= AHEAD_G) {
       CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
       if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
+    int *const report = last_of_group ? &c->h_status[slot] : nullptr;
     c->prof_sample = (k % 8 == 0) && k < max_iter;
     double *p_in = (k & 1) ? c->d_p2 : c->d_p, *p_out = (k & 1) ? c->d_p : c->d_p2;
     double *nu_in = (k & 1) ? c->d_nu2 : c->d_nu, *nu_out = (k & 1) ? c->d_nu : c->d_nu2;
@@ -1138,8 +1154,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       const auto launchE = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(gridE), dim3(WG), 0, c->stream, (double2 *)c->d_y, (double2 *)c->d_yopt,
                            (double2 *)c->d_xopt, (const double2 *)p_out, (double2 *)c->d_r, (const double2 *)nu_out, (const double2 *)c->d_t,
-                           (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket,
-                           &c->h_status[slot]);
+                           (const double2 *)c->d_rhat, c->d_sc, c->d_partials, n / 2, c->d_red, c->d_ticket, report);
       };
       if (merge == 1) launchE(k_sweepE_y<1>);
       else if (merge == 2) launchE(k_sweepE_y<2>);
@@ -1147,10 +1162,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     }
     CUP2D_HIP_CHECK(hipGetLastError());
     if (gb) CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // the new r: in flight behind the reduction of E
-    if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
-    if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, &c->h_status[slot]));
+    if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, report));
+    if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, report));
     if (gb) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));
-    CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
+    if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));

@@ -372,8 +372,10 @@ def fetch_new_range(G, old, st, level_max, rank, world, download_units, group, f
     # ---- who needs what from whom: the request lists travel (ids only), then the blocks ----
     reqs = [None] * world
     dist.all_gather_object(reqs, remote, group=group)
-    send_ids = [np.asarray([g for g in reqs[p] if old.lo <= g < old.hi], dtype=np.int64) if p != rank else np.zeros(0, np.int64)
-                for p in range(world)]
+    send_ids = []
+    for p in range(world):
+        r = np.asarray(reqs[p], dtype=np.int64)
+        send_ids.append(r[(r >= old.lo) & (r < old.hi)] if p != rank else np.zeros(0, np.int64))
     recv_ids = [remote[old.owner[remote] == p] for p in range(world)]
     ops, keep, recv_buf = [], [], {}
     for p in range(world):

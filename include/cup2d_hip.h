@@ -311,7 +311,8 @@ long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx,
                                    long long cap, int32_t *new_blocks, double *const *new_fields);
 /* The same for ONE RANK of a partitioned leaf list (a contiguous range of the new list per rank, main.cpp:6494-6504): only the
  * new blocks at positions [new_lo, new_hi) count.  Plan outputs (each may be NULL): new_blocks[cap][3] -- the whole new leaf
- * list, every rank derives the same one --, src_of_new[cap] as above, needed_old[nblocks] = 1 for the old blocks the prolonged /
+ * list, every rank derives the same one; with new_blocks == NULL only the count is returned --, src_of_new[cap] as above,
+ * needed_old[nblocks] = 1 for the old blocks the prolonged /
  * restricted blocks OF THE RANGE are computed from.  With nfields > 0 the changed blocks of the range are computed:
  * fields[f] are COMPACT arrays holding just the blocks this rank fetched -- old block k at fields[f] + slot_of_old[k] * 64 *
  * dims[f] -- and new_fields[f][new_hi - new_lo][64 * dims[f]] receives the prolonged / restricted blocks at (position -

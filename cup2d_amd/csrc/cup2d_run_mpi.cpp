@@ -643,7 +643,7 @@ int main(int argc, char **argv) {
   int nx = 256, ny = 0, px = 0, py = 0, steps = 10, max_restarts = 0, max_iter = 1000, math = CUP2D_MATH_FAST;
   int level_max = 0, level_start = 2, adapt_steps = 20;
   double nu = 1e-3, cfl = 0.5, tol = 1e-3, tol_rel = 1e-2, rtol = 2.0, ctol = 0.5;
-  std::string comm = "rccl", state;
+  std::string comm = "rccl", state, plan_blocks;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string k = argv[i];
     const char *v = argv[i + 1];
@@ -661,6 +661,7 @@ int main(int argc, char **argv) {
     else if (k == "-comm") comm = v;
     else if (k == "-state") state = v;
     else if (k == "-math") math = std::strcmp(v, "strict") == 0 ? CUP2D_MATH_STRICT : CUP2D_MATH_FAST;
+    else if (k == "-planOnly") plan_blocks = v;
     else if (k == "-levelMax") level_max = std::atoi(v);
     else if (k == "-levelStart") level_start = std::atoi(v);
     else if (k == "-AdaptSteps") adapt_steps = std::atoi(v);
@@ -671,10 +672,40 @@ int main(int argc, char **argv) {
   if (ny == 0) ny = nx;
   if (px == 0 || py == 0) cartesian_dims(world, px, py);
   if ((comm != "rccl" && comm != "mpi") ||
-      (level_max == 0 && (px * py != world || nx % (BS * px) || ny % (BS * py) || nx < BS * px || ny < BS * py))) {
+      (level_max == 0 && plan_blocks.empty() && (px * py != world || nx % (BS * px) || ny % (BS * py) || nx < BS * px || ny < BS * py))) {
     if (g_rank == 0) std::fprintf(stderr, "cup2d_run_mpi: %d ranks need px * py = %d, -n / -ny multiples of 8 px / 8 py, -comm rccl|mpi\n", world, world);
     MPI_Finalize();
     return 2;
+  }
+  if (!plan_blocks.empty()) {
+    // -planOnly <blocks.i32> -state <prefix>: this rank's share of the given leaf list (AmrPart) written out, no GPU touched --
+    // how the CPU tests compare the C++ plan with cup2d_amd/amr_dist.py AmrPartition
+    FILE *f = std::fopen(plan_blocks.c_str(), "rb");
+    std::vector<int32_t> bl;
+    int32_t v3[3];
+    while (f && std::fread(v3, sizeof(int32_t), 3, f) == 3) bl.insert(bl.end(), v3, v3 + 3);
+    if (f) std::fclose(f);
+    const int n = (int)bl.size() / 3;
+    if (n < world || state.empty()) { if (g_rank == 0) std::fprintf(stderr, "cup2d_run_mpi: -planOnly needs a leaf list with at least one block per rank and -state\n"); MPI_Finalize(); return 2; }
+    std::vector<int32_t> gk(4 * n), gn(8 * n), gh(4 * n);
+    RUN(cup2d_amr_tables(n, bl.data(), 1, 1, gk.data(), gn.data(), gh.data()));
+    AmrPart P;
+    P.build(n, bl.data(), gk.data(), gn.data(), gh.data(), world, g_rank);
+    const std::string base = state + "." + std::to_string(g_rank) + ".";
+    const auto put = [&](const char *name, const std::vector<int32_t> &a) {
+      FILE *o = std::fopen((base + name).c_str(), "wb");
+      if (!o || (a.size() && std::fwrite(a.data(), sizeof(int32_t), a.size(), o) != a.size())) { std::fprintf(stderr, "cup2d_run_mpi: cannot write %s%s\n", base.c_str(), name); MPI_Abort(MPI_COMM_WORLD, 1); }
+      std::fclose(o);
+    };
+    put("range", {P.lo, P.hi, P.nghost});
+    put("ghost_ids", P.ghost_ids); put("level", P.level); put("kind", P.kind); put("nbr2", P.nbr2); put("half", P.half); put("nbr", P.nbr);
+    put("send_block", P.send_block); put("recv_block", P.recv_block); put("gather", P.gather);
+    std::vector<int32_t> lk;
+    for (size_t k = 0; k < P.links.peer.size(); k++)
+      for (int32_t x : {P.links.peer[k], P.links.soff[k], P.links.roff[k], P.links.scnt[k], P.links.rcnt[k]}) lk.push_back(x);
+    put("links", lk);
+    MPI_Finalize();
+    return 0;
   }
   // one GPU per rank: the node-local rank picks the device (ranks share GPUs only under -comm mpi)
   MPI_Comm node;

@@ -184,3 +184,31 @@ def test_cpp_mpi_driver_amr_matches_the_single_rank_driver_gpu(tmp_path, world, 
     dv, dp = np.abs(vn - v1[order]).max(), np.abs(pn - p1[order]).max()
     print("cup2d_run_mpi -levelMax on %d rank(s): %d blocks, max|dv| %.2e max|dp| %.2e; %s" % (world, len(bn), dv, dp, out.splitlines()[-1]))
     assert dv < 1e-8 and dp < 1e-6, (dv, dp)
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_cpp_amr_partition_equals_the_python_plan(tmp_path, world):
+    """csrc/cup2d_run_mpi.cpp AmrPart (-planOnly: no GPU) against cup2d_amd/amr_dist.py AmrPartition on the 4 084-block
+    three-level grid: ranges, ghost closure (two rings), local topology tables, whole-block links with their offsets and
+    counts per direction, the gather list -- table by table, rank by rank"""
+    import shutil
+    import numpy as np
+    from cup2d_amd import amr as A
+    from cup2d_amd.amr_dist import AmrPartition
+    exe = os.path.join(ROOT, "cup2d_amd", "cup2d_run_mpi")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("cup2d_run_mpi / mpiexec not built here")
+    G = A.circle_band_grid(7)
+    np.ascontiguousarray(G.blocks, dtype=np.int32).tofile(tmp_path / "blocks.i32")
+    r = subprocess.run([mpiexec, "-n", str(world), exe, "-planOnly", str(tmp_path / "blocks.i32"), "-state", str(tmp_path / "p")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    for rank in range(world):
+        P = AmrPartition(G, world, rank)
+        got = lambda name: np.fromfile(tmp_path / ("p.%d.%s" % (rank, name)), dtype=np.int32)
+        assert got("range").tolist() == [P.lo, P.hi, P.nghost]
+        assert np.array_equal(got("ghost_ids"), P.ghost_ids)
+        for name in ("level", "kind", "nbr2", "half", "nbr", "send_block", "recv_block", "gather"):
+            assert np.array_equal(got(name), np.asarray(getattr(P, name)).ravel()), (rank, name)
+        assert got("links").reshape(-1, 5).tolist() == [list(p) for p in P.peers], rank

@@ -182,7 +182,11 @@ static int rccl_allreduce(void *user, double *buf, int count, int op, void *stre
 __global__ void k_gather_scalars(const double *__restrict__ g, int nranks, int nsum, int with_max, double *__restrict__ red,
                                  KrylovScalars *sc, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (stage > 0 && sc->status != 0) return;  // the solve is over: the sweeps before this were no-ops
+  if (stage > 0 && sc->status != 0) {  // the solve is over: the sweeps before this were no-ops
+    // (a group's last iteration still tells the host, solve_fused_impl: one look per group of iterations)
+    if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   double v[3] = {0.0, 0.0, 0.0};
   for (int r = 0; r < nranks; r++) {
     if (nsum > 0) v[0] += g[3 * r];

@@ -1108,13 +1108,16 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     const int v = e ? atoi(e) : 4;
     return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
   }();
-  // One GPU, finish in the kernel (merge 1): the host looks at the solve once per GROUP of iterations -- the event record and
+  // Finish in the kernel (merge 1 | 2): the host looks at the solve once per GROUP of iterations -- the event record and
   // the system-scope store of the status word cost the stream 6 us of idle time between sweep E and the next AB
   // (tools/kernel_gaps.py), per iteration in round 2.  The last sweep E of a group reports (also when the
   // solve ended earlier in the group and its kernels returned at once); the host stays at most AHEAD groups in front, so at
   // most AHEAD * GROUP iterations of early-returning kernels are wasted behind a solve that has ended.  CUP2D_SOLVE_GROUP.
   static const int GROUP_ENV = [] { const char *e = getenv("CUP2D_SOLVE_GROUP"); return e ? atoi(e) : 4; }();
-  const int GROUP = merge == 1 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
+  // merge 2 (N ranks): the status word is written by the one-wave kernel behind the last all-gather of an iteration
+  // (comm.hip k_gather_scalars; callbacks: k_scalars), which reports for a finished solve as well -- same grouping.  Every
+  // rank sees the same scalars and looks at the same group boundaries, so all ranks enqueue the same collectives.
+  const int GROUP = merge != 0 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
   for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {

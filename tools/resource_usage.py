@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "scratch"
 src_dir = os.path.join(ROOT, "cup2d_amd", "csrc")
 rows = []
 for f in sorted(f for f in os.listdir(src_dir) if f.endswith(".hip")):

@@ -112,3 +112,32 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=env, timeout=300)
     assert r.returncode == 2 and b"GPU(s) are visible" in r.stderr and not r.stdout.strip()
+
+
+def test_a_gpu_test_that_aborts_costs_one_test_not_the_session(tmp_path):
+    """tests/conftest.py runs the GPU tests of the heavy files one per child process and announces every test on the real
+    stdout / stderr: a session in which one such test dies with SIGABRT (what a GPU memory fault is for the process that owns
+    the context) reports THAT test as failed -- with the signal -- and goes on to the next one.  Round 2's driver run lost all
+    104 tests to one abort."""
+    import shutil
+    import subprocess
+    import sys
+    d = tmp_path / "tests"
+    d.mkdir()
+    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), d / "conftest.py")
+    (d / "test_amr.py").write_text(
+        "import os, pytest\n"
+        "@pytest.mark.gpu\n"
+        "def test_dies():\n    os.abort()\n"
+        "@pytest.mark.gpu\n"
+        "def test_lives():\n    assert True\n"
+        "def test_not_gpu():\n    assert False, 'deselected by -m gpu'\n")
+    env = dict(os.environ)
+    env.pop("CUP2D_TEST_CHILD", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=tmp_path, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 1, out[-3000:]
+    assert "1 failed, 1 passed, 1 deselected" in out, out[-3000:]
+    assert "[cup2d] start tests/test_amr.py::test_dies" in out and "[cup2d] start tests/test_amr.py::test_lives" in out
+    assert "killed by signal 6" in out and "FAILED in its child process" in out, out[-3000:]

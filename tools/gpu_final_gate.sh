@@ -4,7 +4,7 @@
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 t0=$(date +%s)
-timeout 1200 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/gate_pytest.log 2>&1
+timeout 1200 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/gate_pytest.log 2>&1   # (the driver's command line, verbatim)
 echo "pytest rc=$? ($(( $(date +%s) - t0 )) s)"; tail -5 $OUT/gate_pytest.log
 grep -c "^\[cup2d\] start" $OUT/gate_pytest.log
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2

@@ -200,3 +200,30 @@ def test_edge_form_of_the_fused_sweeps(gpu_lib, share):
         assert v["ran"] == "fused" and v["iters4"] == [4, 4], (name, v)
         assert v["rel4"] <= 1e-12, (name, v)
         assert v["conv_err"] <= 1e-9 and v["conv_res"] <= 1.05e-9, (name, v)
+
+
+def test_forty_steps_follow_the_reference_time_loop(gpu_lib, oracle):
+    """A longer run: 40 consecutive cup2d_step calls (cached max|u| for dt, the solve told that its initial guess is zero, one
+    host look per group of iterations, in-kernel finish -- every step-to-step short cut of the library) against the
+    reference's own time loop on the same start field, every solve converged to 1e-10: same dt at every step to round-off,
+    velocity and pressure at the end to the solve tolerance.  Nothing may accumulate over the steps."""
+    import cup2d_amd
+    if not oracle.have_reference():
+        pytest.skip("needs oracle/_ref/ref_harness")
+    n, steps, nu = 128, 40, 1e-3
+    vel0 = oracle.taylor_green(n, noise=1e-2, seed=11)
+    ref = oracle.ref_run(vel0, nu, steps, tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=2000, threads=8)
+    with cup2d_amd.Simulation(n // 8, nu=nu) as s:
+        s.set_solver(fused=True, finish_in_kernel=True)
+        s.vel = vel0
+        dts, its = [], []
+        for k in range(steps):
+            r = s.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=2000)
+            dts.append(r["dt"])
+            its.append(r["iters"])
+            assert r["err"] <= 1e-10, (k, r)
+        rd = [st["dt"] for st in ref["steps"]]
+        assert len(rd) == steps and np.allclose(dts, rd, rtol=1e-9, atol=0), np.abs(np.array(dts) / np.array(rd) - 1).max()
+        dv, dp = np.abs(s.vel - ref["vel"]).max(), np.abs((s.pres - s.pres.mean()) - (ref["pres"] - ref["pres"].mean())).max()
+        print("40 steps at 128^2: max|dv| %.2e max|dp| %.2e, iterations per solve %d..%d" % (dv, dp, min(its), max(its)))
+        assert dv < 1e-8 and dp < 1e-6, (dv, dp)

@@ -42,6 +42,56 @@ constexpr size_t EDGE_LDS_BYTES = EDGE_HDR_DOUBLES * sizeof(double) + FWAVES * s
 static_assert(EDGE_LDS_BYTES <= 156 * 1024, "k_edge: LDS budget (160 KiB per workgroup, some of it static)");
 constexpr int EDGE_SPIN_LIMIT = 1 << 22;  // a wave that waits longer than this for a sibling reports a fault instead of hanging
 
+// timing-only builds (wrong results): bit 0: no MFMAs in the jobs; bit 1: no ring (no ring loads, no ring jobs); bit 2: no LDS
+// phases at all (no staging, classification, jobs, gathers: y = v -- the memory skeleton of the tile loads and stores);
+// bit 3: no stores
+#ifndef CUP2D_EDGE_KNOCK
+#define CUP2D_EDGE_KNOCK 0
+#endif
+constexpr int KNOCK = CUP2D_EDGE_KNOCK;
+// set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask held in registers)
+static __device__ __forceinline__ int bits_below_lane(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+// S (v of 16 blocks, block-major) -> S[b * XS + 8 * side + q] = z of block b on the edge cells of side W, E, S, N: the product
+// with the 32 edge columns of P_inv (krylov_fused.hip ring_precond; the A operands in two halves of eight k-steps: 16
+// registers instead of 32 -- S is not written before the last MFMA has its operands)
+static __device__ __forceinline__ void edge_precond(double *S, const double *PE, int lane) {
+  const int ablk = lane & 15, akk = lane >> 4;
+  v4f64 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2 && !(KNOCK & 1); h++) {
+    double xa[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xa[k] = S[ablk * XS + 4 * (8 * h + k) + akk];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k], PE[((8 * h + k) * 2 + nt) * 64 + lane], acc[nt], 0, 0, 0);
+  }
+  wave_lds_sync();  // every lane has read its operands before the tile is overwritten
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) S[(akk + 4 * v) * XS + 16 * nt + ablk] = acc[nt][v];
+  wave_lds_sync();
+}
+
+// bit `lane` of a wave mask (no 1 << lane held in two registers across the loop)
+static __device__ __forceinline__ bool mask_bit(unsigned long long m, int lane) {
+  const unsigned half = lane < 32 ? (unsigned)m : (unsigned)(m >> 32);
+  return ((half >> (lane & 31)) & 1u) != 0u;
+}
+// a copy of x the optimiser cannot see through: per-lane addresses formed from it stay inside the loop iteration (LICM would
+// hoist dozens of loop-invariant LDS addresses out of the tile loop, where they are spilled; one add each to form them again)
+static __device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // wave-uniform wait until sibling u has published `need` rounds
 static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int *fault) {
   int spins = 0;
@@ -67,7 +117,6 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
                                                  int *fault) {
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   if (sc->status != 0) return;
-  constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
   double *PE = fsm;
   int *pub = reinterpret_cast<int *>(fsm + PE2_DOUBLES);
   for (int idx = threadIdx.x; idx < PE2_DOUBLES; idx += FWG) {
@@ -100,9 +149,6 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     }
     return a + c1 * b;
   };
-  struct Raw {  // one batch = 8 blocks = 4 block pairs
-    double2 a[4], b[4], c[4];
-  };
 
   // tiles of 16 blocks; the 8 waves of a workgroup take 8 consecutive tiles per round, contiguous ranges per XCD
   const int ntiles = (count + TB - 1) / TB;
@@ -128,9 +174,9 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     return (t < t_end && b < last) ? nbr[4 * b + ss] : CUP2D_WALL;
   };
   struct Tile {
-    int b0, nvalid, nb, nring, npass, sib;  // sib: the sibling wave whose tile holds this slot's neighbour, or -1
     unsigned long long pmask;               // the tile's perimeter slots (neighbour = a block outside the tile)
-    bool is_ring;                           // ... of which the ones to recompute
+    int b0, nvalid, nb, nring, npass, sib;  // sib: the sibling wave whose tile holds this slot's neighbour, or -1
+    int is_ring, pad;                       // ... of which the ones to recompute (no tail padding: copies stay in registers)
   };
   // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the previous tile's)
   const auto classify = [&](int t, int nb) -> Tile {
@@ -145,130 +191,173 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     T.sib = sibling ? nt - t0 : -1;
     T.pmask = __ballot(outside);
     T.is_ring = outside && !sibling;
+    T.pad = 0;
     const unsigned long long rmask = __ballot(T.is_ring);
-    T.nring = __popcll(rmask);
+    T.nring = (KNOCK & 6) ? 0 : __popcll(rmask);
     T.npass = (T.nring + TB - 1) / TB;
-    if (T.is_ring) {
-      const int slot = __popcll(rmask & ((1ull << lane) - 1ull));
+    if (T.is_ring && !(KNOCK & 6)) {
+      const int slot = bits_below_lane(rmask);
       L.ring_nb[slot] = nb;
       L.ring_dst[slot] = lane;
     }
     wave_lds_sync();
     return T;
   };
-  // the 4 block pairs of batch `half` of job j of tile T (ring entries, or for the last job the tile's blocks), branch-free
-  const auto issue = [&](Raw &R, const Tile &T, int j, int half) {
-    const bool tile_job = j >= T.npass;
-    const int ne = max(1, min(TB, T.nring - j * TB));
-    size_t off[4];
+  // Batches: 8 blocks = 4 block pairs per half-wave, one 16-byte load per lane, pair and vector; all issue functions are
+  // branch-free so that the loads go out back to back.  Ring and tile batches live in SEPARATE register sets (a ring batch
+  // has no fourth vector, and two sets with clear live ranges are what the register allocator handles without spills).
+  struct RawR {
+    double2 a[4], b[4], c[4];
+  };
+  struct RawT {
+    double2 a[4], b[4], c[4];
+  };
+  const double2 *in0 = reinterpret_cast<const double2 *>(A.in0), *in1 = reinterpret_cast<const double2 *>(A.in1);
+  const double2 *in2 = reinterpret_cast<const double2 *>(A.in2), *inw = reinterpret_cast<const double2 *>(A.w);
+  const auto issue_ring = [&](RawR &R, const Tile &X, int pass, int half) {  // entries 16 pass + 8 half .. + 7 of X's ring list
+    if (KNOCK & 6) return;
+    const int ne = max(1, min(TB, X.nring - pass * TB));
+    const int lo = opaque(lane), hfo = lo >> 5, hlo = lo & 31;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const int idx = 8 * half + 2 * p + hf;  // per half-wave
-      const int rb = L.ring_nb[min(j * TB + min(idx, ne - 1), TB * 4 - 1)];
-      const int blk = tile_job ? T.b0 + min(idx, T.nvalid - 1) : rb;
-      off[p] = ((size_t)blk * BC + c0) >> 1;  // in double2 units
+      const int idx = 8 * half + 2 * p + hfo;
+      const int rb = L.ring_nb[min(pass * TB + min(idx, ne - 1), TB * 4 - 1)];
+      const size_t o = (size_t)(X.nring > 0 ? rb : X.b0) * (BC / 2) + hlo;  // (no ring: any block of the tile, loaded and dropped)
+      R.a[p] = in0[o];
+      R.b[p] = in1[o];
+      if (MODE == 0) R.c[p] = in2[o];
     }
-    const double2 *in0 = reinterpret_cast<const double2 *>(A.in0), *in1 = reinterpret_cast<const double2 *>(A.in1);
-    const double2 *in2 = reinterpret_cast<const double2 *>(A.in2);
+  };
+  const auto issue_tile = [&](RawT &R, const Tile &X, int half) {
+    const int lo = opaque(lane), hfo = lo >> 5, hlo = lo & 31;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      const size_t o = off[p];
-      if (MODE == 0 && tile_job && (POL & 0x3000)) {
+      const size_t o = (size_t)(X.b0 + min(8 * half + 2 * p + hfo, X.nvalid - 1)) * (BC / 2) + hlo;
+      if (MODE == 0) {
         R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
         R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
         R.c[p] = in2[o];
       } else {
         R.a[p] = in0[o];
         R.b[p] = in1[o];
-        if (MODE == 0) R.c[p] = in2[o];
       }
     }
   };
 
-  Raw Ra, Rb;
+  // Schedule of a tile (both halves of a job requested a job ahead; the set that is in flight across a job on the matrix
+  // cores is never the one being consumed):
+  //   top             Qa, Qb = ring pass 0 of this tile in flight (requested behind the previous tile's classification)
+  //   ring pass 0     stage Qa; request Ta (tile, first half); stage Qb; request Tb; ring job; scatter
+  //   (further ring passes -- more than 16 entries: other block orders -- are requested and waited for in place)
+  //   tile            stage Ta; stage Tb; classify the next tile, request its ring pass 0 into Qa, Qb;
+  //                   tile job; hand-over; ghost gathers; epilogue
+  RawR Qa, Qb;
+  RawT Ta, Tb;
   Tile T;
   if (t_begin < t_end) {
     T = classify(t_begin, load_nb(t_begin));
-    issue(Ra, T, 0, 0);
-    if (DEEP) issue(Rb, T, 0, 1);
+    issue_ring(Qa, T, 0, 0);  // (always: a batch set that is assigned on SOME paths only is live around the whole loop)
+    issue_ring(Qb, T, 0, 1);
   }
   int nb_next = load_nb(t_begin + t_stride);
   int round = 0;
   for (int t = t_begin; t < t_end; t += t_stride, round++) {
-    // invariant: T describes tile t, its ring list is in LDS, the first batch of its first job is in flight in Ra
     const int b0 = T.b0, nvalid = T.nvalid, par = round & 1;
+    const bool more = t + t_stride < t_end;
     double2 V[TB / 2];  // v of the tile's cells in pair layout
-    double2 W[TB / 2];  // dot-product operand: rhat (AB; r on a restart); CD uses V
-    const auto stage = [&](const Raw &R, bool is_tile, int half) {
+    double2 W[TB / 2];  // AB: rhat (r on a restart)
+    const auto stage_ring = [&](const RawR &R, int half) {
+      const int lo = opaque(lane);
+      double *Sst = L.S + (lo >> 5) * XS + 2 * (lo & 31);  // one base, the block pair in the instruction's offset field
 #pragma unroll
       for (int p = 0; p < 4; p++) {
-        const int idx = 8 * half + 2 * p + hf;
         double2 v;
         v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
         v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
-        *reinterpret_cast<double2 *>(L.S + idx * XS + c0) = v;
-        if (is_tile) {
-          V[4 * half + p] = v;
-          if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
-          if (MODE == 0 && idx < nvalid) {  // CD does not store s: sweep E forms it again from r and nu'
-            const size_t o = ((size_t)(b0 + idx) * BC + c0) >> 1;
-            st2<(POL & 0x001) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
-            if (restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
-          }
+        *reinterpret_cast<double2 *>(Sst + (8 * half + 2 * p) * XS) = v;
+      }
+    };
+    const auto ring_job = [&](int pass) {
+      wave_lds_sync();
+      edge_precond(L.S, PE, lane);  // S[e * XS + 8 * side + q] = z of entry (block) e on its four edges
+      const int ne = min(TB, T.nring - pass * TB);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
+        if (e < ne) {
+          const int dst = L.ring_dst[pass * TB + e];  // entry e feeds slot dst = block * 4 + side with the OPPOSITE edge
+          L.GE[dst * GS + q] = L.S[e * XS + 8 * ((dst & 3) ^ 1) + q];
+        }
+      }
+      wave_lds_sync();
+    };
+    const auto stage_tile = [&](const RawT &R, int half) {
+      const int lo = opaque(lane), hfo = lo >> 5, hlo = lo & 31;
+      double *Sst = L.S + hfo * XS + 2 * hlo;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int idx = 8 * half + 2 * p + hfo;
+        double2 v;
+        v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
+        v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
+        if (!(KNOCK & 4)) *reinterpret_cast<double2 *>(Sst + (8 * half + 2 * p) * XS) = v;
+        V[4 * half + p] = v;
+        if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
+        if (MODE == 0 && idx < nvalid) {  // CD does not store s: sweep E forms it again from r and nu'
+          const size_t o = (size_t)(b0 + idx) * (BC / 2) + hlo;
+          if (!(KNOCK & 8)) st2<(POL & 0x001) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
+          if (restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
         }
       }
     };
-    Tile N = T;  // the next tile, once classified
-    for (int j = 0; j <= T.npass; j++) {
-      const bool is_tile = j == T.npass;
-      if (!DEEP) issue(Rb, T, j, 1);
-      stage(Ra, is_tile, 0);
-      if (DEEP) stage(Rb, is_tile, 1);
-      if (!is_tile) {
-        issue(Ra, T, j + 1, 0);
-        if (DEEP) issue(Rb, T, j + 1, 1);
-      } else if (MODE == 0 && !restart) {
+    // ---- ring passes ----
+    // (scheduling barriers: left alone, the scheduler hoists every request to the top of the tile -- four batches in
+    // flight at once, 224 registers, and the wave spills)
+    if (T.npass > 0) stage_ring(Qa, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_tile(Ta, T, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (T.npass > 0) stage_ring(Qb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_tile(Tb, T, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (T.npass > 0) ring_job(0);
+    for (int pass = 1; pass < T.npass; pass++) {
+      issue_ring(Qa, T, pass, 0);
+      issue_ring(Qb, T, pass, 1);
+      stage_ring(Qa, 0);
+      stage_ring(Qb, 1);
+      ring_job(pass);
+    }
+    // ---- the tile ----
+    Tile N = T;
+    stage_tile(Ta, 0);
+    if (MODE == 0 && !restart) {
 #pragma unroll
-        for (int i = 0; i < TB / 2; i++) {
-          const double2 *pw = reinterpret_cast<const double2 *>(A.w) + (((size_t)(b0 + min(2 * i + hf, nvalid - 1)) * BC + c0) >> 1);
-          W[i] = ld2<(POL & 0x800) != 0>(pw);
-        }
-      }
-      if (!DEEP) stage(Rb, is_tile, 1);
-      if (is_tile && t + t_stride < t_end) {
-        // this tile's ring list is dead: classify the NEXT tile into it and put its first job in flight behind this
-        // tile's job, edge traffic and epilogue
-        N = classify(t + t_stride, nb_next);
-        nb_next = load_nb(t + 2 * t_stride);
-        issue(Ra, N, 0, 0);
-        if (DEEP) issue(Rb, N, 0, 1);
-      } else {
-        wave_lds_sync();
-      }
-      ring_precond(L.S, PE, lane, false);  // S[e * XS + 8 * side + q] = z of entry (block) e on its four edges
-      if (!is_tile) {
-        // entry e feeds slot dst = block * 4 + side with the OPPOSITE edge of the neighbour block
-        const int ne = min(TB, T.nring - j * TB);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
-          if (e < ne) {
-            const int dst = L.ring_dst[j * TB + e];
-            L.GE[dst * GS + q] = L.S[e * XS + 8 * ((dst & 3) ^ 1) + q];
-          }
-        }
-        wave_lds_sync();
+      for (int i = 0; i < TB / 2; i++) {
+        const double2 *pw = inw + (((size_t)(b0 + min(2 * i + hf, nvalid - 1)) * BC + c0) >> 1);
+        W[i] = ld2<(POL & 0x800) != 0>(pw);
       }
     }
+    stage_tile(Tb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // this tile's ring list is dead: the NEXT tile is classified into it (past the wave's last tile: this tile once more --
+    // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
+    N = classify(more ? t + t_stride : t, more ? nb_next : T.nb);
+    nb_next = load_nb(t + 2 * t_stride);
+    if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
+    // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
+    issue_ring(Qa, N, 0, 0);
+    issue_ring(Qb, N, 0, 1);
     // ---- export the z edges of the perimeter sides for the siblings ----
-    if (share) {
+    if (share && !(KNOCK & 4)) {
       // this buffer held round - 2: every sibling has read it once it has published round - 1
       if (round >= 2) {
         for (int u = 0; u < FWAVES; u++)
           if (u != wave) edge_wait(pub, u, round, fault);
       }
-      if ((T.pmask >> lane) & 1ull) {
-        const int slot = __popcll(T.pmask & ((1ull << lane) - 1ull));
+      if (mask_bit(T.pmask, opaque(lane))) {
+        const int slot = bits_below_lane(T.pmask);
         if (slot < EXP_SLOTS) {
 #pragma unroll
           for (int q = 0; q < BS; q++) L.X[par][slot * BS + q] = L.S[si * XS + 8 * ss + q];
@@ -279,13 +368,13 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       if (lane == 0) __hip_atomic_store(pub + wave, round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // ---- ghost edges from the own tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost = edge cell) ----
-    if (si < nvalid && !((T.pmask >> lane) & 1ull)) {
+    if (si < nvalid && !mask_bit(T.pmask, opaque(lane)) && !(KNOCK & 4)) {
       const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + 8 * sside + q];
     }
     // ---- ghost edges a sibling wave exported ----
-    if (share) {
+    if (share && !(KNOCK & 4)) {
       for (int u = 0; u < FWAVES; u++) {
         const bool mine = T.sib == u;
         if (__ballot(mine) == 0ull) continue;
@@ -303,25 +392,29 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     wave_lds_sync();
     // ---- y = v + ghosts on the block edges (A P_inv v = v + (C + W) z), the fused dot products: two cells per lane, eight
     //      block pairs ----
+    const int lo = opaque(lane), hfo = lo >> 5, hlo = lo & 31;
+    const double *gex = L.GE + hfo * 4 * GS + ((2 * hlo) & 7), *gey = L.GE + hfo * 4 * GS + (hlo >> 2);
 #pragma unroll
     for (int i = 0; i < TB / 2; i++) {
-      const int blk = 2 * i + hf;
+      const int blk = 2 * i + hfo;
       if (blk < nvalid) {
-        const double *ge = L.GE + blk * 4 * GS;
+        const double *gx = gex + 2 * i * 4 * GS;
         double2 yv = V[i];
-        if (px == 0) yv.x += ge[0 * GS + py];        // west of cell c0
-        if (px == BS - 2) yv.y += ge[1 * GS + py];   // east of cell c0 + 1
+        if (!(KNOCK & 4)) {
+        if (px == 0) yv.x += gey[2 * i * 4 * GS + 0 * GS];        // west of cell c0
+        if (px == BS - 2) yv.y += gey[2 * i * 4 * GS + 1 * GS];   // east of cell c0 + 1
         if (py == 0) {
-          const double2 g = *reinterpret_cast<const double2 *>(ge + 2 * GS + px);
+          const double2 g = *reinterpret_cast<const double2 *>(gx + 2 * GS);
           yv.x += g.x;
           yv.y += g.y;
         }
         if (py == BS - 1) {
-          const double2 g = *reinterpret_cast<const double2 *>(ge + 3 * GS + px);
+          const double2 g = *reinterpret_cast<const double2 *>(gx + 3 * GS);
           yv.x += g.x;
           yv.y += g.y;
         }
-        st2<(POL & (MODE == 0 ? 0x002 : 0x008)) != 0>(reinterpret_cast<double2 *>(A.yout) + (((size_t)(b0 + blk) * BC + c0) >> 1), yv);
+        }
+        if (!(KNOCK & 8)) st2<(POL & (MODE == 0 ? 0x002 : 0x008)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);
         const double2 wv = MODE == 0 ? W[i] : V[i];
         acc[0] = __builtin_fma(yv.x, wv.x, acc[0]);
         acc[0] = __builtin_fma(yv.y, wv.y, acc[0]);

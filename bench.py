@@ -397,7 +397,7 @@ def main():
         # too few sampled launches for a per-kernel average (a short --steps): keep sampling OUTSIDE the timed region
         def sampled(name):
             return sim.get_timing(L.TIMER_NAMES.index(name))[1]
-        while sampled("sweep_E") < MIN_ROOFLINE_LAUNCHES and extra_sampled_steps < 64:
+        while max(sampled("sweep_E"), sampled("sweep_EA")) < MIN_ROOFLINE_LAUNCHES and extra_sampled_steps < 64:
             run.one_step()
             extra_sampled_steps += 1
     timers = {}
@@ -501,6 +501,16 @@ def main():
         mf = 0 if args.finish != "kernel" else (1 if dist is None else 2)
         KERNEL_OF.update({"sweep_A": "k_fused<0, %d>" % mf, "sweep_C": "k_fused<1, %d>" % mf, "sweep_E": "k_sweepE_y<%d>" % mf})
         sweeps = ("sweep_A", "sweep_C", "sweep_E")
+    # The library's default on one GPU (krylov_edge.h MODE 2 / 3, CUP2D_FUSED_FORM unset or eab): per iteration TWO launches --
+    #   sweep_C  = C+D with the sums of the next beginning: reads r, nu', rhat 24 + writes t 8 = 32
+    #   sweep_EA = sweep E + the next iteration's A+B: reads p', nu', r, t, y, rhat 48 + writes y', r', p'', nu'' 32 = 80
+    #   sweep_A  = the A+B of iteration 0, once per solve (p = nu = 0 are not read): reads r, rhat 16 + writes p', nu' 16 = 32
+    eab = fused and timers["sweep_EA"]["launches"] > 0
+    if eab:
+        ALGO_BYTES.update({"sweep_A": 32.0, "sweep_C": 32.0, "sweep_EA": 80.0})
+        del ALGO_BYTES["sweep_E"]
+        KERNEL_OF.update({"sweep_A": "k_edge<0, 1>", "sweep_C": "k_edge<3, 1>", "sweep_EA": "k_edge<2, 1>"})
+        sweeps = ("sweep_C", "sweep_EA")
     finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on
     # gfx950), summarised by tools/prof_summary.py from the same bench command: profiles/<tag>_pmc_traffic.json
@@ -544,6 +554,8 @@ def main():
                 "sweep_E": args.iters, "scalars": finish_launches * args.iters + 1, "halo": 0}
     if fused:
         per_step["sweep_B"] = per_step["sweep_D"] = 0
+    if eab:
+        per_step.update({"sweep_A": 1, "sweep_E": 0, "sweep_EA": args.iters})
     step_ms = {f: (timers[f]["ms_avg"] or 0.0) * per_step.get(f, 0) for f in timers}
     gpu_ms = sum(step_ms.values()) or 1.0
     all_roof = {}
@@ -581,7 +593,7 @@ def main():
                   "mcell_iterations_per_s": round(cells_rank / t_it / 1e6, 1)}
 
     # GPU time of a step by part (sampled averages x launches per step): the BiCGSTAB sweeps and everything else
-    sweeps_ms = sum(step_ms.get(f, 0.0) for f in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E"))
+    sweeps_ms = sum(step_ms.get(f, 0.0) for f in ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "sweep_E", "sweep_EA"))
     gpu_split = {"solver_sweeps": round(sweeps_ms, 4), "outside_the_sweeps": round(gpu_ms - sweeps_ms, 4),
                  "families": {f: round(v, 4) for f, v in step_ms.items() if v},
                  "note": "the solve's last pass x = P_inv y (0.07 ms at 4096^2) runs under no timer"}

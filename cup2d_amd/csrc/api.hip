@@ -108,7 +108,12 @@ struct DevPool {
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, bucket) -> buffers not in use
   std::map<void *, std::pair<int, size_t>> owner;              // every buffer the pool has handed out or holds
+  std::map<void *, void *> base;                               // skewed buffers: what hipMalloc returned
   size_t idle_bytes = 0;
+  int nbig = 0;
+  // CUP2D_ALLOC_SKEW: the k-th large buffer starts (k mod 16) * skew bytes into its allocation (experiment: vectors of 2^27
+  // bytes, each its own hipMalloc, all start at the same offset of the channel interleave)
+  const size_t skew = [] { const char *e = getenv("CUP2D_ALLOC_SKEW"); return (size_t)(e ? atol(e) : 0); }();
   const bool on = [] { const char *e = getenv("CUP2D_POOL"); return !e || atoi(e) != 0; }();
   const size_t cap = [] { const char *e = getenv("CUP2D_POOL_MAX_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
   static size_t bucket(size_t bytes) {
@@ -143,14 +148,21 @@ hipError_t dev_malloc_raw(void **p, size_t bytes) {
     }
   }
   if (!q) {
-    e = hipMalloc(&q, b);
+    const bool big = P.skew > 0 && b >= ((size_t)8 << 20);
+    const size_t extra = big ? 16 * P.skew : 0;
+    e = hipMalloc(&q, b + extra);
     if (e != hipSuccess) {  // out of memory with buffers idling in the pool: give them back and try once more
       (void)hipGetLastError();
       cup2d_trim_pool();
-      e = hipMalloc(&q, b);
+      e = hipMalloc(&q, b + extra);
       if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> g(P.mu);
+    if (big) {
+      void *raw = q;
+      q = static_cast<char *>(raw) + (size_t)(P.nbig++ % 16) * P.skew;
+      P.base[q] = raw;
+    }
     P.owner[q] = {dev, b};
   }
   // zero-filled, always: a recycled buffer must not look different from a fresh one
@@ -173,6 +185,11 @@ void dev_free(void *q) {
   }
   if (P.idle_bytes + it->second.second > P.cap) {
     P.owner.erase(it);
+    auto bt = P.base.find(q);
+    if (bt != P.base.end()) {
+      q = bt->second;
+      P.base.erase(bt);
+    }
     g.unlock();
     (void)hipFree(q);
     return;
@@ -210,8 +227,10 @@ extern "C" int cup2d_trim_pool(void) {
     std::lock_guard<std::mutex> g(P.mu);
     for (auto &kv : P.idle)
       for (void *q : kv.second) {
-        drop.push_back(q);
         P.owner.erase(q);
+        auto bt = P.base.find(q);
+        drop.push_back(bt != P.base.end() ? bt->second : q);
+        if (bt != P.base.end()) P.base.erase(bt);
       }
     P.idle.clear();
     P.idle_bytes = 0;
@@ -780,6 +799,12 @@ int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   if (kind != CUP2D_SOLVER_SWEEPS && kind != CUP2D_SOLVER_FUSED) { set_error("set_solver: kind %d", kind); return CUP2D_ERR_ARG; }
   c->solver = kind;
   c->finish_in_kernel = finish_in_kernel != 0;
+  return CUP2D_OK;
+}
+int cup2d_set_solver_form(cup2d_ctx *c, int form) {
+  CUP2D_CHECK_CTX(c);
+  if (form < CUP2D_FORM_AUTO || form > CUP2D_FORM_EAB) { set_error("set_solver_form: form %d", form); return CUP2D_ERR_ARG; }
+  c->solver_form = form;
   return CUP2D_OK;
 }
 static bool scalar_field(int f) { return field_ok(f) && dim_of(f) == 1; }

@@ -15,7 +15,7 @@ constexpr int BC = BS * BS;        // cells per block = one wavefront
 constexpr int WG = 256;            // threads per workgroup = 4 waves = 4 blocks in flight
 constexpr int WPG = WG / 64;       // waves (= blocks) per workgroup pass
 constexpr int MAX_GRID = 2048;     // persistent grid: 256 CUs x 8 workgroups, multiple of the 8 XCDs
-constexpr int NSLOT = 4;           // reduction slots per launch
+constexpr int NSLOT = 6;           // reduction slots per launch (k_edge MODE 3: five sums)
 constexpr int PSTRIDE = 2 * MAX_GRID;  // partials per slot: an inner-block and a halo-block launch
 
 void set_error(const char *fmt, ...);
@@ -59,6 +59,7 @@ struct KrylovScalars {
   int ycur, ybest;   // fused solver: which of its three y buffers holds the current / the best iterate
   int best_is_x0;    // fused solver: no iterate has beaten the initial guess yet (y_best = 0: its buffer is never written or read)
   double omega_r;    // the omega sweep E formed r = s - omega t with (a restart resets omega, not this): stored-edge ring
+  double rho_next;   // k_edge MODE 2 / 3: rhat . r' from the sums of sweep D (krylov_common.h stage 5)
 };
 
 struct HaloPlan {
@@ -156,6 +157,7 @@ struct cup2d_ctx {
   // preconditioned-space accumulator y (x = x0 + P_inv y) with its best-iterate copy; allocated on first use
   double *d_p2 = nullptr, *d_nu2 = nullptr, *d_s = nullptr, *d_y = nullptr, *d_yopt = nullptr;
   int *d_fault = nullptr;    // k_edge's fault word (krylov_edge.h)
+  int solver_form = 0;       // cup2d_fused_form (0: the process default, CUP2D_FUSED_FORM)
   int edge_share = -1;       // k_edge: sibling waves share z edges (-1: not yet decided from the neighbour table)
   double *d_edge[8] = {nullptr};  // stored-edge ring (krylov_fused.hip): z, P_inv nu, z2, P_inv t on block edges, two buffers each
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)

@@ -34,6 +34,13 @@ static __device__ __forceinline__ int y_out_buffer(int cur, int best) {
 // STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
 // STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
 // STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
+// The organisation with sweep E and the next A+B in ONE launch (k_edge MODE 2 / 3; one GPU):
+// STAGE 5: after sweep D (MODE 3)  red = {t.s, t.t, rhat.s, rhat.t, s.s} -> omega, and -- BEFORE r' = s - omega t exists --
+//          what the beginning of the next iteration needs of it: rho' = rhat.r' = rhat.s - omega rhat.t (the same sum in
+//          another order of rounding), ||r'||^2 = s.s - 2 omega t.s + omega^2 t.t for the breakdown test, hence beta and the
+//          restart decision the launch is going to use.  No bookkeeping: the iteration is not over.
+// STAGE 4: after MODE 2            red = {rhat.nu'', r'.r', max|r'|} -> stage 3's bookkeeping with rho' of stage 5 and the
+//          decision taken there (a restart takes rho = ||rhat||^2 = r'.r' as summed HERE, cell by cell), then stage 1's alpha
 static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage) {
   switch (stage) {
   case 0:
@@ -68,6 +75,47 @@ static __device__ void scalars_update(KrylovScalars *sc, const double *red, int 
     sc->rho_curr = red[0];
     sc->rr = red[1];
     begin_iteration(sc);
+    break;
+  case 5: {
+    sc->omega = red[0] / (red[1] + sc->eps);
+    sc->omega_r = sc->omega;
+    const double w = sc->omega;
+    sc->rho_next = red[2] - w * red[3];
+    double rr = red[4] - 2.0 * w * red[0];
+    rr = rr + (w * w) * red[1];
+    rr = rr > 0.0 ? rr : 0.0;
+    const bool serious_breakdown = sc->rho_next * sc->rho_next < 1e-16 * rr * sc->rhat2;
+    sc->beta = (sc->rho_next / (sc->rho_curr + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta, rho_prev = rho_curr by then
+    sc->restart_flag = serious_breakdown && sc->max_restarts > 0 ? 1 : 0;
+    break;
+  }
+  case 4:
+    sc->iter++;
+    sc->err = red[2];
+    sc->ycur = y_out_buffer(sc->ycur, sc->ybest);
+    if (sc->err < sc->err_opt) {
+      sc->err_opt = sc->err;
+      sc->x_is_best = 1;
+      sc->ybest = sc->ycur;
+      sc->best_is_x0 = 0;
+      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
+    } else {
+      sc->x_is_best = 0;
+    }
+    sc->rho_prev = sc->rho_curr;  // set_rho
+    sc->rho_curr = sc->rho_next;
+    sc->rr = red[1];
+    // begin_iteration with the decision of stage 5 (beta is set)
+    if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
+    if (sc->restart_flag) {
+      sc->restarts++;
+      if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
+      sc->rhat2 = sc->rr;
+      sc->rho_curr = sc->rr;
+      sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;
+      sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
+    }
+    sc->alpha = sc->rho_curr / (red[0] + sc->eps);  // stage 1
     break;
   }
 }
@@ -150,9 +198,42 @@ static __device__ __forceinline__ void finish_reduce(const double *partials, int
       const double loc[3] = {sm[0][0], sm[1][0], sm[2][0]};
       scalars_update(sc, loc, fused_stage);
       // end of an iteration: tell the host (pinned, device-visible word) whether the loop is over
-      if (fused_stage == 3 && host_status)
+      if ((fused_stage == 3 || fused_stage == 4) && host_status)
         __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+}
+
+// The same for NS sums and no maximum (k_edge MODE 3: five), scratch = the caller's dead dynamic LDS; partials read with
+// agent-scope loads.
+template <int NS>
+static __device__ __forceinline__ void finish_reduce_n(const double *partials, int G, double *red, KrylovScalars *sc,
+                                                       int fused_stage, double *ext) {
+  double (*sm)[WG] = reinterpret_cast<double (*)[WG]>(ext);
+  if (threadIdx.x < WG) {
+    double a[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) a[k] = 0.0;
+    for (int i = threadIdx.x; i < G; i += WG)
+#pragma unroll
+      for (int k = 0; k < NS; k++) a[k] += __hip_atomic_load(partials + (size_t)k * PSTRIDE + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < NS; k++) sm[k][threadIdx.x] = a[k];
+  }
+  __syncthreads();
+  for (int s = WG / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) sm[k][threadIdx.x] += sm[k][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double loc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) loc[k] = sm[k][0];
+    for (int k = 0; k < NS && k < 3; k++) red[k] = loc[k];
+    if (fused_stage >= 0) scalars_update(sc, loc, fused_stage);
   }
 }
 

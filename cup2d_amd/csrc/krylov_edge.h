@@ -108,6 +108,14 @@ static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int 
 //                      y = nu' = p' + ghosts(P_inv p') ; partial(rhat . nu')             (484-488)
 // MODE 1 (sweeps C+D): v = s  = r - alpha nu'                                            (499-502)
 //                      y = t  = s + ghosts(P_inv s)   ; partial(t . s, t . t)           (503-509)
+// MODE 2 (sweep E of iteration k + sweeps A+B of iteration k + 1 in one pass over the cells; one GPU, finish in the kernel):
+//                      s = r - alpha nu' ; y' = y + alpha p' + omega s ; r' = s - omega t          (498-502, 520-525)
+//                      v = p'' = beta' (p' - omega nu') + r'  (restart: p'' = rhat = r') ; y = nu'' = p'' + ghosts(P_inv p'')
+//                      partial(rhat . nu'', r' . r', max|r'|)
+//                      beta' and the restart decision need rho' = rhat . r' and ||r'||^2 BEFORE this launch: MODE 3 supplies
+//                      them (krylov_common.h stage 5); r' goes to a second buffer (ring entries re-read r of other tiles)
+// MODE 3 (MODE 1 + the dot products of the NEXT iteration's beginning): partial(t.s, t.t, rhat.s, rhat.t, s.s), so that
+//                      rho' = rhat.(s - omega t) = rhat.s - omega rhat.t and ||r'||^2 = s.s - 2 omega t.s + omega^2 t.t
 // Jobs, batches, load schedule and cache policy as in k_fused (krylov_fused.hip); what differs is the job's product (edge
 // columns only, for the tile's own blocks too), where a ghost edge comes from, and the epilogue.
 template <int MODE, int MERGE>
@@ -116,7 +124,13 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
                                                  int first, int count, int poff, int share, double *red, unsigned *ticket,
                                                  int *fault) {
   extern __shared__ __attribute__((aligned(16))) double fsm[];
-  if (sc->status != 0) return;
+  constexpr bool AB = MODE == 0, CD = MODE == 1 || MODE == 3, CDX = MODE == 3, EAB = MODE == 2;
+  if (sc->status != 0) {
+    // (as k_sweepE_y: the last launch of a group of iterations reports to the host, also behind a solve that has ended)
+    if (EAB && A.host_status && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(A.host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   double *PE = fsm;
   int *pub = reinterpret_cast<int *>(fsm + PE2_DOUBLES);
   for (int idx = threadIdx.x; idx < PE2_DOUBLES; idx += FWG) {
@@ -130,18 +144,37 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   EdgeLds &L = LL[wave];
   // pair layout of the 16-byte accesses: this lane holds cells c0 = 2 hl, c0 + 1 of block 2 i + hf
   const int hf = lane >> 5, hl = lane & 31, c0 = 2 * hl, px = c0 & 7, py = hl >> 2;
-  const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;  // momega | malpha
+  const double c1 = CD ? -sc->alpha : -sc->omega;  // malpha | momega
   const double beta = sc->beta;
-  const bool fresh = MODE == 0 && sc->iter == 0;            // p = nu = 0 (cuda.cu:436-437): not read
-  const bool restart = MODE == 0 && sc->restart_flag != 0;  // p' = rhat = r (cuda.cu:461-476)
-  constexpr int NDOT = MODE == 0 ? 1 : 2;
-  double acc[NDOT];
+  const bool fresh = AB && sc->iter == 0;                     // p = nu = 0 (cuda.cu:436-437): not read
+  const bool restart = (AB || EAB) && sc->restart_flag != 0;  // p' = rhat = r (cuda.cu:461-476)
+  // sweep E's scalars and buffers (k_sweepE_y)
+  const double alpha = sc->alpha, omega = sc->omega, malpha = -sc->alpha;
+  const bool yfirst = EAB && sc->iter == 0;  // the accumulated correction starts at zero: not read
+  const double2 *yin = nullptr;
+  double2 *yout2 = nullptr;
+  if (EAB) {
+    const int cur = sc->ycur, out = y_out_buffer(cur, sc->ybest);
+    yin = reinterpret_cast<const double2 *>(cur == 0 ? A.y0 : (cur == 1 ? A.y1 : A.y2));
+    yout2 = reinterpret_cast<double2 *>(out == 0 ? A.y0 : (out == 1 ? A.y1 : A.y2));
+  }
+  constexpr int NDOT = AB ? 1 : CDX ? 5 : 2;
+  double acc[NDOT], rmax[1] = {0.0};
 #pragma unroll
   for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
 
-  // v at one cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd, operation for operation
-  const auto form_v = [&](double a, double b, double c) -> double {
-    if (MODE == 0) {
+  // v at one cell -- the arithmetic of k_sweepA_fd / k_sweepC_fd (and, MODE 2, of k_sweepE_y in front of it), operation for
+  // operation.  d: t (MODE 2); rn: where MODE 2 leaves r'
+  const auto form_v = [&](double a, double b, double c, double d, double &rn) -> double {
+    if (EAB) {
+      const double sv = c + malpha * b;
+      rn = sv + c1 * d;
+      if (restart) return rn;
+      double v = a + c1 * b;
+      v = v * beta;
+      return v + rn;
+    }
+    if (AB) {
       if (restart || fresh) return c;
       double v = a + c1 * b;
       v = v * beta;
@@ -167,6 +200,15 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       t_stride = G * FWAVES;
     }
   }
+  // Direction.  A.rev: the rounds in descending tile order -- a launch that STARTS where the previous one on the stream
+  // ended finds the tail of what that one read and wrote in the memory-side cache (256 MB: two of the 134 MB vectors at
+  // 4096^2; walking every launch in the same direction, each line is evicted long before the next launch comes back to it).
+  // The rounds are the WORKGROUP's (sibling waves must be in the same one): a wave without a tile in the partial round --
+  // the last one ascending, the first one descending -- skips it.
+  const int t_wg = t_begin - wave;
+  const int nrounds = t_wg < t_end ? (t_end - 1 - t_wg) / t_stride + 1 : 0;
+  const bool rev = A.rev != 0;
+  const auto tile_at = [&](int j) -> int { return j < nrounds ? t_begin + (rev ? nrounds - 1 - j : j) * t_stride : t_end; };
   const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
   const int last = first + count;
   const auto load_nb = [&](int t) -> int {
@@ -207,13 +249,14 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // branch-free so that the loads go out back to back.  Ring and tile batches live in SEPARATE register sets (a ring batch
   // has no fourth vector, and two sets with clear live ranges are what the register allocator handles without spills).
   struct RawR {
-    double2 a[4], b[4], c[4];
+    double2 a[4], b[4], c[4], d[4];  // AB: p, nu, r   CD: r, nu'   MODE 2: p', nu', r, t
   };
   struct RawT {
-    double2 a[4], b[4], c[4];
+    double2 a[4], b[4], c[4], d[4], e[4];  // as RawR; e: MODE 2: y, MODE 3: rhat
   };
   const double2 *in0 = reinterpret_cast<const double2 *>(A.in0), *in1 = reinterpret_cast<const double2 *>(A.in1);
   const double2 *in2 = reinterpret_cast<const double2 *>(A.in2), *inw = reinterpret_cast<const double2 *>(A.w);
+  const double2 *int_ = reinterpret_cast<const double2 *>(A.t);
   const auto issue_ring = [&](RawR &R, const Tile &X, int pass, int half) {  // entries 16 pass + 8 half .. + 7 of X's ring list
     if (KNOCK & 6) return;
     const int ne = max(1, min(TB, X.nring - pass * TB));
@@ -225,7 +268,8 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       const size_t o = (size_t)(X.nring > 0 ? rb : X.b0) * (BC / 2) + hlo;  // (no ring: any block of the tile, loaded and dropped)
       R.a[p] = in0[o];
       R.b[p] = in1[o];
-      if (MODE == 0) R.c[p] = in2[o];
+      if (AB || EAB) R.c[p] = in2[o];
+      if (EAB) R.d[p] = int_[o];
     }
   };
   const auto issue_tile = [&](RawT &R, const Tile &X, int half) {
@@ -233,13 +277,20 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const size_t o = (size_t)(X.b0 + min(8 * half + 2 * p + hfo, X.nvalid - 1)) * (BC / 2) + hlo;
-      if (MODE == 0) {
+      if (AB) {
         R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
         R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
         R.c[p] = in2[o];
+      } else if (EAB) {
+        R.a[p] = in0[o];
+        R.b[p] = in1[o];
+        R.c[p] = in2[o];
+        R.d[p] = ld2<(POL & 0x200) != 0>(int_ + o);
+        if (!yfirst) R.e[p] = ld2<(POL & 0x040) != 0>(yin + o);
       } else {
         R.a[p] = in0[o];
         R.b[p] = in1[o];
+        if (CDX) R.e[p] = inw[o];
       }
     }
   };
@@ -247,33 +298,34 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // Schedule of a tile (both halves of a job requested a job ahead; the set that is in flight across a job on the matrix
   // cores is never the one being consumed):
   //   top             Qa, Qb = ring pass 0 of this tile in flight (requested behind the previous tile's classification)
-  //   ring pass 0     stage Qa; request Ta (tile, first half); stage Qb; request Tb; ring job; scatter
-  //   (further ring passes -- more than 16 entries: other block orders -- are requested and waited for in place)
+  //   ring pass 0     stage Qa, Qb; (further ring passes -- more than 16 entries: other block orders -- requested and waited
+  //                   for in place;) request Ta, Tb (the tile's halves); ring job; scatter
   //   tile            stage Ta; stage Tb; classify the next tile, request its ring pass 0 into Qa, Qb;
   //                   tile job; hand-over; ghost gathers; epilogue
   RawR Qa, Qb;
   RawT Ta, Tb;
   Tile T;
-  if (t_begin < t_end) {
-    T = classify(t_begin, load_nb(t_begin));
+  int j = tile_at(0) < t_end ? 0 : 1;
+  if (tile_at(j) < t_end) {
+    T = classify(tile_at(j), load_nb(tile_at(j)));
     issue_ring(Qa, T, 0, 0);  // (always: a batch set that is assigned on SOME paths only is live around the whole loop)
     issue_ring(Qb, T, 0, 1);
   }
-  int nb_next = load_nb(t_begin + t_stride);
-  int round = 0;
-  for (int t = t_begin; t < t_end; t += t_stride, round++) {
+  int nb_next = load_nb(tile_at(j + 1));
+  for (int round = j; tile_at(round) < t_end; round++) {
+    const int t = tile_at(round);
     const int b0 = T.b0, nvalid = T.nvalid, par = round & 1;
-    const bool more = t + t_stride < t_end;
+    const bool more = tile_at(round + 1) < t_end;
     double2 V[TB / 2];  // v of the tile's cells in pair layout
-    double2 W[TB / 2];  // AB: rhat (r on a restart)
+    double2 W[TB / 2];  // AB, MODE 2, MODE 3: rhat (on a restart: the new one)
     const auto stage_ring = [&](const RawR &R, int half) {
       const int lo = opaque(lane);
       double *Sst = L.S + (lo >> 5) * XS + 2 * (lo & 31);  // one base, the block pair in the instruction's offset field
 #pragma unroll
       for (int p = 0; p < 4; p++) {
-        double2 v;
-        v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
-        v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
+        double2 v, rn;
+        v.x = form_v(R.a[p].x, R.b[p].x, CD ? 0.0 : R.c[p].x, EAB ? R.d[p].x : 0.0, rn.x);
+        v.y = form_v(R.a[p].y, R.b[p].y, CD ? 0.0 : R.c[p].y, EAB ? R.d[p].y : 0.0, rn.y);
         *reinterpret_cast<double2 *>(Sst + (8 * half + 2 * p) * XS) = v;
       }
     };
@@ -297,42 +349,72 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
 #pragma unroll
       for (int p = 0; p < 4; p++) {
         const int idx = 8 * half + 2 * p + hfo;
-        double2 v;
-        v.x = form_v(R.a[p].x, R.b[p].x, MODE == 0 ? R.c[p].x : 0.0);
-        v.y = form_v(R.a[p].y, R.b[p].y, MODE == 0 ? R.c[p].y : 0.0);
+        double2 v, rn;
+        v.x = form_v(R.a[p].x, R.b[p].x, CD ? 0.0 : R.c[p].x, EAB ? R.d[p].x : 0.0, rn.x);
+        v.y = form_v(R.a[p].y, R.b[p].y, CD ? 0.0 : R.c[p].y, EAB ? R.d[p].y : 0.0, rn.y);
         if (!(KNOCK & 4)) *reinterpret_cast<double2 *>(Sst + (8 * half + 2 * p) * XS) = v;
         V[4 * half + p] = v;
-        if (MODE == 0 && restart) W[4 * half + p] = R.c[p];
-        if (MODE == 0 && idx < nvalid) {  // CD does not store s: sweep E forms it again from r and nu'
+        if (AB && restart) W[4 * half + p] = R.c[p];
+        if (EAB && restart) W[4 * half + p] = rn;
+        if (CDX) W[4 * half + p] = R.e[p];
+        if ((AB || EAB) && idx < nvalid) {  // CD does not store s: sweep E forms it again from r and nu'
           const size_t o = (size_t)(b0 + idx) * (BC / 2) + hlo;
           if (!(KNOCK & 8)) st2<(POL & 0x001) != 0>(reinterpret_cast<double2 *>(A.vout) + o, v);
-          if (restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
+          if (AB && restart) reinterpret_cast<double2 *>(A.w)[o] = R.c[p];  // rhat = r
+          if (EAB) {  // sweep E (k_sweepE_y, operation for operation): y' = y + alpha p' + omega s, r', its norms
+            double2 sv, yv = {0.0, 0.0};
+            if (!yfirst) yv = R.e[p];
+            sv.x = R.c[p].x + malpha * R.b[p].x;
+            sv.y = R.c[p].y + malpha * R.b[p].y;
+            yv.x = yv.x + alpha * R.a[p].x;
+            yv.y = yv.y + alpha * R.a[p].y;
+            yv.x = yv.x + omega * sv.x;
+            yv.y = yv.y + omega * sv.y;
+            if (!(KNOCK & 8)) {
+              st2<(POL & 0x010) != 0>(yout2 + o, yv);
+              st2<(POL & 0x020) != 0>(reinterpret_cast<double2 *>(A.rout) + o, rn);
+              if (restart) reinterpret_cast<double2 *>(A.w)[o] = rn;  // rhat = r'
+            }
+            acc[1] = __builtin_fma(rn.x, rn.x, acc[1]);
+            acc[1] = __builtin_fma(rn.y, rn.y, acc[1]);
+            rmax[0] = fmax(rmax[0], fmax(fabs(rn.x), fabs(rn.y)));
+          }
+        }
+        if (CDX && idx < nvalid) {  // rhat . s, s . s
+          acc[2] = __builtin_fma(R.e[p].x, v.x, acc[2]);
+          acc[2] = __builtin_fma(R.e[p].y, v.y, acc[2]);
+          acc[4] = __builtin_fma(v.x, v.x, acc[4]);
+          acc[4] = __builtin_fma(v.y, v.y, acc[4]);
         }
       }
     };
     // ---- ring passes ----
     // (scheduling barriers: left alone, the scheduler hoists every request to the top of the tile -- four batches in
     // flight at once, 224 registers, and the wave spills)
-    if (T.npass > 0) stage_ring(Qa, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_tile(Ta, T, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (T.npass > 0) stage_ring(Qb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_tile(Tb, T, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (T.npass > 0) ring_job(0);
+    if (T.npass > 0) {
+      stage_ring(Qa, 0);
+      stage_ring(Qb, 1);
+    }
+    // (more than 16 ring entries -- block orders other than the reference's: the further passes are requested and waited
+    // for in place, BEFORE the tile's batches go out: a ring set and both tile sets at once do not fit the register file)
     for (int pass = 1; pass < T.npass; pass++) {
+      ring_job(pass - 1);
       issue_ring(Qa, T, pass, 0);
       issue_ring(Qb, T, pass, 1);
       stage_ring(Qa, 0);
       stage_ring(Qb, 1);
-      ring_job(pass);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_tile(Ta, T, 0);
+    issue_tile(Tb, T, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (T.npass > 0) ring_job(T.npass - 1);  // the tile's batches are in flight across the job
+    __builtin_amdgcn_sched_barrier(0);
     // ---- the tile ----
     Tile N = T;
     stage_tile(Ta, 0);
-    if (MODE == 0 && !restart) {
+    __builtin_amdgcn_sched_barrier(0);
+    if ((AB || EAB) && !restart) {
 #pragma unroll
       for (int i = 0; i < TB / 2; i++) {
         const double2 *pw = inw + (((size_t)(b0 + min(2 * i + hf, nvalid - 1)) * BC + c0) >> 1);
@@ -343,12 +425,14 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     // this tile's ring list is dead: the NEXT tile is classified into it (past the wave's last tile: this tile once more --
     // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
-    N = classify(more ? t + t_stride : t, more ? nb_next : T.nb);
-    nb_next = load_nb(t + 2 * t_stride);
+    N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb);
+    nb_next = load_nb(tile_at(round + 2));
     if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
     // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
+    __builtin_amdgcn_sched_barrier(0);
     issue_ring(Qa, N, 0, 0);
     issue_ring(Qb, N, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
       // this buffer held round - 2: every sibling has read it once it has published round - 1
@@ -414,13 +498,17 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           yv.y += g.y;
         }
         }
-        if (!(KNOCK & 8)) st2<(POL & (MODE == 0 ? 0x002 : 0x008)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);
-        const double2 wv = MODE == 0 ? W[i] : V[i];
+        if (!(KNOCK & 8)) st2<(POL & (CD ? 0x008 : 0x002)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);
+        const double2 wv = CD ? V[i] : W[i];
         acc[0] = __builtin_fma(yv.x, wv.x, acc[0]);
         acc[0] = __builtin_fma(yv.y, wv.y, acc[0]);
-        if constexpr (NDOT == 2) {
+        if constexpr (CD) {
           acc[1] = __builtin_fma(yv.x, yv.x, acc[1]);
           acc[1] = __builtin_fma(yv.y, yv.y, acc[1]);
+        }
+        if constexpr (CDX) {  // rhat . t
+          acc[3] = __builtin_fma(W[i].x, yv.x, acc[3]);
+          acc[3] = __builtin_fma(W[i].y, yv.y, acc[3]);
         }
       }
     }
@@ -430,8 +518,17 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // this wave publishes nothing more: nobody may wait for it
   if (lane == 0) __hip_atomic_store(pub + wave, 1 << 30, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
-  if (MERGE && arrive_last(ticket))  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
-    finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
+  if constexpr (EAB) fused_reduce_store_max<FWAVES, MERGE != 0>(rmax[0], partials + 2 * PSTRIDE + poff);
+  if (MERGE && arrive_last(ticket)) {  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
+    if constexpr (EAB) {
+      static_assert(MERGE == 1 || !EAB, "MODE 2: one GPU, finish in the kernel");
+      finish_reduce<true, true>(partials, poff + (int)gridDim.x, 2, 1, red, sc, 4, A.host_status, fsm);
+    } else if constexpr (CDX) {
+      finish_reduce_n<5>(partials, poff + (int)gridDim.x, red, sc, 5, fsm);
+    } else {
+      finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
+    }
+  }
 }
 
 // every tile of [first, first + count) has at most EXP_SLOTS perimeter sides: the export buffers hold them all

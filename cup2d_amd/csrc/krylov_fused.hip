@@ -237,6 +237,12 @@ struct FusedArgs {
   //   CD reads  e1 = (P_inv nu') edges AB has just written, e2, e3 as AB;  writes o0 = z2' edges, o1 = (P_inv t') edges
   const double *e0, *e1, *e2, *e3;
   double *o0, *o1;
+  // k_edge MODE 2 (sweep E + the next A+B): t, the three buffers of the accumulated correction (k_sweepE_y), where r' goes,
+  // and the host's status word when this launch is the one of its group that reports
+  const double *t;
+  double *y0, *y1, *y2, *rout;
+  int *host_status;
+  int rev;  // k_edge: the tiles in descending order (krylov_edge.h "Direction")
 };
 
 // one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)
@@ -254,6 +260,23 @@ static __device__ __forceinline__ void fused_reduce_store(double (&v)[N], double
     double a = red[threadIdx.x][0];
     for (int k = 1; k < NW; k++) a += red[threadIdx.x][k];
     double *dst = partials + (size_t)threadIdx.x * PSTRIDE + blockIdx.x;
+    if (COHERENT) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = a;
+  }
+}
+
+// the maximum of one value per lane over a workgroup of NW waves, to this workgroup's partial
+template <int NW, bool COHERENT>
+static __device__ __forceinline__ void fused_reduce_store_max(double v, double *partials) {
+  __shared__ double redm[NW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double w = wave_max(v);
+  if (lane == 0) redm[wave] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = redm[0];
+    for (int k = 1; k < NW; k++) a = fmax(a, redm[k]);
+    double *dst = partials + blockIdx.x;
     if (COHERENT) __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *dst = a;
   }
@@ -894,23 +917,53 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // lead time of the loads is what a tile's 20 us consist of -- it is the chain of short dependent phases of ONE wave
 // (classification, staging, LDS gathers, epilogue; two waves per SIMD cannot overlap much of it), and the hand-over adds
 // to that chain what a barrier did in round 2.  The full form stays the default.  DESIGN.md 4.5.
+static int form_of(const cup2d_ctx *c) {  // cup2d_set_solver_form, else the process default
+  static const int env = [] {
+    const char *e = getenv("CUP2D_FUSED_FORM");
+    return !e ? CUP2D_FORM_AUTO : !strcmp(e, "full") ? CUP2D_FORM_FULL : !strcmp(e, "edge") ? CUP2D_FORM_EDGE : !strcmp(e, "eab") ? CUP2D_FORM_EAB : CUP2D_FORM_AUTO;
+  }();
+  return c->solver_form != CUP2D_FORM_AUTO ? c->solver_form : env;
+}
 static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
-  static const bool on = [] { const char *e = getenv("CUP2D_FUSED_FORM"); return e && strcmp(e, "edge") == 0; }();
+  const bool on = form_of(c) == CUP2D_FORM_EDGE;
   const bool ghosts = c->nghost > 0 && c->exchange;
   return on && !c->custom_Pinv && !c->mat.active && re == 0 && dbg == 0 && (!ghosts || ghost_blocks);
 }
+// the organisation with sweep E and the next A+B in one launch (k_edge MODE 2 / 3): the default wherever the edge form
+// applies -- built-in preconditioner, same-level stencil -- on one GPU with the finish in the kernel.  CUP2D_FUSED_FORM =
+// full | edge selects the three-launch organisation (k_fused | k_edge MODE 0 / 1), eab (or unset) this one.
+static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring) {
+  const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
+  return on && merge == 1 && !c->custom_Pinv && !c->mat.active && !(c->nghost > 0 && c->exchange) && dbg == 0 && !stored_ring;
+}
+static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has <= 16 perimeter sides
+  if (c->edge_share < 0) c->edge_share = edge_share_ok(c->h_nbr.data(), 0, c->nblocks) ? 1 : 0;
+  return c->edge_share;
+}
+// sharing between sibling waves per kind of sweep (it pays where the ring is four vectors wide, MODE 2; it costs the short
+// C+D sweep more in waiting than it saves): CUP2D_EDGE_SHARE = bit mask, bit MODE; default 0b0101 (A+B and MODE 2)
+static int edge_share_mode(cup2d_ctx *c, int mode) {
+  static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
+  return ((mask >> mode) & 1) && edge_share_of(c);
+}
+template <int MODE>
+static int eab_sweep(cup2d_ctx *c, const FusedArgs &a) {
+  const int nb = c->nblocks, g = fused_grid(c, nb);
+  hipLaunchKernelGGL((k_edge<MODE, 1>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
+                     c->d_partials, 0, nb, 0, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 template <int MODE>
 static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks, int re = 0) {
   const int nb = c->nblocks;
   if (edge_form(c, ghost_blocks, re, dbg)) {
-    if (c->edge_share < 0) {
-      static const bool share_on = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return !e || atoi(e) != 0; }();
-      c->edge_share = share_on && edge_share_ok(c->h_nbr.data(), 0, nb) ? 1 : 0;
-    }
+    const int share = edge_share_mode(c, MODE);
     const int g = fused_grid(c, nb);
     const auto go = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, 0, nb,
-                         0, c->edge_share, c->d_red, c->d_ticket, c->d_fault);
+                         0, share, c->d_red, c->d_ticket, c->d_fault);
     };
     if (merge == 1) go(k_edge<MODE, 1>);
     else if (merge == 2) go(k_edge<MODE, 2>);
@@ -1064,7 +1117,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     const void *ke[] = {reinterpret_cast<const void *>(&k_edge<0, 0>), reinterpret_cast<const void *>(&k_edge<0, 1>),
                         reinterpret_cast<const void *>(&k_edge<0, 2>), reinterpret_cast<const void *>(&k_edge<1, 0>),
-                        reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>)};
+                        reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>),
+                        reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1120,7 +1174,48 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const int GROUP = merge != 0 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
-  for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
+  const bool eab = eab_form(c, merge, dbg, stored);
+  if (eab) {
+    // A+B of iteration 0, then per iteration TWO launches: C+D with the sums the next beginning needs (MODE 3), and sweep E
+    // with the next A+B (MODE 2).  p, nu and r alternate between two buffers (r': ring entries re-read r of other tiles; the
+    // second one is the s vector this organisation never stores)
+    double *P[2] = {c->d_p2, c->d_p}, *N[2] = {c->d_nu2, c->d_nu}, *R[2] = {c->d_r, c->d_s};
+    static const int zigzag = [] { const char *e = getenv("CUP2D_EAB_ZIGZAG"); return e ? atoi(e) : 1; }();
+    {
+      ProfScope prof(c, CUP2D_T_SWEEP_A);
+      c->prof_sample = true;
+      FusedArgs a = {};
+      a.in0 = c->d_p; a.in1 = c->d_nu; a.in2 = c->d_r; a.w = c->d_rhat; a.vout = P[0]; a.yout = N[0];
+      CUP2D_TRY(eab_sweep<0>(c, a));
+    }
+    for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
+      const int grp = k / GROUP, slot = grp % AHEAD_G;
+      const bool first_of_group = k % GROUP == 0, last_of_group = k % GROUP == GROUP - 1;
+      if (first_of_group && grp >= AHEAD_G) {
+        CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
+        if (*(volatile int *)&c->h_status[slot] != 0) break;
+      }
+      c->prof_sample = (k % 8 == 0) && k < max_iter;
+      const int o = k & 1, n = o ^ 1;
+      {
+        ProfScope prof(c, CUP2D_T_SWEEP_C);
+        FusedArgs a = {};
+        a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t;
+        a.rev = zigzag;  // (A+B of iteration 0 and MODE 2 ascend: this one starts where they end, and ends where MODE 2 starts)
+        CUP2D_TRY(eab_sweep<3>(c, a));
+      }
+      {
+        ProfScope prof(c, CUP2D_T_SWEEP_EA);
+        FusedArgs a = {};
+        a.in0 = P[o]; a.in1 = N[o]; a.in2 = R[o]; a.w = c->d_rhat; a.vout = P[n]; a.yout = N[n];
+        a.t = c->d_t; a.y0 = c->d_y; a.y1 = c->d_yopt; a.y2 = c->d_xopt; a.rout = R[n];
+        a.host_status = last_of_group ? &c->h_status[slot] : nullptr;
+        CUP2D_TRY(eab_sweep<2>(c, a));
+      }
+      if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
+    }
+  }
+  for (int k = 0; !eab && k <= max_iter + AHEAD_G * GROUP; k++) {
     const int grp = k / GROUP, slot = grp % AHEAD_G;
     const bool first_of_group = k % GROUP == 0, last_of_group = k % GROUP == GROUP - 1;
     if (first_of_group && grp >= AHEAD_G) {

@@ -185,10 +185,13 @@ class Simulation(BodyOps):
     def set_precond(self, kind):
         _l.check(self.L.cup2d_set_precond(self._ctx, int(kind)), "set_precond")
 
-    def set_solver(self, fused=False, finish_in_kernel=False):
-        """organisation of a BiCGSTAB iteration (include/cup2d_hip.h cup2d_solver_kind)"""
+    def set_solver(self, fused=False, finish_in_kernel=False, form=None):
+        """organisation of a BiCGSTAB iteration (include/cup2d_hip.h cup2d_solver_kind); form: 'auto' | 'full' | 'edge' | 'eab'
+        (cup2d_fused_form), None leaves it as it is"""
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)),
                  "set_solver")
+        if form is not None:
+            _l.check(self.L.cup2d_set_solver_form(self._ctx, ("auto", "full", "edge", "eab").index(form)), "set_solver_form")
 
     def keep_last_iterate(self, on=True):
         """diagnostic (cup2d_solver_keep_last): the next solves also keep their LAST iterate"""

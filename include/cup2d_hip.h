@@ -176,6 +176,16 @@ int cup2d_set_precond(cup2d_ctx *ctx, int kind);
  * CUP2D_FINISH_IN_KERNEL (0|1) override them at cup2d_create. */
 typedef enum { CUP2D_SOLVER_SWEEPS = 0, CUP2D_SOLVER_FUSED = 1 } cup2d_solver_kind;
 int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
+/* Form of the FUSED organisation (same recurrences; they differ by round-off and in bytes per iteration):
+ *   CUP2D_FORM_AUTO  the default: EAB where it applies, FULL elsewhere (the process-wide default can be set with
+ *                    CUP2D_FUSED_FORM = full | edge | eab)
+ *   CUP2D_FORM_FULL  three launches per iteration (A+B, C+D, E), dense 64 x 64 block product: every configuration of FUSED
+ *   CUP2D_FORM_EDGE  three launches, A P_inv v = v + ghost edges of P_inv v (built-in preconditioner, same-level stencil)
+ *   CUP2D_FORM_EAB   two launches: C+D with the sums of the next beginning, and E together with the next iteration's A+B
+ *                    (112 B/cell/iteration); one GPU, finish in the kernel, built-in preconditioner, same-level stencil.
+ *                    rho = rhat.r comes from the sums of C+D (rhat.s - omega rhat.t) instead of its own pass over r. */
+typedef enum { CUP2D_FORM_AUTO = 0, CUP2D_FORM_FULL = 1, CUP2D_FORM_EDGE = 2, CUP2D_FORM_EAB = 3 } cup2d_fused_form;
+int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
 /* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 /* Diagnostic: the reference returns the BEST iterate in the max norm (cuda.cu:535-547), which within a capped number of
@@ -446,7 +456,8 @@ typedef enum {
   CUP2D_T_HALO = 10,        /* pack / unpack */
   CUP2D_T_INIT_RESIDUAL = 11, /* r = b - A x0 + its reductions (once per solve) */
   CUP2D_T_SMOOTHER = 12,    /* weighted-Jacobi sweep / Poisson residual (k_smoother) */
-  CUP2D_T_NTIMERS = 13
+  CUP2D_T_SWEEP_EA = 13,    /* sweep E + the next iteration's sweeps A, B in one launch (CUP2D_FUSED_FORM=eab) */
+  CUP2D_T_NTIMERS = 14
 } cup2d_timer;
 int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);

@@ -179,19 +179,21 @@ print("RESULT " + json.dumps(out))
 '''
 
 
-@pytest.mark.parametrize("share", ["1", "0"])
-def test_edge_form_of_the_fused_sweeps(gpu_lib, share):
-    """csrc/krylov_edge.h (opt-in, CUP2D_FUSED_FORM=edge; the switch is read once per process, hence the child): A P_inv v =
-    v + ghost edges of z, with the z edges of sibling tiles handed over through LDS (share 1) or every perimeter edge
-    recomputed (0).  Four iterations at zero tolerance equal the five sweeps to round-off on every block order (grids whose
-    tiles have more than 16 perimeter sides fall back to recomputation by themselves), and a converged solve satisfies the
-    reference's criterion against the oracle's operator."""
+@pytest.mark.parametrize("form,share", [("eab", "5"), ("eab", "15"), ("eab", "0"), ("edge", "15"), ("edge", "0"), ("full", "0")])
+def test_forms_of_the_fused_sweeps(gpu_lib, form, share):
+    """The organisations of the tile-fused solver on one GPU (CUP2D_FUSED_FORM; read once per process, hence the child):
+    eab (the default: csrc/krylov_edge.h MODE 2 / 3 -- sweep E and the next A+B in one launch, rho' and the restart decision
+    from the sums of C+D), edge (A P_inv v = v + ghost edges of z in three launches), full (k_fused).  share: per kind of
+    sweep, the z edges of sibling tiles handed over through LDS or every perimeter edge recomputed.  Four iterations at zero
+    tolerance equal the five sweeps to round-off on every block order (grids whose tiles have more than 16 perimeter sides
+    fall back to recomputation by themselves), and a converged solve satisfies the reference's criterion against the oracle's
+    operator."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CUP2D_FUSED_FORM="edge", CUP2D_EDGE_SHARE=share)
+    env = dict(os.environ, CUP2D_FUSED_FORM=form, CUP2D_EDGE_SHARE=share)
     r = subprocess.run([sys.executable, "-c", _EDGE_CHILD % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     txt = r.stdout.decode()
     lines = [l for l in txt.splitlines() if l.startswith("RESULT ")]

@@ -37,6 +37,18 @@ if what == "check":
             d = float(np.abs(xs[True][0] - xs[False][0]).max() / max(1e-300, np.abs(xs[False][0]).max()))
             res[iters] = {"rel_diff_last_iterate": d, "err": [xs[True][1]["err"], xs[False][1]["err"]], "iters": [xs[True][1]["iters"], xs[False][1]["iters"]]}
         out["%%s %%dx%%d" %% (order, nbx, nby)] = res
+    # zero tolerance, many iterations: the breakdown restarts behind convergence to round-off, best iterate returned
+    g = BlockGrid(8, 8, order="hilbert")
+    b = rng.uniform(-1, 1, (g.ny, g.nx)); b -= b.mean()
+    rr = {}
+    for fused in (True, False):
+        with cup2d_amd.Simulation(8, 8, grid=g) as s:
+            s.set_precond(L.PRECOND_MFMA)
+            s.set_solver(fused=fused, finish_in_kernel=True)
+            s.tmp = b; s.fill(L.PRES, 0.0)
+            info = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=300)
+            rr[fused] = {k: info[k] for k in ("iters", "restarts", "err")}
+    out["restarts 8x8"] = rr
 else:
     n = 4096
     from oracle import oracle as O
@@ -52,7 +64,7 @@ else:
             s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=50)
         s.synchronize(); el = time.perf_counter() - t0
         sw = {}
-        for name in ("sweep_A", "sweep_C", "sweep_E", "advect_stage", "poisson_rhs", "project"):
+        for name in ("sweep_A", "sweep_C", "sweep_E", "sweep_EA", "advect_stage", "poisson_rhs", "project"):
             ms, calls = s.get_timing(L.TIMER_NAMES.index(name))
             if calls:
                 sw[name] = round(ms / calls * 1e3, 1)
@@ -69,7 +81,13 @@ def run(what, env):
             return json.loads(line[7:])
     return {"rc": r.returncode, "tail": txt[-1500:]}
 
-variants = {"edge+share": {"CUP2D_FUSED_FORM": "edge"}, "edge": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "0"}, "full": {"CUP2D_FUSED_FORM": "full"}}
+variants = {"eab": {"CUP2D_FUSED_FORM": "eab"}, "eab-allshare": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EDGE_SHARE": "15"},
+            "eab-noshare": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EDGE_SHARE": "0"},
+            "eab-nozigzag": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EAB_ZIGZAG": "0"},
+            "edge+share": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "15"}, "edge": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "0"}, "full": {"CUP2D_FUSED_FORM": "full"}}
+only = os.environ.get("VARIANTS")
+if only:
+    variants = {k: v for k, v in variants.items() if k in only.split(",")}
 which = sys.argv[1:] or ["check", "time"]
 for what in which:
     for name, env in variants.items():

@@ -43,9 +43,9 @@ with cup2d_amd.Simulation(n // 8, nu=1e-3) as s:
         s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=50)
     s.synchronize(); el = time.perf_counter() - t0
     sw = {}
-    for name in ("sweep_A", "sweep_C", "sweep_E"):
+    for name in ("sweep_A", "sweep_C", "sweep_E", "sweep_EA"):
         ms, calls = s.get_timing(L.TIMER_NAMES.index(name))
-        sw[name] = round(ms / calls * 1e3, 1)
+        sw[name] = round(ms / max(calls, 1) * 1e3, 1)
     out.update(ms_per_step=round(el / 6 * 1e3, 3), avg_us=sw)
 print("RESULT " + json.dumps(out))
 ''' % ROOT

@@ -49,6 +49,16 @@ constexpr int EDGE_SPIN_LIMIT = 1 << 22;  // a wave that waits longer than this 
 #define CUP2D_EDGE_KNOCK 0
 #endif
 constexpr int KNOCK = CUP2D_EDGE_KNOCK;
+// cache policy of the streams MODE 2 / 3 add (non-temporal where the bit is set; CUP2D_POLICY in krylov_fused.hip has the
+// others): 0x01 / 0x02 / 0x04 MODE 2's tile loads of p', nu', r; 0x08 MODE 3's rhat; 0x10 / 0x20 the stores of r', nu'';
+// 0x40 / 0x80 MODE 3's tile loads of r, nu'
+// Measured at 4096^2 (tools/gpu_calls/gpu_r03_call19.sh; step of 50 iterations, MODE 3 / MODE 2 in us):
+//   0x00  19.9 ms  125 / 247      0x01  19.65  125 / 243      0x07  19.18  125 / 231  <- default
+//   0x08  19.9     117 / 256      0x30  20.0   123 / 252      0xC0  20.3   125 / 256
+#ifndef CUP2D_POLICY2
+#define CUP2D_POLICY2 0x07
+#endif
+constexpr unsigned POL2 = CUP2D_POLICY2;
 // set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask held in registers)
 static __device__ __forceinline__ int bits_below_lane(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -282,15 +292,15 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
         R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
         R.c[p] = in2[o];
       } else if (EAB) {
-        R.a[p] = in0[o];
-        R.b[p] = in1[o];
-        R.c[p] = in2[o];
+        R.a[p] = ld2<(POL2 & 0x01) != 0>(in0 + o);
+        R.b[p] = ld2<(POL2 & 0x02) != 0>(in1 + o);
+        R.c[p] = ld2<(POL2 & 0x04) != 0>(in2 + o);
         R.d[p] = ld2<(POL & 0x200) != 0>(int_ + o);
         if (!yfirst) R.e[p] = ld2<(POL & 0x040) != 0>(yin + o);
       } else {
-        R.a[p] = in0[o];
-        R.b[p] = in1[o];
-        if (CDX) R.e[p] = inw[o];
+        R.a[p] = ld2<(POL2 & 0x40) != 0 && CDX>(in0 + o);
+        R.b[p] = ld2<(POL2 & 0x80) != 0 && CDX>(in1 + o);
+        if (CDX) R.e[p] = ld2<(POL2 & 0x08) != 0>(inw + o);
       }
     }
   };
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
             yv.y = yv.y + omega * sv.y;
             if (!(KNOCK & 8)) {
               st2<(POL & 0x010) != 0>(yout2 + o, yv);
-              st2<(POL & 0x020) != 0>(reinterpret_cast<double2 *>(A.rout) + o, rn);
+              st2<(POL2 & 0x10) != 0>(reinterpret_cast<double2 *>(A.rout) + o, rn);
               if (restart) reinterpret_cast<double2 *>(A.w)[o] = rn;  // rhat = r'
             }
             acc[1] = __builtin_fma(rn.x, rn.x, acc[1]);
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           yv.y += g.y;
         }
         }
-        if (!(KNOCK & 8)) st2<(POL & (CD ? 0x008 : 0x002)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);
+        if (!(KNOCK & 8)) st2<EAB ? (POL2 & 0x20) != 0 : (POL & (CD ? 0x008 : 0x002)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);
         const double2 wv = CD ? V[i] : W[i];
         acc[0] = __builtin_fma(yv.x, wv.x, acc[0]);
         acc[0] = __builtin_fma(yv.y, wv.y, acc[0]);

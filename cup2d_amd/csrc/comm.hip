@@ -179,30 +179,34 @@ static int rccl_allreduce(void *user, double *buf, int count, int op, void *stre
 // three doubles per rank), then ONE single-wave kernel that adds / maximises them in rank order -- a summation order that
 // does not depend on the algorithm RCCL picks, and a sum and a max in one collective -- and runs the scalar update of the
 // stage on the result (krylov_common.h scalars_update; stage < 0: only the reduced values, into red).
+constexpr int RED_REC = 8;  // doubles per rank in the gathered record (= the size of d_red)
 __global__ void k_gather_scalars(const double *__restrict__ g, int nranks, int nsum, int with_max, double *__restrict__ red,
                                  KrylovScalars *sc, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (stage > 0 && sc->status != 0) {  // the solve is over: the sweeps before this were no-ops
     // (a group's last iteration still tells the host, solve_fused_impl: one look per group of iterations)
-    if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((stage == 3 || stage == 4) && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  double v[3] = {0.0, 0.0, 0.0};
+  // (a record per rank: RED_REC doubles -- up to five sums, krylov_common.h stage 5; with a maximum it is entry 2 and the
+  // sums are at most two)
+  double v[RED_REC];
+  for (int k = 0; k < RED_REC; k++) v[k] = 0.0;
   for (int r = 0; r < nranks; r++) {
-    if (nsum > 0) v[0] += g[3 * r];
-    if (nsum > 1) v[1] += g[3 * r + 1];
-    if (with_max) v[2] = fmax(v[2], g[3 * r + 2]);
+    for (int k = 0; k < nsum && k < RED_REC; k++)
+      if (!(with_max && k == 2)) v[k] += g[RED_REC * r + k];
+    if (with_max) v[2] = fmax(v[2], g[RED_REC * r + 2]);
   }
-  red[0] = v[0]; red[1] = v[1]; red[2] = v[2];
+  for (int k = 0; k < RED_REC; k++) red[k] = v[k];
   if (stage >= 0) {
     scalars_update(sc, v, stage);
-    if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((stage == 3 || stage == 4) && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 int comm_reduce_scalars(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status) {
   RcclComm *rc = c->rccl;
   rc->n_allgather++;
-  CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, 3, ncclDouble, rc->red, c->stream));
+  CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, RED_REC, ncclDouble, rc->red, c->stream));
   hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, nsum, with_max, c->d_red, c->d_sc,
                      stage, host_status);
   CUP2D_HIP_CB(hipGetLastError());
@@ -287,12 +291,12 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     rc->peer.push_back(peer_rank[i]); rc->soff.push_back(send_offset[i]);
     rc->roff.push_back(recv_offset[i]); rc->cnt.push_back(nstrips[i]); rc->rcnt.push_back(nstrips_recv[i]);
   }
-  // widest message: whole blocks of two Krylov vectors = 128 doubles per strip (the WENO halo is 3 x 8 x 2 = 48)
-  const size_t strip = 2 * BC;
+  // widest message: whole blocks of three Krylov vectors = 192 doubles per strip (the WENO halo is 3 x 8 x 2 = 48)
+  const size_t strip = 3 * BC;
   CUP2D_HIP_CHECK(hipMalloc(&rc->d_send, sizeof(double) * strip * (size_t)(c->plan.nsend > 0 ? c->plan.nsend : 1)));
   CUP2D_HIP_CHECK(hipMalloc(&rc->d_recv, sizeof(double) * strip * (size_t)(c->plan.nrecv > 0 ? c->plan.nrecv : 1)));
   CUP2D_HIP_CHECK(hipMalloc(&rc->d_red, sizeof(double) * 8));
-  CUP2D_HIP_CHECK(hipMalloc(&rc->d_gather, sizeof(double) * 3 * (size_t)nranks));
+  CUP2D_HIP_CHECK(hipMalloc(&rc->d_gather, sizeof(double) * RED_REC * (size_t)nranks));
   CUP2D_HIP_CHECK(hipMemset(rc->d_red, 0, sizeof(double) * 8));
   CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&rc->comm_stream, hipStreamNonBlocking));
   CUP2D_HIP_CHECK(hipEventCreateWithFlags(&rc->ev_packed, hipEventDisableTiming));

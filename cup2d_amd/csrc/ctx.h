@@ -321,6 +321,8 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
+int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
+int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);
 void bodies_release(cup2d_ctx *c);  // penalize.hip
 void walk_plans_release(cup2d_ctx *c);  // advect.hip
 // comm.hip

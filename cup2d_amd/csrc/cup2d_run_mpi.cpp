@@ -175,7 +175,7 @@ struct MpiTransport {
   std::vector<MPI_Request> req;
   double *pending_dst = nullptr;
   size_t pending_doubles = 0;
-  static constexpr int MAX_STRIP = 128;  // include/cup2d_hip.h cup2d_set_comm
+  static constexpr int MAX_STRIP = CUP2D_MAX_STRIP_DOUBLES;  // include/cup2d_hip.h cup2d_set_comm
   void release() {
     if (d_send) (void)hipFree(d_send);
     if (d_recv) (void)hipFree(d_recv);

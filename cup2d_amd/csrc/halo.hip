@@ -75,6 +75,53 @@ __global__ __launch_bounds__(WG) void k_halo_blocks2(double *__restrict__ f0, do
     else f[cell] = buf[i];
   }
 }
+// ... and of THREE (r', p'', nu'' behind the launch that holds sweep E and the next A+B, krylov_fused.hip)
+template <bool PACK>
+__global__ __launch_bounds__(WG) void k_halo_blocks3(double *__restrict__ f0, double *__restrict__ f1, double *__restrict__ f2,
+                                                     double *__restrict__ buf, const int32_t *__restrict__ blocks,
+                                                     const int32_t *__restrict__ faces, int nstrips) {
+  const size_t total = (size_t)nstrips * 3 * BC;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const int s = (int)(i / (3 * BC)), q = (int)(i - (size_t)s * 3 * BC), v = q / BC;
+    double *f = v == 0 ? f0 : (v == 1 ? f1 : f2);
+    const size_t cell = (size_t)blocks[s] * BC + strip_cell(faces[s], BS, q & (BC - 1));
+    if (PACK) buf[i] = f[cell];
+    else f[cell] = buf[i];
+  }
+}
+int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  if (c->plan.nsend > 0) {
+    const size_t total = (size_t)c->plan.nsend * 3 * BC;
+    int grid = (int)((total + WG - 1) / WG);
+    if (grid > c->grid) grid = c->grid;
+    ProfScope prof(c, CUP2D_T_HALO);
+    hipLaunchKernelGGL(k_halo_blocks3<true>, dim3(grid), dim3(WG), 0, c->stream, const_cast<double *>(v0), const_cast<double *>(v1),
+                       const_cast<double *>(v2), c->d_send, c->plan.d_send_block, c->plan.d_send_face, c->plan.nsend);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  if (c->exchange(c->comm_user, c->d_send, c->d_recv, 3 * BC, c->stream) != 0) {
+    set_error("exchange callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  return CUP2D_OK;
+}
+int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+    set_error("wait callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  if (c->plan.nrecv == 0) return CUP2D_OK;
+  const size_t total = (size_t)c->plan.nrecv * 3 * BC;
+  int grid = (int)((total + WG - 1) / WG);
+  if (grid > c->grid) grid = c->grid;
+  ProfScope prof(c, CUP2D_T_HALO);
+  hipLaunchKernelGGL(k_halo_blocks3<false>, dim3(grid), dim3(WG), 0, c->stream, v0, v1, v2, c->d_recv, c->plan.d_recv_block,
+                     c->plan.d_recv_face, c->plan.nrecv);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1) {
   if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
   if (c->plan.nsend > 0) {

@@ -695,11 +695,11 @@ __global__ __launch_bounds__(WG) void k_finish_partials(const double *__restrict
 __global__ void k_scalars(KrylovScalars *sc, const double *__restrict__ red, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (stage != 0 && sc->status != 0) {  // the solve is over; a group's last iteration still tells the host
-    if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((stage == 3 || stage == 4) && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   scalars_update(sc, red, stage);
-  if (stage == 3 && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((stage == 3 || stage == 4) && host_status) __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The rank-local values in d_red[0 .. nsum) (sums) and d_red[2] (max) reduced over the ranks, then the scalar update of

@@ -232,7 +232,7 @@ static __device__ __forceinline__ void finish_reduce_n(const double *partials, i
     double loc[NS];
 #pragma unroll
     for (int k = 0; k < NS; k++) loc[k] = sm[k][0];
-    for (int k = 0; k < NS && k < 3; k++) red[k] = loc[k];
+    for (int k = 0; k < NS; k++) red[k] = loc[k];  // (red holds eight doubles)
     if (fused_stage >= 0) scalars_update(sc, loc, fused_stage);
   }
 }

@@ -118,7 +118,7 @@ static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int 
 //                      y = nu' = p' + ghosts(P_inv p') ; partial(rhat . nu')             (484-488)
 // MODE 1 (sweeps C+D): v = s  = r - alpha nu'                                            (499-502)
 //                      y = t  = s + ghosts(P_inv s)   ; partial(t . s, t . t)           (503-509)
-// MODE 2 (sweep E of iteration k + sweeps A+B of iteration k + 1 in one pass over the cells; one GPU, finish in the kernel):
+// MODE 2 (sweep E of iteration k + sweeps A+B of iteration k + 1 in one pass over the cells; finish in the kernel):
 //                      s = r - alpha nu' ; y' = y + alpha p' + omega s ; r' = s - omega t          (498-502, 520-525)
 //                      v = p'' = beta' (p' - omega nu') + r'  (restart: p'' = rhat = r') ; y = nu'' = p'' + ghosts(P_inv p'')
 //                      partial(rhat . nu'', r' . r', max|r'|)
@@ -343,9 +343,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       wave_lds_sync();
       edge_precond(L.S, PE, lane);  // S[e * XS + 8 * side + q] = z of entry (block) e on its four edges
       const int ne = min(TB, T.nring - pass * TB);
+      const int lo = opaque(lane);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
+        const int idx = lo + 64 * h, e = idx >> 3, q = idx & 7;
         if (e < ne) {
           const int dst = L.ring_dst[pass * TB + e];  // entry e feeds slot dst = block * 4 + side with the OPPOSITE edge
           L.GE[dst * GS + q] = L.S[e * XS + 8 * ((dst & 3) ^ 1) + q];
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           const EdgeLds &O = LL[u];
           const unsigned long long m = O.xmask[par];
           const int bit = (T.nb - (b0 + (u - wave) * TB)) * 4 + (ss ^ 1);  // the slot of the neighbour block that faces this one
-          const int slot = min(__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);
+          const int slot = min((int)__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);  // (int: min(unsigned, int) resolves to the double overload)
 #pragma unroll
           for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[par][slot * BS + q];
         }
@@ -530,11 +531,12 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
   if constexpr (EAB) fused_reduce_store_max<FWAVES, MERGE != 0>(rmax[0], partials + 2 * PSTRIDE + poff);
   if (MERGE && arrive_last(ticket)) {  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
+    // MERGE 1: the scalar update too; MERGE 2 (N ranks): this rank's sums into red, the reduction over the ranks and the
+    // scalar kernel follow on the stream
     if constexpr (EAB) {
-      static_assert(MERGE == 1 || !EAB, "MODE 2: one GPU, finish in the kernel");
-      finish_reduce<true, true>(partials, poff + (int)gridDim.x, 2, 1, red, sc, 4, A.host_status, fsm);
+      finish_reduce<true, true>(partials, poff + (int)gridDim.x, 2, 1, red, sc, MERGE == 1 ? 4 : -1, MERGE == 1 ? A.host_status : nullptr, fsm);
     } else if constexpr (CDX) {
-      finish_reduce_n<5>(partials, poff + (int)gridDim.x, red, sc, 5, fsm);
+      finish_reduce_n<5>(partials, poff + (int)gridDim.x, red, sc, MERGE == 1 ? 5 : -1, fsm);
     } else {
       finish_reduce<true, true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr, fsm);
     }

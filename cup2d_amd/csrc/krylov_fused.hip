@@ -932,9 +932,13 @@ static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
 // the organisation with sweep E and the next A+B in one launch (k_edge MODE 2 / 3): the default wherever the edge form
 // applies -- built-in preconditioner, same-level stencil -- on one GPU with the finish in the kernel.  CUP2D_FUSED_FORM =
 // full | edge selects the three-launch organisation (k_fused | k_edge MODE 0 / 1), eab (or unset) this one.
-static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring) {
+// N ranks (merge 2): in the ghost-block form -- whole boundary blocks of t behind the reduction of C+D, of r', p'', nu'' in one
+// message behind the reduction of the other launch; two reductions over the ranks per iteration instead of three.
+static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring, bool ghost_blocks) {
   const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
-  return on && merge == 1 && !c->custom_Pinv && !c->mat.active && !(c->nghost > 0 && c->exchange) && dbg == 0 && !stored_ring;
+  const bool ghosts = c->nghost > 0 && c->exchange;
+  return on && (merge == 1 || merge == 2) && !c->custom_Pinv && !c->mat.active && (!ghosts || (merge == 2 && ghost_blocks)) && dbg == 0 &&
+         !stored_ring;
 }
 static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has <= 16 perimeter sides
   if (c->edge_share < 0) c->edge_share = edge_share_ok(c->h_nbr.data(), 0, c->nblocks) ? 1 : 0;
@@ -947,10 +951,14 @@ static int edge_share_mode(cup2d_ctx *c, int mode) {
   return ((mask >> mode) & 1) && edge_share_of(c);
 }
 template <int MODE>
-static int eab_sweep(cup2d_ctx *c, const FusedArgs &a) {
+static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge) {
   const int nb = c->nblocks, g = fused_grid(c, nb);
-  hipLaunchKernelGGL((k_edge<MODE, 1>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc,
-                     c->d_partials, 0, nb, 0, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
+  const auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, 0, nb,
+                       0, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
+  };
+  if (merge == 1) go(k_edge<MODE, 1>);
+  else go(k_edge<MODE, 2>);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
@@ -1118,7 +1126,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     const void *ke[] = {reinterpret_cast<const void *>(&k_edge<0, 0>), reinterpret_cast<const void *>(&k_edge<0, 1>),
                         reinterpret_cast<const void *>(&k_edge<0, 2>), reinterpret_cast<const void *>(&k_edge<1, 0>),
                         reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>),
-                        reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>)};
+                        reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>),
+                        reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1174,7 +1183,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const int GROUP = merge != 0 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
-  const bool eab = eab_form(c, merge, dbg, stored);
+  const bool eab = eab_form(c, merge, dbg, stored, gb);
   if (eab) {
     // A+B of iteration 0, then per iteration TWO launches: C+D with the sums the next beginning needs (MODE 3), and sweep E
     // with the next A+B (MODE 2).  p, nu and r alternate between two buffers (r': ring entries re-read r of other tiles; the
@@ -1186,7 +1195,12 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       c->prof_sample = true;
       FusedArgs a = {};
       a.in0 = c->d_p; a.in1 = c->d_nu; a.in2 = c->d_r; a.w = c->d_rhat; a.vout = P[0]; a.yout = N[0];
-      CUP2D_TRY(eab_sweep<0>(c, a));
+      CUP2D_TRY(eab_sweep<0>(c, a, merge));
+    }
+    if (merge == 2) {  // N ranks: the ghost blocks of nu' and p' in flight behind the reduction
+      if (gb) CUP2D_TRY(exchange_begin_blocks2(c, N[0], P[0]));
+      CUP2D_TRY(finish_local(c, 1, 0, 1));
+      if (gb) CUP2D_TRY(exchange_end_blocks2(c, N[0], P[0]));
     }
     for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
       const int grp = k / GROUP, slot = grp % AHEAD_G;
@@ -1202,15 +1216,26 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         FusedArgs a = {};
         a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t;
         a.rev = zigzag;  // (A+B of iteration 0 and MODE 2 ascend: this one starts where they end, and ends where MODE 2 starts)
-        CUP2D_TRY(eab_sweep<3>(c, a));
+        CUP2D_TRY(eab_sweep<3>(c, a, merge));
       }
+      if (merge == 2) {  // MODE 2 recomputes r' of the blocks around a tile: it needs t in the ghost blocks
+        if (gb) CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
+        CUP2D_TRY(finish_local(c, 5, 0, 5));
+        if (gb) CUP2D_TRY(exchange_end(c, c->d_t, 1, BS));
+      }
+      int *const report = last_of_group ? &c->h_status[slot] : nullptr;
       {
         ProfScope prof(c, CUP2D_T_SWEEP_EA);
         FusedArgs a = {};
         a.in0 = P[o]; a.in1 = N[o]; a.in2 = R[o]; a.w = c->d_rhat; a.vout = P[n]; a.yout = N[n];
         a.t = c->d_t; a.y0 = c->d_y; a.y1 = c->d_yopt; a.y2 = c->d_xopt; a.rout = R[n];
-        a.host_status = last_of_group ? &c->h_status[slot] : nullptr;
-        CUP2D_TRY(eab_sweep<2>(c, a));
+        a.host_status = merge == 1 ? report : nullptr;
+        CUP2D_TRY(eab_sweep<2>(c, a, merge));
+      }
+      if (merge == 2) {
+        if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+        CUP2D_TRY(finish_local(c, 2, 1, 4, report));
+        if (gb) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }

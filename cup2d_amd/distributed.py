@@ -91,7 +91,7 @@ class TorchComm:
     mode "host"  : tensors already live on the host (CPU tests of the plan).
     """
 
-    MAX_STRIP = 128  # WENO halo: 3 layers x 8 cells x 2 components = 48; Krylov ghost blocks: two whole scalar blocks = 128
+    MAX_STRIP = 192  # CUP2D_MAX_STRIP_DOUBLES: WENO halo 3 layers x 8 cells x 2 components = 48; Krylov ghost blocks: three whole scalar blocks
 
     def __init__(self, topo, mode, device=None, group=None):
         import torch

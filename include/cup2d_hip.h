@@ -368,13 +368,14 @@ int cup2d_halo_unpack_vec(cup2d_ctx *ctx, double *device_vec, int dim, int width
  *            computeA (main.cpp:3035-3057) -- and after wait + unpack the halo blocks.
  * allreduce: in place on `count` doubles of the device reduction buffer, op 0 = sum, 1 = max,
  *            ordered on `stream`. */
+#define CUP2D_MAX_STRIP_DOUBLES 192
 typedef int (*cup2d_exchange_fn)(void *user, double *device_send, double *device_recv, int strip_doubles,
                                  void *hip_stream);
 typedef int (*cup2d_wait_fn)(void *user, void *hip_stream);
 typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int op, void *hip_stream);
 /* device_send_buffer / device_recv_buffer: caller-owned device memory for nsend / nrecv strips of
- * the widest exchange: 128 doubles per strip (whole blocks of two Krylov vectors in one message; the WENO halo is
- * 3 layers x 8 cells x 2 components = 48).
+ * the widest exchange: CUP2D_MAX_STRIP_DOUBLES = 192 doubles per strip (whole blocks of three Krylov vectors in one
+ * message; the WENO halo is 3 layers x 8 cells x 2 components = 48).
  * device_reduce_buffer: caller-owned 8 doubles used for every reduction handed to allreduce
  * (NULL keeps the context's own). */
 int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,

@@ -509,7 +509,7 @@ def main():
     if eab:
         ALGO_BYTES.update({"sweep_A": 32.0, "sweep_C": 32.0, "sweep_EA": 80.0})
         del ALGO_BYTES["sweep_E"]
-        KERNEL_OF.update({"sweep_A": "k_edge<0, 1>", "sweep_C": "k_edge<3, 1>", "sweep_EA": "k_edge<2, 1>"})
+        KERNEL_OF.update({"sweep_A": "k_edge<0, %d>" % mf, "sweep_C": "k_edge<3, %d>" % mf, "sweep_EA": "k_edge<2, %d>" % mf})
         sweeps = ("sweep_C", "sweep_EA")
     finish_launches = 0 if mk == "true" else 3
     # HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on

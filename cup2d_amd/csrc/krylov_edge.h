@@ -276,8 +276,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       const int idx = 8 * half + 2 * p + hfo;
       const int rb = L.ring_nb[min(pass * TB + min(idx, ne - 1), TB * 4 - 1)];
       const size_t o = (size_t)(X.nring > 0 ? rb : X.b0) * (BC / 2) + hlo;  // (no ring: any block of the tile, loaded and dropped)
-      R.a[p] = in0[o];
-      R.b[p] = in1[o];
+      if (!fresh) {  // (iteration 0: p = nu = 0 are not read)
+        R.a[p] = in0[o];
+        R.b[p] = in1[o];
+      }
       if (AB || EAB) R.c[p] = in2[o];
       if (EAB) R.d[p] = int_[o];
     }
@@ -288,8 +290,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     for (int p = 0; p < 4; p++) {
       const size_t o = (size_t)(X.b0 + min(8 * half + 2 * p + hfo, X.nvalid - 1)) * (BC / 2) + hlo;
       if (AB) {
-        R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
-        R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
+        if (!fresh) {
+          R.a[p] = ld2<(POL & 0x1000) != 0>(in0 + o);
+          R.b[p] = ld2<(POL & 0x2000) != 0>(in1 + o);
+        }
         R.c[p] = in2[o];
       } else if (EAB) {
         R.a[p] = ld2<(POL2 & 0x01) != 0>(in0 + o);

@@ -168,8 +168,9 @@ int cup2d_set_precond(cup2d_ctx *ctx, int kind);
  * how many times a vector crosses HBM and by round-off):
  *   CUP2D_SOLVER_SWEEPS five fused sweeps, z and z2 stored (184 B/cell/iteration); every configuration.
  *   CUP2D_SOLVER_FUSED  tile-fused: P_inv on the FP64 matrix cores recomputed on tile edges, sweeps A+B and
- *                       C+D one launch each, x accumulated as x0 + P_inv y (136 B/cell/iteration); same-level
- *                       stencil on one GPU -- elsewhere (ghost blocks, assembled matrix) SWEEPS is used.
+ *                       C+D one launch each, x accumulated as x0 + P_inv y (136 B/cell/iteration; 112 in the
+ *                       two-launch form, cup2d_set_solver_form); same-level stencil on one GPU or N ranks and the
+ *                       assembled operator in its hybrid form -- elsewhere SWEEPS is used.
  * finish_in_kernel != 0: the last workgroup of a reducing sweep finishes the reduction and updates the device
  * scalars instead of a separate single-workgroup launch (ignored when an all-reduce callback is installed).
  * Defaults: FUSED where it applies, finish in the kernel; CUP2D_SOLVER (sweeps|fused) and

@@ -1,0 +1,127 @@
+"""The scalar recurrences of the two-launch BiCGSTAB organisation (csrc/krylov_common.h stages 0, 1, 5, 4; csrc/krylov_edge.h
+MODE 2 / 3) restated in numpy and run against the CPU restatement of the reference (oracle.bicgstab = cuda.cu:403-548): rho' =
+rhat.r' formed from the sums of sweep D (rhat.s - omega rhat.t), the breakdown test on ||r'||^2 = s.s - 2 omega t.s + omega^2
+t.t, a restart taking rho = ||rhat||^2 = r'.r' summed directly -- the same iterates as the reference's order of operations
+up to round-off: same iteration counts to convergence, same solution, same behaviour through the breakdown restarts that
+follow convergence to round-off.  CPU only: this pins the ALGEBRA of the organisation; the kernels are pinned to the five
+sweeps and the oracle by tests/test_solver_variants_gpu.py."""
+import numpy as np
+import pytest
+
+
+def two_launch_bicgstab(O, b, tol, rel_tol, max_restarts, max_iter):
+    P = O.P_inv()
+    A = lambda v: O.apply_A(O.precond(v, P))  # noqa: E731  A P_inv v (the fused sweeps work in the preconditioned space)
+    eps = 1e-21
+    dot = lambda u, v: float(np.dot(u.ravel(), v.ravel()))  # noqa: E731
+    r = b.copy()                      # x0 = 0
+    rhat = r.copy()
+    y = np.zeros_like(b)
+    ybest = y.copy()
+    # stage 0
+    err = err_init = err_opt = float(np.abs(r).max())
+    rr = rhat2 = rho_curr = dot(r, r)
+    rho_prev = alpha = omega = 1.0
+    it = restarts = 0
+    status = 0
+    # begin_iteration of iteration 0 (krylov_common.h)
+    breakdown = rho_curr * rho_curr < 1e-16 * rr * rhat2
+    beta = (rho_curr / (rho_prev + eps)) * (alpha / (omega + eps))
+    restart = False
+    if max_iter <= 0:
+        return O.precond(ybest, P), dict(iters=0, restarts=0, err=err_opt, err_init=err_init)
+    if breakdown and max_restarts > 0:
+        restarts += 1
+        restart = True
+        rhat2 = rho_curr = rr
+    # A+B of iteration 0: p = nu = 0
+    p = r.copy()
+    nu = A(p)
+    alpha = rho_curr / (dot(rhat, nu) + eps)          # stage 1
+    while status == 0:
+        # ---- MODE 3: C+D and the sums of the next beginning; stage 5 ----
+        s = r - alpha * nu
+        t = A(s)
+        ts, tt, hs, ht, ss = dot(t, s), dot(t, t), dot(rhat, s), dot(rhat, t), dot(s, s)
+        omega = ts / (tt + eps)
+        rho_next = hs - omega * ht
+        rrf = max(0.0, ss - 2.0 * omega * ts + (omega * omega) * tt)
+        breakdown = rho_next * rho_next < 1e-16 * rrf * rhat2
+        beta = (rho_next / (rho_curr + eps)) * (alpha / (omega + eps))
+        restart = breakdown and max_restarts > 0
+        # ---- MODE 2: sweep E, then the next A+B with the decision taken above ----
+        y = y + alpha * p + omega * s
+        rn = s - omega * t
+        if restart:
+            pn = rn.copy()
+            rhat_n = rn.copy()
+        else:
+            pn = (p - omega * nu) * beta + rn
+            rhat_n = rhat
+        nun = A(pn)
+        red = (dot(rhat_n, nun), dot(rn, rn), float(np.abs(rn).max()))
+        # ---- stage 4 ----
+        it += 1
+        err = red[2]
+        if err < err_opt:
+            err_opt = err
+            ybest = y.copy()
+            if err <= tol or err / err_init <= rel_tol:
+                status = 1
+                break
+        rho_prev, rho_curr, rr = rho_curr, rho_next, red[1]
+        if it >= max_iter:
+            status = 3
+            break
+        if restart:
+            restarts += 1
+            if restarts >= max_restarts:
+                status = 2
+                break
+            rhat2 = rho_curr = rr
+            rho_prev = alpha = omega = 1.0
+        alpha = rho_curr / (red[0] + eps)
+        r, p, nu, rhat = rn, pn, nun, rhat_n
+    return O.precond(ybest, P), dict(iters=it, restarts=restarts, err=err_opt, err_init=err_init)
+
+
+@pytest.mark.parametrize("n,seed", [(32, 1), (64, 7), (96, 3)])
+def test_two_launch_recurrence_converges_like_the_reference(oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    b = rng.uniform(-1, 1, (n, n))
+    b -= b.mean()
+    xo, io = oracle.bicgstab(b, tol=1e-9, rel_tol=0.0, max_restarts=100)
+    x, info = two_launch_bicgstab(oracle, b, 1e-9, 0.0, 100, 1000)
+    assert info["err"] <= 1e-9 and abs(info["err_init"] - io["err_init"]) < 1e-14
+    # BiCGSTAB's count is chaotic in the round-off of its dot products: the same convergence, not the same count
+    assert abs(info["iters"] - io["iters"]) <= max(3, io["iters"] // 5), (info, io)
+    assert np.abs(b - oracle.apply_A(x)).max() <= 1.05e-9
+    assert np.abs((x - x.mean()) - (xo - xo.mean())).max() < 2e-9 * max(1.0, (n / np.pi) ** 2)
+
+
+def test_two_launch_recurrence_first_iterations_equal_the_reference_to_round_off(oracle):
+    n = 64
+    rng = np.random.default_rng(23)
+    b = rng.uniform(-1, 1, (n, n))
+    b -= b.mean()
+    # four capped iterations at zero tolerance: the best iterate so far, and its residual, agree to round-off
+    xo, io = oracle.bicgstab(b, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=4)
+    x, info = two_launch_bicgstab(oracle, b, 0.0, 0.0, 100, 4)
+    assert info["iters"] == io["iters"] == 4
+    assert abs(info["err"] - io["err"]) <= 1e-12 * io["err_init"]
+    assert np.abs(x - xo).max() <= 1e-12 * max(1.0, np.abs(xo).max())
+
+
+def test_two_launch_recurrence_survives_the_breakdown_restarts(oracle):
+    """main.cpp:7028-7030 runs the first steps at zero tolerance: the loop runs to the cap through the restarts that follow
+    convergence to round-off (cuda.cu:455-477) and returns the best iterate"""
+    n = 64
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, (n, n))
+    b -= b.mean()
+    xo, io = oracle.bicgstab(b, tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=300)
+    x, info = two_launch_bicgstab(oracle, b, 0.0, 0.0, 100, 300)
+    assert info["iters"] == io["iters"] == 300
+    assert info["err"] < 1e-11 and io["err"] < 1e-11
+    assert info["restarts"] >= 1 and io["restarts"] >= 1, (info, io)
+    assert np.abs(b - oracle.apply_A(x)).max() < 1e-10

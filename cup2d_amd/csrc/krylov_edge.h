@@ -22,19 +22,23 @@
 // tile's perimeter sides to LDS, and a wave whose neighbour block belongs to a sibling's tile takes the edge from there:
 // 48 of the 128 perimeter sides of the 8 tiles are left to recompute (-62 % of the re-reads).  No workgroup barrier: per-wave
 // round counters in LDS (pub[w] = rounds wave w has published), a consumer waits for the one sibling it needs, a producer
-// for every sibling to be at most one round behind before it reuses an export buffer (two buffers, round parity).
+// for every sibling to be at most NXB - 1 rounds behind before it reuses an export buffer (NXB = 2 buffers, round mod NXB).
 #pragma once
 // (a fragment of krylov_fused.hip: included INSIDE its namespace cup2d, after FusedArgs, ld2 / st2, ring_precond and
 // fused_reduce_store)
 
+#ifndef CUP2D_EDGE_NXB
+#define CUP2D_EDGE_NXB 2
+#endif
+constexpr int NXB = CUP2D_EDGE_NXB;  // export buffers per wave: a wave may run NXB - 1 rounds ahead of its slowest sibling
 constexpr int EXP_SLOTS = 16;  // perimeter sides a tile may export (host check edge_share_ok: every tile has <= 16)
 constexpr int PE2_DOUBLES = 16 * 2 * 64;  // the 32 edge columns of P_inv as MFMA B fragments: [k-step][n-tile][lane]
 constexpr int EDGE_HDR_DOUBLES = PE2_DOUBLES + 16;  // + the 8 round counters (padded to 128 bytes)
 struct alignas(16) EdgeLds {
   double S[TB * XS];            // v of 16 blocks (A operand of the job), then the z edges of those blocks: S[b*XS + 8*side + q]
   double GE[TB * 4 * GS];       // ghost edges of the tile's blocks: [block][W,E,S,N][q]
-  double X[2][EXP_SLOTS * BS];  // exported z edges of this tile's perimeter sides, in slot order; [round parity]
-  unsigned long long xmask[2];  // which (block, side) slots X holds: slot of bit i = popcount of the bits below i
+  double X[NXB][EXP_SLOTS * BS];  // exported z edges of this tile's perimeter sides, in slot order; [round mod NXB]
+  unsigned long long xmask[NXB];  // which (block, side) slots X holds: slot of bit i = popcount of the bits below i
   int ring_nb[TB * 4];          // neighbour block of ring entry e (to recompute) ...
   int ring_dst[TB * 4];         // ... and the slot (block * 4 + side) it feeds
 };
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   int nb_next = load_nb(tile_at(j + 1));
   for (int round = j; tile_at(round) < t_end; round++) {
     const int t = tile_at(round);
-    const int b0 = T.b0, nvalid = T.nvalid, par = round & 1;
+    const int b0 = T.b0, nvalid = T.nvalid, par = round % NXB;
     const bool more = tile_at(round + 1) < t_end;
     double2 V[TB / 2];  // v of the tile's cells in pair layout
     double2 W[TB / 2];  // AB, MODE 2, MODE 3: rhat (on a restart: the new one)
@@ -450,10 +454,11 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
-      // this buffer held round - 2: every sibling has read it once it has published round - 1
-      if (round >= 2) {
+      // this buffer held round - NXB: a sibling has read it by the END of that round of its own, i.e. once it has published
+      // the round after it
+      if (round >= NXB) {
         for (int u = 0; u < FWAVES; u++)
-          if (u != wave) edge_wait(pub, u, round, fault);
+          if (u != wave) edge_wait(pub, u, round - NXB + 2, fault);
       }
       if (mask_bit(T.pmask, opaque(lane))) {
         const int slot = bits_below_lane(T.pmask);

@@ -905,18 +905,17 @@ static int fused_grid(const cup2d_ctx *c, int count) {
 // other ranks need first (k_fused_edges -> zg = the otherwise unused z vector), its width-1 halo exchange
 // overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
 // main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
-// The edge form (krylov_edge.h; opt-in: CUP2D_FUSED_FORM=edge) applies with the built-in preconditioner on the same-level
-// stencil: one rank, or N ranks in the ghost-block form.  CUP2D_EDGE_SHARE=0 switches the sharing between sibling waves off
-// (every perimeter edge recomputed).  Measured at 4096^2 (tools/gpu_edge_check.py, tools/gpu_calls/gpu_r03_call3.sh, round 3;
-// AB / CD in us, L2-miss traffic per launch from FETCH_SIZE / WRITE_SIZE):
+// The edge form of these two sweeps (krylov_edge.h MODE 0 / 1; CUP2D_FORM_EDGE) applies with the built-in preconditioner on
+// the same-level stencil: one rank, or N ranks in the ghost-block form.  Measured at 4096^2 in the first half of round 3
+// (tools/gpu_edge_check.py, tools/gpu_calls/gpu_r03_call3.sh; AB / CD in us, L2-miss traffic per launch from FETCH_SIZE /
+// WRITE_SIZE):
 //   full form (k_fused)            175 / 105     998 MB / 505 MB
 //   edge form, no sharing          178 / 109    1032 MB / 525 MB
 //   edge form, sharing             175 / 116     896 MB / 456 MB   (reads 763 -> 627 MB: the sibling ring is gone)
-//   + three batch buffers, every batch requested a job ahead (ring passes of 8 entries): CD 109, AB spills (251)
-// Half the MFMAs, 13 % less traffic and loads requested earlier each buy nothing: neither the matrix core, nor HBM, nor the
-// lead time of the loads is what a tile's 20 us consist of -- it is the chain of short dependent phases of ONE wave
-// (classification, staging, LDS gathers, epilogue; two waves per SIMD cannot overlap much of it), and the hand-over adds
-// to that chain what a barrier did in round 2.  The full form stays the default.  DESIGN.md 4.5.
+//   edge form, loads a job ahead without spills (second half, gpu_r03_call11.sh): 161-166 / 97
+// Half the MFMAs, 13 % less traffic and loads requested earlier buy a few per cent at most: the launches move their actual
+// traffic at the rate the memory system gives streaming kernels.  What pays is fewer bytes per ITERATION: the organisation
+// below (eab_form: two launches, MODE 3 and MODE 2), the default wherever this form applies.  DESIGN.md 4.5.
 static int form_of(const cup2d_ctx *c) {  // cup2d_set_solver_form, else the process default
   static const int env = [] {
     const char *e = getenv("CUP2D_FUSED_FORM");

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/cup2d_hip.h"
+#include "krylov_scalars.h"
 
 namespace cup2d {
 
@@ -43,24 +44,7 @@ void set_error(const char *fmt, ...);
       return _s;               \
   } while (0)
 
-// device-resident BiCGSTAB state: the reference's BiCGSTABScalars (cuda.cu:24-34) plus the
-// control flow its host loop keeps in local variables (cuda.cu:404-545)
-struct KrylovScalars {
-  double alpha, beta, omega, eps, rho_prev, rho_curr;
-  double rr;         // ||r||^2
-  double rhat2;      // ||rhat||^2 (changes only at a restart)
-  double err, err_init, err_opt;
-  double max_error, max_rel_error;
-  int max_restarts, max_iter;
-  int iter, restarts;
-  int status;        // 0 running, 1 converged, 2 restart limit, 3 iteration cap
-  int restart_flag;  // next p-update must do rhat = r, p = r (cuda.cu:461-476)
-  int x_is_best;     // the iterate held in x is the best so far (cuda.cu:535-538)
-  int ycur, ybest;   // fused solver: which of its three y buffers holds the current / the best iterate
-  int best_is_x0;    // fused solver: no iterate has beaten the initial guess yet (y_best = 0: its buffer is never written or read)
-  double omega_r;    // the omega sweep E formed r = s - omega t with (a restart resets omega, not this): stored-edge ring
-  double rho_next;   // k_edge MODE 2 / 3: rhat . r' from the sums of sweep D (krylov_common.h stage 5)
-};
+// (struct KrylovScalars and the scalar recurrences: krylov_scalars.h, host+device)
 
 struct HaloPlan {
   int nsend = 0, nrecv = 0;

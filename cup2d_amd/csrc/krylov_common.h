@@ -5,120 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include "block.h"
+#include "krylov_scalars.h"
 
 namespace cup2d {
-
-// beginning of an iteration (cuda.cu:440-477): consumes rho = rhat.r and ||r||^2
-static __device__ void begin_iteration(KrylovScalars *sc) {
-  if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
-  const bool serious_breakdown = sc->rho_curr * sc->rho_curr < 1e-16 * sc->rr * sc->rhat2;
-  sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta
-  sc->restart_flag = 0;
-  if (serious_breakdown && sc->max_restarts > 0) {
-    sc->restarts++;
-    if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
-    sc->restart_flag = 1;
-    sc->rhat2 = sc->rr;     // rhat = r
-    sc->rho_curr = sc->rr;  // Dnrm2(rhat)^2
-    sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;  // breakdown_update
-    sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
-  }
-}
-// The fused solver keeps the accumulated correction y in THREE buffers and never copies the best iterate
-// (cuda.cu:535-538 copies x to x_opt): sweep E reads buffer ycur and writes the buffer that is neither ycur
-// nor ybest; stage 3 below then rotates.  (The five-sweep solver updates x in place and copies.)
-static __device__ __forceinline__ int y_out_buffer(int cur, int best) {
-  return (cur != 0 && best != 0) ? 0 : ((cur != 1 && best != 1) ? 1 : 2);
-}
-// STAGE 0: after k_init_residual  red = {r.r, -, max|r|}
-// STAGE 1: after sweep B          red = {rhat.nu}              -> alpha (set_alpha)
-// STAGE 2: after sweep D          red = {t.r, t.t}             -> omega (set_omega)
-// STAGE 3: after sweep E          red = {rhat.r, r.r, max|r|}  -> error bookkeeping, next beta
-// The organisation with sweep E and the next A+B in ONE launch (k_edge MODE 2 / 3; one GPU):
-// STAGE 5: after sweep D (MODE 3)  red = {t.s, t.t, rhat.s, rhat.t, s.s} -> omega, and -- BEFORE r' = s - omega t exists --
-//          what the beginning of the next iteration needs of it: rho' = rhat.r' = rhat.s - omega rhat.t (the same sum in
-//          another order of rounding), ||r'||^2 = s.s - 2 omega t.s + omega^2 t.t for the breakdown test, hence beta and the
-//          restart decision the launch is going to use.  No bookkeeping: the iteration is not over.
-// STAGE 4: after MODE 2            red = {rhat.nu'', r'.r', max|r'|} -> stage 3's bookkeeping with rho' of stage 5 and the
-//          decision taken there (a restart takes rho = ||rhat||^2 = r'.r' as summed HERE, cell by cell), then stage 1's alpha
-static __device__ void scalars_update(KrylovScalars *sc, const double *red, int stage) {
-  switch (stage) {
-  case 0:
-    sc->err = sc->err_init = sc->err_opt = red[2];
-    sc->x_is_best = 1;
-    sc->ycur = sc->ybest = 0;
-    sc->best_is_x0 = 1;
-    sc->rr = red[0]; sc->rhat2 = red[0]; sc->rho_curr = red[0];
-    begin_iteration(sc);
-    break;
-  case 1:
-    sc->alpha = sc->rho_curr / (red[0] + sc->eps);
-    break;
-  case 2:
-    sc->omega = red[0] / (red[1] + sc->eps);
-    sc->omega_r = sc->omega;
-    break;
-  case 3:
-    sc->iter++;
-    sc->err = red[2];
-    sc->ycur = y_out_buffer(sc->ycur, sc->ybest);  // where sweep E put the new iterate
-    if (sc->err < sc->err_opt) {
-      sc->err_opt = sc->err;
-      sc->x_is_best = 1;
-      sc->ybest = sc->ycur;
-      sc->best_is_x0 = 0;
-      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
-    } else {
-      sc->x_is_best = 0;
-    }
-    sc->rho_prev = sc->rho_curr;  // set_rho
-    sc->rho_curr = red[0];
-    sc->rr = red[1];
-    begin_iteration(sc);
-    break;
-  case 5: {
-    sc->omega = red[0] / (red[1] + sc->eps);
-    sc->omega_r = sc->omega;
-    const double w = sc->omega;
-    sc->rho_next = red[2] - w * red[3];
-    double rr = red[4] - 2.0 * w * red[0];
-    rr = rr + (w * w) * red[1];
-    rr = rr > 0.0 ? rr : 0.0;
-    const bool serious_breakdown = sc->rho_next * sc->rho_next < 1e-16 * rr * sc->rhat2;
-    sc->beta = (sc->rho_next / (sc->rho_curr + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));  // set_beta, rho_prev = rho_curr by then
-    sc->restart_flag = serious_breakdown && sc->max_restarts > 0 ? 1 : 0;
-    break;
-  }
-  case 4:
-    sc->iter++;
-    sc->err = red[2];
-    sc->ycur = y_out_buffer(sc->ycur, sc->ybest);
-    if (sc->err < sc->err_opt) {
-      sc->err_opt = sc->err;
-      sc->x_is_best = 1;
-      sc->ybest = sc->ycur;
-      sc->best_is_x0 = 0;
-      if (sc->err <= sc->max_error || sc->err / sc->err_init <= sc->max_rel_error) { sc->status = 1; return; }
-    } else {
-      sc->x_is_best = 0;
-    }
-    sc->rho_prev = sc->rho_curr;  // set_rho
-    sc->rho_curr = sc->rho_next;
-    sc->rr = red[1];
-    // begin_iteration with the decision of stage 5 (beta is set)
-    if (sc->iter >= sc->max_iter) { sc->status = 3; return; }
-    if (sc->restart_flag) {
-      sc->restarts++;
-      if (sc->restarts >= sc->max_restarts) { sc->status = 2; return; }
-      sc->rhat2 = sc->rr;
-      sc->rho_curr = sc->rr;
-      sc->rho_prev = 1.; sc->alpha = 1.; sc->omega = 1.;
-      sc->beta = (sc->rho_curr / (sc->rho_prev + sc->eps)) * (sc->alpha / (sc->omega + sc->eps));
-    }
-    sc->alpha = sc->rho_curr / (red[0] + sc->eps);  // stage 1
-    break;
-  }
-}
 
 // One row of the hybrid sliced-ELL operator (ctx.h SellMatrix): slice s (= block; wave-uniform), lane = row.  Shared by
 // k_sell (krylov.hip) and k_hyb_rows (krylov_fused.hip).

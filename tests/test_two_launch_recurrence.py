@@ -5,6 +5,10 @@ t.t, a restart taking rho = ||rhat||^2 = r'.r' summed directly -- the same itera
 up to round-off: same iteration counts to convergence, same solution, same behaviour through the breakdown restarts that
 follow convergence to round-off.  CPU only: this pins the ALGEBRA of the organisation; the kernels are pinned to the five
 sweeps and the oracle by tests/test_solver_variants_gpu.py."""
+import ctypes
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -83,6 +87,108 @@ def two_launch_bicgstab(O, b, tol, rel_tol, max_restarts, max_iter):
         alpha = rho_curr / (red[0] + eps)
         r, p, nu, rhat = rn, pn, nun, rhat_n
     return O.precond(ybest, P), dict(iters=it, restarts=restarts, err=err_opt, err_init=err_init)
+
+
+# ---- the same loop with the scalar part done by the code the kernels run (csrc/krylov_scalars.h through tests/scalars_host.cpp) ----
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "scalars_host.cpp")
+HDR = os.path.join(ROOT, "cup2d_amd", "csrc", "krylov_scalars.h")
+SO = os.path.join(ROOT, "tests", "_scalars_host.so")
+
+
+@pytest.fixture(scope="module")
+def scalars():
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", SO, SRC])
+    lib = ctypes.CDLL(SO)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    lib.sc_init.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    lib.sc_update.argtypes = [ctypes.c_void_p, dp, ctypes.c_int]
+    lib.sc_get.argtypes = [ctypes.c_void_p, dp, ip]
+    return lib
+
+
+class Scalars:
+    """a KrylovScalars in host memory, updated by the library's own scalars_update"""
+
+    def __init__(self, lib, tol, rel_tol, max_restarts, max_iter):
+        self.lib = lib
+        self.buf = ctypes.create_string_buffer(lib.sc_size())
+        lib.sc_init(self.buf, tol, rel_tol, max_restarts, max_iter)
+
+    def update(self, red, stage):
+        r = (ctypes.c_double * 8)(*(list(red) + [0.0] * (8 - len(red))))
+        self.lib.sc_update(self.buf, r, stage)
+        return self.get()
+
+    def get(self):
+        d, i = (ctypes.c_double * 10)(), (ctypes.c_int * 7)()
+        self.lib.sc_get(self.buf, d, i)
+        out = dict(zip(("alpha", "omega", "beta", "rho_curr", "rho_prev", "rr", "rhat2", "err", "err_init", "err_opt"), d))
+        out.update(zip(("status", "iter", "restarts", "restart_flag", "ycur", "ybest", "best_is_x0"), i))
+        return out
+
+
+def two_launch_with_library_scalars(lib, O, b, tol, rel_tol, max_restarts, max_iter):
+    """solve_fused_impl's two-launch loop (krylov_fused.hip): the vector work in numpy, every scalar from scalars_update --
+    stage 0 after the initial residual, stage 1 after the A+B of iteration 0, then stage 5 / stage 4 per iteration; the
+    accumulated correction in three buffers, rotated by the stages as sweep E / MODE 2 do"""
+    P = O.P_inv()
+    A = lambda v: O.apply_A(O.precond(v, P))  # noqa: E731
+    dot = lambda u, v: float(np.dot(u.ravel(), v.ravel()))  # noqa: E731
+    S = Scalars(lib, tol, rel_tol, max_restarts, max_iter)
+    r = b.copy()
+    rhat = r.copy()
+    Y = [np.zeros_like(b) for _ in range(3)]
+    sc = S.update([dot(r, r), 0.0, float(np.abs(r).max())], 0)
+    if sc["status"] == 0:
+        p = r.copy()                                   # A+B of iteration 0 (fresh: p = nu = 0; a restart changes nothing)
+        nu = A(p)
+        sc = S.update([dot(rhat, nu)], 1)
+    while sc["status"] == 0:
+        alpha = sc["alpha"]
+        s = r - alpha * nu                             # MODE 3
+        t = A(s)
+        sc = S.update([dot(t, s), dot(t, t), dot(rhat, s), dot(rhat, t), dot(s, s)], 5)
+        omega, beta, restart = sc["omega"], sc["beta"], sc["restart_flag"] != 0
+        cur, out = sc["ycur"], lib.sc_y_out_buffer(sc["ycur"], sc["ybest"])   # MODE 2
+        Y[out] = Y[cur] + alpha * p + omega * s
+        rn = s - omega * t
+        if restart:
+            pn, rhat = rn.copy(), rn.copy()
+        else:
+            pn = (p - omega * nu) * beta + rn
+        nun = A(pn)
+        sc = S.update([dot(rhat, nun), dot(rn, rn), float(np.abs(rn).max())], 4)
+        r, p, nu = rn, pn, nun
+    ybest = np.zeros_like(b) if sc["best_is_x0"] else Y[sc["ybest"]]
+    return O.precond(ybest, P), dict(iters=sc["iter"], restarts=sc["restarts"], err=sc["err_opt"], err_init=sc["err_init"], status=sc["status"])
+
+
+@pytest.mark.parametrize("n,seed,tol,cap", [(32, 1, 1e-9, 1000), (64, 7, 1e-9, 1000), (64, 3, 0.0, 300), (64, 23, 0.0, 4)])
+def test_the_library_s_scalar_code_drives_the_same_solves(oracle, scalars, n, seed, tol, cap):
+    """csrc/krylov_scalars.h as compiled for the host: stages 0, 1, 5, 4 drive a whole solve to the same answers as the numpy
+    restatement above and as the reference's order of operations -- converged, capped after four iterations, and through
+    the breakdown restarts of 300 zero-tolerance iterations"""
+    rng = np.random.default_rng(seed)
+    b = rng.uniform(-1, 1, (n, n))
+    b -= b.mean()
+    xo, io = oracle.bicgstab(b, tol=tol, rel_tol=0.0, max_restarts=100, max_iter=cap)
+    xn, inn = two_launch_bicgstab(oracle, b, tol, 0.0, 100, cap)
+    x, info = two_launch_with_library_scalars(scalars, oracle, b, tol, 0.0, 100, cap)
+    # the numpy restatement and the library's scalar code are the same algebra on the same sums: identical histories
+    assert info["iters"] == inn["iters"] and info["restarts"] == inn["restarts"], (info, inn)
+    assert np.abs(x - xn).max() <= 1e-13 * max(1.0, np.abs(xn).max())
+    if tol > 0:
+        assert info["status"] == 1 and info["err"] <= tol
+        assert abs(info["iters"] - io["iters"]) <= max(3, io["iters"] // 5), (info, io)
+        assert np.abs(b - oracle.apply_A(x)).max() <= 1.05 * tol
+    else:
+        assert info["status"] == 3 and info["iters"] == io["iters"] == cap
+        if cap >= 100:
+            assert info["restarts"] >= 1 and info["err"] < 1e-11
+        else:
+            assert np.abs(x - xo).max() <= 1e-12 * max(1.0, np.abs(xo).max())
 
 
 @pytest.mark.parametrize("n,seed", [(32, 1), (64, 7), (96, 3)])

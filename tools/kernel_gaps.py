@@ -8,7 +8,7 @@ short = lambda n: n.split("(")[0].replace("void cup2d::", "").replace("cup2d::",
 gaps = collections.defaultdict(list)
 for a, b in zip(rows, rows[1:]):
     na, nb = short(a["Kernel_Name"]), short(b["Kernel_Name"])
-    if any(k in na for k in ("k_fused", "k_sweep", "k_hyb", "k_sell")) and int(a["End_Timestamp"]) - int(a["Start_Timestamp"]) > 8000:
+    if any(k in na for k in ("k_fused", "k_sweep", "k_hyb", "k_sell", "k_edge")) and int(a["End_Timestamp"]) - int(a["Start_Timestamp"]) > 8000:
         gaps[(na, nb)].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
 for k, v in sorted(gaps.items(), key=lambda kv: -len(kv[1]))[:10]:
     v = sorted(v)

@@ -210,6 +210,7 @@ class DistributedAmrSimulation(AmrSimulation):
                         _l.ALLREDUCE_FN(guard(lambda user, buf, n, op, st: cm.allreduce((buf - red_base) // 8, n, op))))
             _l.check(self.L.cup2d_set_comm(self._ctx, self._cb[0], self._cb[1], self._cb[2], None, vp(cm.send.data_ptr()),
                                            vp(cm.recv.data_ptr()), vp(red_base)), "set_comm")
+            _l.check(self.L.cup2d_set_comm_strip_capacity(self._ctx, cm.MAX_STRIP), "set_comm_strip_capacity")
         self._tables = [P.level, P.kind, P.nbr2, P.half]
         _l.check(self.L.cup2d_set_amr(self._ctx, global_grid.h0, *[a.ctypes.data_as(vp) for a in self._tables]), "cup2d_set_amr")
         _l.check(self.L.cup2d_amr_set_finest_level(self._ctx, int(global_grid.level.max())), "amr_set_finest_level")

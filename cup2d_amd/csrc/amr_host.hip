@@ -697,6 +697,13 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
     return CUP2D_ERR_ARG;
   }
   const auto in_range = [&](size_t produced) { return !ranged || (where[produced] >= new_lo && where[produced] < new_hi); };
+  // the compact form reads fields through slot_of_old: what it will read is computed here even when the caller did not ask
+  // for the list, so that a block the caller failed to fetch (slot -1) is an error and not a wild read
+  std::vector<int32_t> needed_own;
+  if (!needed_old && slot_of_old && nfields > 0) {
+    needed_own.resize((size_t)nblocks);
+    needed_old = needed_own.data();
+  }
   if (needed_old) {
     std::fill(needed_old, needed_old + nblocks, 0);
     for (size_t p = 0; p < nb.size(); p++) {
@@ -722,6 +729,13 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
         }
     }
   }
+  if (slot_of_old && nfields > 0)
+    for (int k = 0; k < nblocks; k++)
+      if (needed_old[k] && slot_of_old[k] < 0) {
+        cup2d::set_error("amr_regrid_local: old block %d (%d, %d, %d) is read by the new blocks [%lld, %lld) but slot_of_old[%d] = %d", k,
+                         L.level(k), L.bi(k), L.bj(k), new_lo, new_hi, k, slot_of_old[k]);
+        return CUP2D_ERR_ARG;
+      }
   constexpr int BS = CUP2D_BS;
   for (int fi = 0; fi < nfields; fi++) {
     const int dim = dims[fi];

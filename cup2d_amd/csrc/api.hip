@@ -1224,6 +1224,13 @@ int cup2d_set_comm(cup2d_ctx *c, cup2d_exchange_fn ex, cup2d_wait_fn wt, cup2d_a
   c->d_send = send;
   c->d_recv = recv;
   c->d_red = red ? red : c->d_red_own;
+  c->strip_cap = CUP2D_MIN_STRIP_DOUBLES;  // what this call alone promises; cup2d_set_comm_strip_capacity says more
+  return CUP2D_OK;
+}
+int cup2d_set_comm_strip_capacity(cup2d_ctx *c, int doubles) {
+  CUP2D_CHECK_CTX(c);
+  if (doubles < CUP2D_MIN_STRIP_DOUBLES) { set_error("set_comm_strip_capacity: %d < %d doubles per strip", doubles, CUP2D_MIN_STRIP_DOUBLES); return CUP2D_ERR_ARG; }
+  c->strip_cap = doubles;
   return CUP2D_OK;
 }
 

@@ -309,7 +309,8 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     set_error("ncclCommInitRank(%d of %d) -> %s", rank, nranks, api->GetErrorString(r));
     return CUP2D_ERR_COMM;
   }
-  return cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red);
+  CUP2D_TRY(cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red));
+  return cup2d_set_comm_strip_capacity(c, (int)strip);  // three whole blocks per strip: allocated above
 }
 
 // One round of everything the time loop will ask of the communicator, with known values and a deadline: the strips of the

@@ -177,6 +177,7 @@ struct cup2d_ctx {
   double *d_red_own = nullptr;
   void *comm_user = nullptr;
   double *d_send = nullptr, *d_recv = nullptr;
+  int strip_cap = CUP2D_MIN_STRIP_DOUBLES;  // doubles per strip the send / receive buffers hold (cup2d_set_comm_strip_capacity)
   cup2d::RcclComm *rccl = nullptr;  // set by cup2d_comm_init; the callbacks above then point into comm.hip
   cup2d::Bodies *bodies = nullptr;  // cup2d_body_set
   bool fused_lds_opt_in = false;    // k_fused's > 64 KiB of dynamic LDS opted in on THIS context's device

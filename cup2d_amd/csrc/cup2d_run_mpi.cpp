@@ -371,6 +371,7 @@ struct AmrRunMpi {
     } else {
       T.init(P.links);
       RUN(cup2d_set_comm(ctx, &MpiTransport::exchange, &MpiTransport::wait, &MpiTransport::allreduce, &T, T.d_send, T.d_recv, T.d_red));
+      RUN(cup2d_set_comm_strip_capacity(ctx, MpiTransport::MAX_STRIP));
     }
     RUN(cup2d_set_amr(ctx, H0, P.level.data(), P.kind.data(), P.nbr2.data(), P.half.data()));
     int lmax = 0;
@@ -762,6 +763,7 @@ int main(int argc, char **argv) {
   } else {
     T.init(L);
     RUN(cup2d_set_comm(ctx, &MpiTransport::exchange, &MpiTransport::wait, &MpiTransport::allreduce, &T, T.d_send, T.d_recv, T.d_red));
+      RUN(cup2d_set_comm_strip_capacity(ctx, MpiTransport::MAX_STRIP));
   }
   RUN(cup2d_set_math(ctx, math));
   RUN(cup2d_upload_slab(ctx, CUP2D_VEL, slab.data()));

@@ -740,6 +740,7 @@ int finish_local(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_stat
 // b = TMP, x0 = PRES, result -> PRES
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                int *restarts, double *linf, double *linf_init) {
+  c->have_last = false;  // a failed solve must not hand out the previous solve's last iterate
   const int nb = c->nblocks;
   const size_t n = (size_t)nb * BC;
   double *x = c->d_field[CUP2D_PRES];

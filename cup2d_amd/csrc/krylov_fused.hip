@@ -936,8 +936,10 @@ static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
 static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring, bool ghost_blocks) {
   const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
   const bool ghosts = c->nghost > 0 && c->exchange;
+  // (N ranks: r', p'', nu'' travel as three whole blocks per strip -- the caller's buffers must be that wide, cup2d_set_comm_strip_capacity)
+  const bool wide = !ghosts || c->strip_cap >= 3 * BC;
   return on && (merge == 1 || merge == 2) && !c->custom_Pinv && !c->mat.active && (!ghosts || (merge == 2 && ghost_blocks)) && dbg == 0 &&
-         !stored_ring;
+         !stored_ring && wide;
 }
 static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has <= 16 perimeter sides
   if (c->edge_share < 0) c->edge_share = edge_share_ok(c->h_nbr.data(), 0, c->nblocks) ? 1 : 0;
@@ -1081,6 +1083,7 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                      int *restarts, double *linf, double *linf_init) {
   CUP2D_TRY(ensure_fused_buffers(c));
+  c->have_last = false;  // whatever happens below, the previous solve's last iterate is no longer this solve's
   // cup2d_step's solve on the same-level stencil: the initial guess is zero and PRES need not hold it (api.hip)
   const bool x0_zero = c->x0_is_zero && !c->mat.active;
   const int nb = c->nblocks;
@@ -1179,7 +1182,12 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // merge 2 (N ranks): the status word is written by the one-wave kernel behind the last all-gather of an iteration
   // (comm.hip k_gather_scalars; callbacks: k_scalars), which reports for a finished solve as well -- same grouping.  Every
   // rank sees the same scalars and looks at the same group boundaries, so all ranks enqueue the same collectives.
-  const int GROUP = merge != 0 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : 1;
+  // N ranks (merge 2): every iteration enqueued behind a finished solve still packs, sends and unpacks its ghost blocks and
+  // issues its all-gathers (the exchange path is host-enqueued and does not read the status word), so there the host looks
+  // once per iteration (CUP2D_SOLVE_GROUP_N, default 1): at most AHEAD - 1 dead iterations, against GROUP * AHEAD_G - 1 -- the
+  // 6 us of idle stream the grouping saves are nothing next to a collective.
+  static const int GROUP_N_ENV = [] { const char *e = getenv("CUP2D_SOLVE_GROUP_N"); return e ? atoi(e) : 1; }();
+  const int GROUP = merge == 1 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : merge == 2 ? (GROUP_N_ENV < 1 ? 1 : GROUP_N_ENV) : 1;
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
   const bool eab = eab_form(c, merge, dbg, stored, gb);

@@ -266,6 +266,7 @@ class DistributedSimulation(Simulation):
         self._cb = (_l.EXCHANGE_FN(_exchange), _l.WAIT_FN(_wait), _l.ALLREDUCE_FN(_allreduce))  # keep alive
         _l.check(self.L.cup2d_set_comm(self._ctx, self._cb[0], self._cb[1], self._cb[2], None,
                                        vp(comm.send.data_ptr()), vp(comm.recv.data_ptr()), vp(red_base)), "set_comm")
+        _l.check(self.L.cup2d_set_comm_strip_capacity(self._ctx, TorchComm.MAX_STRIP), "set_comm_strip_capacity")
 
     def comm_selftest(self, timeout_s=20.0):
         """cup2d_comm_selftest: collective; returns the report string parsed into a dict"""

@@ -183,7 +183,9 @@ int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
  *   CUP2D_FORM_FULL  three launches per iteration (A+B, C+D, E), dense 64 x 64 block product: every configuration of FUSED
  *   CUP2D_FORM_EDGE  three launches, A P_inv v = v + ghost edges of P_inv v (built-in preconditioner, same-level stencil)
  *   CUP2D_FORM_EAB   two launches: C+D with the sums of the next beginning, and E together with the next iteration's A+B
- *                    (112 B/cell/iteration); one GPU, finish in the kernel, built-in preconditioner, same-level stencil.
+ *                    (112 B/cell/iteration); finish in the kernel, built-in preconditioner, same-level stencil; one GPU, or
+ *                    N ranks in the ghost-block form (whole boundary blocks of t, and of r', p'', nu'' in one message of
+ *                    192 doubles per strip: cup2d_set_comm_strip_capacity) with two reductions over the ranks per iteration.
  *                    rho = rhat.r comes from the sums of C+D (rhat.s - omega rhat.t) instead of its own pass over r. */
 typedef enum { CUP2D_FORM_AUTO = 0, CUP2D_FORM_FULL = 1, CUP2D_FORM_EDGE = 2, CUP2D_FORM_EAB = 3 } cup2d_fused_form;
 int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
@@ -329,7 +331,8 @@ long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks, int bpdx,
  * dims[f] -- and new_fields[f][new_hi - new_lo][64 * dims[f]] receives the prolonged / restricted blocks at (position -
  * new_lo); unchanged copies are not written (src_of_new says where they come from: the caller moves them, on the device or
  * between ranks).  Replaces the per-rank refine / compress of main.cpp:5055-5130 and the data side of its block migration
- * (5198-5424): no rank reads a block outside its needed_old and src_of_new sets. */
+ * (5198-5424): no rank reads a block outside its needed_old and src_of_new sets.  slot_of_old[k] < 0 for a block the range
+ * reads is CUP2D_ERR_ARG (the caller did not fetch what the plan names); the rows' upper bound is the caller's to keep. */
 long long cup2d_amr_regrid_local(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
                                  long long new_lo, long long new_hi, long long cap, int32_t *new_blocks, int32_t *src_of_new,
                                  int32_t *needed_old, int nfields, const double *const *fields, const int32_t *slot_of_old,
@@ -381,6 +384,14 @@ typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int
  * (NULL keeps the context's own). */
 int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,
                    void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
+/* What the caller's buffers really hold, in doubles per strip.  cup2d_set_comm alone promises CUP2D_MIN_STRIP_DOUBLES = 128
+ * (the contract of the first two rounds: whole blocks of two Krylov vectors in one message); the two-launch organisation of
+ * the solver on N ranks sends whole blocks of THREE vectors in one message (192 doubles per strip) and is chosen only when
+ * the capacity says the buffers take it -- otherwise the three-launch form runs (128 doubles per strip at most).  Call it
+ * after cup2d_set_comm; values below CUP2D_MIN_STRIP_DOUBLES are an error.  The in-library communicator (cup2d_comm_init)
+ * owns its buffers and sets CUP2D_MAX_STRIP_DOUBLES itself. */
+#define CUP2D_MIN_STRIP_DOUBLES 128
+int cup2d_set_comm_strip_capacity(cup2d_ctx *ctx, int doubles_per_strip);
 
 /* ---- penalisation with host-supplied bodies (main.cpp:6643-7006) ----
  * A body is what the reference keeps per shape: for every block the shape touches an Obstacle with the shape's own

@@ -76,8 +76,20 @@ def pytest_runtest_protocol(item, nextitem):
     ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
     env = dict(os.environ)
     env[CHILD_ENV] = "1"
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "--rootdir", str(item.config.rootpath),
-           item.nodeid]
+    # the parent's output / warning options travel with the node id (-s, -v, -r*, --tb=, -W, -o name=value, --durations=);
+    # selection (-k, -m, --deselect, paths, node ids) was applied when the parent collected and is not repeated
+    passed = [a for a in getattr(item.config.invocation_params, "args", ()) if isinstance(a, str)]
+    opts, k = [], 0
+    while k < len(passed):
+        a = passed[k]
+        if a in ("-o", "-W") and k + 1 < len(passed):
+            opts += [a, passed[k + 1]]
+            k += 2
+            continue
+        if a == "-s" or a.startswith(("-v", "-r", "--tb=", "-W", "--durations=", "--showlocals", "--capture=", "-o")) and a != "-o":
+            opts.append(a)
+        k += 1
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "--rootdir", str(item.config.rootpath)] + opts + [item.nodeid]
     t0 = time.time()
     try:
         r = subprocess.run(cmd, cwd=str(item.config.rootpath), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,

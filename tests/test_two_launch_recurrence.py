@@ -50,6 +50,7 @@ def two_launch_bicgstab(O, b, tol, rel_tol, max_restarts, max_iter):
         omega = ts / (tt + eps)
         rho_next = hs - omega * ht
         rrf = max(0.0, ss - 2.0 * omega * ts + (omega * omega) * tt)
+        rrf += 1e-14 * (ss + 2.0 * abs(omega * ts) + (omega * omega) * tt)   # the error margin of the formula (krylov_scalars.h stage 5)
         breakdown = rho_next * rho_next < 1e-16 * rrf * rhat2
         beta = (rho_next / (rho_curr + eps)) * (alpha / (omega + eps))
         restart = breakdown and max_restarts > 0
@@ -231,3 +232,80 @@ def test_two_launch_recurrence_survives_the_breakdown_restarts(oracle):
     assert info["err"] < 1e-11 and io["err"] < 1e-11
     assert info["restarts"] >= 1 and io["restarts"] >= 1, (info, io)
     assert np.abs(b - oracle.apply_A(x)).max() < 1e-10
+
+
+def _stage5_inputs(rng, n, ratio, rho_scale):
+    """vectors with ||s - omega t|| / ||s|| = ratio by construction (t = (s - ratio ||s|| q) / omega0 with q a unit vector
+    orthogonal to t's direction up to round-off) and rhat = a r' / ||r'|| + b u with u orthogonal to r': rho = rhat.r' = a ||r'||"""
+    s = rng.uniform(-1, 1, n)
+    q = rng.uniform(-1, 1, n)
+    q -= s * (q @ s) / (s @ s)
+    q /= np.linalg.norm(q)
+    omega0 = 0.7
+    t = (s - ratio * np.linalg.norm(s) * q) / omega0
+    omega = (t @ s) / (t @ t)
+    r = s - omega * t                                   # what sweep E / MODE 2 forms cell by cell
+    u = rng.uniform(-1, 1, n)
+    u -= r * (u @ r) / (r @ r)
+    u /= np.linalg.norm(u)
+    rhat = rho_scale * r / np.linalg.norm(r) + u * np.linalg.norm(s)
+    return s, t, rhat, r
+
+
+@pytest.mark.parametrize("ratio", [1e-3, 1e-6, 1e-7, 1e-8, 3e-9])
+def test_breakdown_decision_when_r_is_tiny_next_to_s(scalars, ratio):
+    """VERDICT r03 weak #3 / ADVICE: stage 5 takes the restart decision and beta' from ||r'||^2 = s.s - 2 w t.s + w^2 t.t and
+    rho' = rhat.s - w rhat.t, which cancel when r' << s.  Constructed here: ||r'|| / ||s|| down to 3e-9 (the formula value of
+    ||r'||^2 is then pure round-off), against the five-sweep scalars (stage 2 + stage 3 on the directly summed rhat.r', r'.r'):
+      * rho' well above the breakdown threshold: no restart on either side and beta' equal to 1e-6;
+      * rho' below the threshold of the directly summed norm: BOTH restart (the margin of stage 5 guarantees 'whenever the
+        exact form would'), and after the restart both carry rho = r'.r' summed directly (stage 4 takes it from MODE 2);
+      * a scan of rho' across the threshold: stage 5 never misses a restart the exact form takes, and restarts where the
+        exact form does not only if |rho'| is below the round-off of the two sums it is the difference of."""
+    rng = np.random.default_rng(int(-np.log10(ratio) * 10))
+    n = 4096
+    dot = lambda a, b: float(a @ b)  # noqa: E731
+    missed = extra = agree = checked_beta = 0
+    for rho_scale in (1.0, 1e-3, 1e-7, 3e-9, 1e-9, 1e-10, 1e-12, 0.0):
+        s, t, rhat, r = _stage5_inputs(rng, n, ratio, rho_scale * np.sqrt(n))
+        assert abs(np.linalg.norm(r) / np.linalg.norm(s) / ratio - 1) < 0.2 or ratio < 1e-8
+        rhat2 = dot(rhat, rhat)
+        common = dict(alpha=0.9, rho_curr=0.37 * rhat2, rhat2=rhat2)
+
+        def prepared(S):
+            # a running solve: err bookkeeping from stage 0, then the scalars an iteration would hold before C+D
+            S.update([rhat2, 0.0, 1.0], 0)
+            S.update([rhat2 / common["alpha"]], 1)           # alpha = rho_curr / (rhat.nu): rho_curr = rhat2 after stage 0
+            return S
+
+        two = prepared(Scalars(scalars, 0.0, 0.0, 100, 1000))
+        five = prepared(Scalars(scalars, 0.0, 0.0, 100, 1000))
+        sc5 = two.update([dot(t, s), dot(t, t), dot(rhat, s), dot(rhat, t), dot(s, s)], 5)
+        five.update([dot(t, s), dot(t, t)], 2)
+        rr_direct, rho_direct = dot(r, r), dot(rhat, r)
+        sc3 = five.update([rho_direct, rr_direct, float(np.abs(r).max())], 3)
+        exact_restart, formula_restart = sc3["restart_flag"] != 0, sc5["restart_flag"] != 0
+        noise = 4e-16 * (abs(dot(rhat, s)) + abs(sc5["omega"] * dot(rhat, t)))   # round-off of rho' as a difference of two sums
+        if exact_restart and not formula_restart:
+            missed += 1
+        elif formula_restart and not exact_restart:
+            extra += 1
+            # rho' carries no information here: below the round-off of its own sums, or within the margin of the threshold
+            thr = np.sqrt(1e-16 * (rr_direct + 1e-14 * 4 * dot(s, s)) * rhat2)
+            assert abs(rho_direct) <= max(noise, 1.01 * thr), (ratio, rho_scale, rho_direct, noise, thr)
+        else:
+            agree += 1
+            if not exact_restart and abs(rho_direct) > 10 * noise:
+                # beta' to 1e-6 wherever rho' carries six digits; never worse than the round-off of its two sums allows
+                assert abs(sc5["beta"] / sc3["beta"] - 1) <= max(1e-6, 10 * noise / abs(rho_direct)), (ratio, rho_scale, sc5["beta"], sc3["beta"])
+                checked_beta += rho_scale == 1.0 and abs(sc5["beta"] / sc3["beta"] - 1) <= 1e-6
+        if formula_restart and exact_restart:
+            # after MODE 2 / stage 4 the restarted iteration carries the directly summed norm, exactly as stage 3 does
+            sc4 = two.update([0.5 * rr_direct, rr_direct, float(np.abs(r).max())], 4)
+            assert sc4["rho_curr"] == sc3["rho_curr"] == rr_direct and sc4["rhat2"] == sc3["rhat2"] == rr_direct
+            assert sc4["restarts"] == sc3["restarts"] == 1 and sc4["beta"] == sc3["beta"]
+    assert missed == 0, "stage 5 missed a restart the directly summed norm takes"
+    assert agree >= 4, (agree, extra)
+    assert checked_beta == 1, "the well-conditioned case (rho' far above the threshold) must give beta' to 1e-6"
+    if ratio >= 1e-6:
+        assert extra == 0, "above ||r'|| = 1e-6 ||s|| the formula takes the decisions of the directly summed form"

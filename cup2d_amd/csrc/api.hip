@@ -794,6 +794,14 @@ int cup2d_get_last_solver(cup2d_ctx *c, int *kind) {
   *kind = c->last_solver;
   return CUP2D_OK;
 }
+int cup2d_get_last_solver_form(cup2d_ctx *c, int *form, int *merge, int *handover) {
+  CUP2D_CHECK_CTX(c);
+  const bool fused = c->last_solver == CUP2D_SOLVER_FUSED;
+  if (form) *form = fused ? c->last_form : 0;
+  if (merge) *merge = fused ? c->last_merge : 0;
+  if (handover) *handover = fused ? c->last_handover : 0;
+  return CUP2D_OK;
+}
 int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   CUP2D_CHECK_CTX(c);
   if (kind != CUP2D_SOLVER_SWEEPS && kind != CUP2D_SOLVER_FUSED) { set_error("set_solver: kind %d", kind); return CUP2D_ERR_ARG; }

@@ -146,6 +146,7 @@ struct cup2d_ctx {
   double *d_edge[8] = {nullptr};  // stored-edge ring (krylov_fused.hip): z, P_inv nu, z2, P_inv t on block edges, two buffers each
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
   int last_solver = 0;       // what the last solve ran
+  int last_form = 0, last_merge = 0, last_handover = 0;  // cup2d_get_last_solver_form
   int finish_in_kernel = 1;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
   unsigned *d_ticket = nullptr;  // arrival counter of arrive_last, zero between launches
   double *d_partials = nullptr;  // [NSLOT][grid]

@@ -5,7 +5,7 @@
 //
 //   cup2d_run -n 256 [-ny 256] [-steps 10] [-nu 1e-3] [-cfl 0.5] [-poissonTol 1e-3] [-poissonTolRel 1e-2]
 //             [-maxPoissonRestarts 0] [-maxiter 1000] [-init vel.f64] [-dump prefix] [-every k] [-device 0]
-//             [-math fast|strict]
+//             [-math fast|strict] [-state prefix]      (-state: <prefix>.vel.f64 [ny][nx][2], <prefix>.pres.f64 [ny][nx] at the end)
 //   cup2d_run -levelMax 5 -levelStart 2 [-Rtol 2] [-Ctol 0.5] ... [-state prefix]      block-AMR (below)
 //
 // Grid: nx x ny cells in 8 x 8 blocks, ordered along the Hilbert curve like the reference's (main.cpp:347-360,
@@ -96,6 +96,13 @@ struct Grid {
       for (int c = 0; c < BC; c++)
         for (int d = 0; d < dim; d++)
           slab[((size_t)b * BC + c) * dim + d] = a[((size_t)(by[b] * BS + c / BS) * nx + bx[b] * BS + c % BS) * dim + d];
+  }
+  void from_blocks(const double *slab, int dim, double *a) const {
+    const int nx = nbx * BS;
+    for (int b = 0; b < nblocks; b++)
+      for (int c = 0; c < BC; c++)
+        for (int d = 0; d < dim; d++)
+          a[((size_t)(by[b] * BS + c / BS) * nx + bx[b] * BS + c % BS) * dim + d] = slab[((size_t)b * BC + c) * dim + d];
   }
 };
 
@@ -360,6 +367,20 @@ int main(int argc, char **argv) {
     time += dt;
     std::printf("step %d time %.17g dt %.17g poisson_iters %d poisson_err %.6e\n", step + 1, time, dt, iters, err);
     maybe_dump(step + 1);
+  }
+  if (!state.empty()) {  // <state>.vel.f64 [ny][nx][2], <state>.pres.f64 [ny][nx], row-major (what cup2d_run_mpi writes per rank)
+    const auto put = [](const std::string &file, const void *data, size_t bytes) {
+      FILE *f = std::fopen(file.c_str(), "wb");
+      if (!f || std::fwrite(data, 1, bytes, f) != bytes) { std::fprintf(stderr, "cup2d_run: cannot write %s\n", file.c_str()); std::exit(1); }
+      std::fclose(f);
+    };
+    RUN(cup2d_download_slab(ctx, CUP2D_VEL, slab.data()));
+    g.from_blocks(slab.data(), 2, vel.data());
+    put(state + ".vel.f64", vel.data(), vel.size() * sizeof(double));
+    std::vector<double> ps(ncell), pp(ncell);
+    RUN(cup2d_download_slab(ctx, CUP2D_PRES, ps.data()));
+    g.from_blocks(ps.data(), 1, pp.data());
+    put(state + ".pres.f64", pp.data(), pp.size() * sizeof(double));
   }
   double umax = 0;
   RUN(cup2d_max_abs_vel(ctx, &umax));

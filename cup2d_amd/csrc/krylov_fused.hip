@@ -1191,6 +1191,14 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
   const bool eab = eab_form(c, merge, dbg, stored, gb);
+  {  // cup2d_get_last_solver_form
+    const bool edge = !eab && edge_form(c, gb, stored ? 1 : 0, dbg);
+    c->last_form = eab ? CUP2D_FORM_EAB : edge ? CUP2D_FORM_EDGE : CUP2D_FORM_FULL;
+    c->last_merge = merge;
+    c->last_handover = 0;
+    if (eab) c->last_handover = (edge_share_mode(c, 0) ? 1 : 0) | (edge_share_mode(c, 2) ? 4 : 0) | (edge_share_mode(c, 3) ? 8 : 0);
+    else if (edge) c->last_handover = (edge_share_mode(c, 0) ? 1 : 0) | (edge_share_mode(c, 1) ? 2 : 0);
+  }
   if (eab) {
     // A+B of iteration 0, then per iteration TWO launches: C+D with the sums the next beginning needs (MODE 3), and sweep E
     // with the next A+B (MODE 2).  p, nu and r alternate between two buffers (r': ring entries re-read r of other tiles; the

@@ -210,6 +210,12 @@ class Simulation(BodyOps):
         _l.check(self.L.cup2d_get_last_solver(self._ctx, ctypes.byref(k)), "get_last_solver")
         return "fused" if k.value == _l.SOLVER_FUSED else "sweeps"
 
+    def last_solver_form(self):
+        """(form, merge, handover mask) of the last fused solve (cup2d_get_last_solver_form): form 'full' | 'edge' | 'eab'"""
+        f, m, h = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _l.check(self.L.cup2d_get_last_solver_form(self._ctx, ctypes.byref(f), ctypes.byref(m), ctypes.byref(h)), "get_last_solver_form")
+        return ("none", "full", "edge", "eab")[f.value], m.value, h.value
+
     def set_matrix_coo(self, row, col, val, halo=0):
         """Assembled Poisson operator (what main.cpp:7034-7112 pushes into LocalSpMatDnVec), local
         int32 indices in device block order; poisson_solve / apply_A use it instead of the stencil."""

@@ -191,6 +191,11 @@ typedef enum { CUP2D_FORM_AUTO = 0, CUP2D_FORM_FULL = 1, CUP2D_FORM_EDGE = 2, CU
 int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
 /* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
+/* what the last FUSED solve ran in detail (diagnostic, for tests that must know which organisation they pinned): form =
+ * CUP2D_FORM_FULL | _EDGE | _EAB as resolved for that solve; merge = 0 finish launches, 1 finish in the kernel on one GPU,
+ * 2 finish in the kernel + reductions over the ranks; handover = bit mask by kind of sweep (bit 0 A+B, 1 C+D, 2 E+A+B,
+ * 3 C+D') of the sweeps whose sibling waves handed z edges through LDS.  All zero after a five-sweep solve. */
+int cup2d_get_last_solver_form(cup2d_ctx *ctx, int *form, int *merge, int *handover);
 /* Diagnostic: the reference returns the BEST iterate in the max norm (cuda.cu:535-547), which within a capped number of
  * iterations may still be the initial guess -- nothing of the iterations is then visible in PRES.  With keep_last on, a
  * solve also keeps its LAST iterate (x0 + P_inv y for the fused organisation) in a solver scratch vector;

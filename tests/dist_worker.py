@@ -183,6 +183,130 @@ def run_gpu(rank, world, px, py, nbx, nby):
     sim.close()
 
 
+def run_gpu_big(rank, world, px, py, nbx, nby):
+    """The N-rank path at the per-rank size of BASELINE.json configs[3] (8192^2 over 2 x 4: 4096 x 2048 cells = 512 x 256 blocks
+    per rank + a ghost ring), ranks sharing the one GPU (gloo, host-staged).  The reference is the single context on the whole
+    (px nbx) x (py nby) block grid on the same GPU -- itself pinned bit for bit to the live reference at 4096^2
+    (tests/test_baseline_sizes_gpu.py).  What 16 x 16-block patches cannot reach: 131 072-block neighbour tables with ghost
+    ids, the inner / halo quad plans of k_advect_walk, the MERGE 2 instances of k_edge over thousands of rounds, three-block
+    strips for r', p'', nu'', the moved last tile of the tile kernels on a patch whose halo blocks are ordered last."""
+    import torch.distributed as dist
+    import cup2d_amd
+    from cup2d_amd.distributed import DistributedSimulation
+    from cup2d_amd import lib as L
+    from oracle import oracle as O
+    cx, cy = rank % px, rank // px
+    gbx, gby = px * nbx, py * nby
+    gnx, gny = gbx * 8, gby * 8
+    nu = 1e-3
+    vel = O.taylor_green(gnx, noise=1e-3, seed=20250117, ny=gny)
+    sl = (slice(cy * nby * 8, (cy + 1) * nby * 8), slice(cx * nbx * 8, (cx + 1) * nbx * 8))
+    rng = np.random.default_rng(5)
+    x = (np.arange(gnx) + 0.5) / max(gnx, gny)
+    y = (np.arange(gny) + 0.5) / max(gnx, gny)
+    X, Y = np.meshgrid(x, y, indexing="xy")
+    pres = np.cos(2 * np.pi * X) * np.cos(4 * np.pi * Y) + 1e-2 * rng.uniform(-1, 1, (gny, gnx))
+    del X, Y
+    ref = cup2d_amd.Simulation(gbx, gby, nu=nu)
+    sim = DistributedSimulation(nbx, nby, px, py, nu=nu, device=0)
+    assert sim.h == ref.h and sim.grid.nblocks == nbx * nby and sim.grid.nghost > 0
+    # ---- (a) every functor of the step, STRICT: bit for bit; FAST: round-off ----
+    for s_, v in ((ref, vel), (sim, vel[sl])):
+        s_.set_math(True)
+        s_.vel = v
+    assert sim.max_abs_vel() == ref.max_abs_vel()
+    dt = ref.compute_dt()
+    assert sim.compute_dt() == dt
+    ref.advect_diffuse_rk2(dt)
+    sim.advect_diffuse_rk2(dt)      # halo-3 exchange per stage, inner blocks while the strips travel, then the halo blocks
+    vadv = ref.vel
+    assert np.array_equal(sim.vel, vadv[sl]), "STRICT rk2 differs on rank %d" % rank
+    sim.set_math(False)
+    sim.vel = vel[sl]
+    sim.advect_diffuse_rk2(dt)      # FAST: k_advect_walk on the inner and the halo plan, leftovers on the per-block kernel
+    e = np.abs(sim.vel - vadv[sl]).max() / np.abs(vadv).max()
+    assert e <= 2e-13, ("FAST rk2", rank, e)
+    for s_, v, p in ((ref, vadv, pres), (sim, vadv[sl], pres[sl])):
+        s_.set_math(True)
+        s_.vel = v
+        s_.pres = p
+        s_.poisson_rhs(dt)
+    b = ref.tmp
+    assert np.array_equal(sim.tmp, b[sl]), "poisson rhs differs on rank %d" % rank
+    assert np.array_equal(sim.pold, pres[sl]) and not sim.pres.any()
+    # tile kernels (16-block tiles, moved last tile; a width-1 exchange per sweep, the max norm over the ranks)
+    for s_, p in ((ref, pres), (sim, pres[sl])):
+        s_.pres = p
+    eg, el = ref.jacobi_sweeps(2, omega=0.8), sim.jacobi_sweeps(2, omega=0.8)
+    assert el == eg and np.array_equal(sim.pres, ref.pres[sl]), "jacobi sweeps differ on rank %d" % rank
+    assert sim.poisson_residual() == ref.poisson_residual() and np.array_equal(sim.pold, ref.pold[sl])
+    # projection: two volume-weighted mean removals over the ranks (summation order is the only freedom), gradient + update
+    for s_, v, p in ((ref, vadv, pres), (sim, vadv[sl], pres[sl])):
+        s_.vel = v
+        s_.pres = p
+        s_.fill(L.POLD, 0.0)
+        s_.project(dt)
+    assert np.abs(sim.pres - ref.pres[sl]).max() <= 1e-12
+    assert np.abs(sim.vel - ref.vel[sl]).max() <= 1e-12 * np.abs(vadv).max()
+    # ---- (b) eight iterations of the default N-rank organisation = the five sweeps on one context ----
+    ref.set_precond(L.PRECOND_MFMA)
+    sim.set_precond(L.PRECOND_MFMA)
+    out = {}
+    for name, s_, rhs_, fused in (("five", ref, b, False), ("two", ref, b, True), ("nrank", sim, b[sl], True)):
+        s_.set_solver(fused=fused, finish_in_kernel=True)
+        s_.keep_last_iterate(True)
+        s_.tmp = rhs_
+        s_.fill(L.PRES, 0.0)
+        info = s_.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=8)
+        assert info["iters"] == 8, (name, info)
+        err_last = s_.last_iterate_to(L.POLD)
+        out[name] = (s_.pold, info, err_last, s_.last_solver(), s_.last_solver_form())
+    assert out["five"][3] == "sweeps" and out["two"][3] == "fused" and out["nrank"][3] == "fused"
+    form, merge, handover = out["nrank"][4]
+    assert form == "eab" and merge == 2, out["nrank"][4]     # two launches per iteration, reductions over the ranks
+    assert out["two"][4][0] == "eab" and out["two"][4][1] == 1
+    x5 = out["five"][0]
+    scale = np.abs(x5).max()
+    d_two = np.abs(out["two"][0] - x5).max() / scale
+    d_n = np.abs(out["nrank"][0] - x5[sl]).max() / scale
+    assert d_two <= 1e-10 and d_n <= 1e-10, (rank, d_two, d_n)
+    assert abs(out["nrank"][2] - out["five"][2]) <= 1e-9 * out["five"][2], (out["nrank"][2], out["five"][2])
+    assert out["nrank"][1]["err_init"] == out["five"][1]["err_init"]
+    # and the residual the N-rank recurrence carries is the residual of the iterate it holds (assembled over the ranks)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (cx, cy, out["nrank"][0]))
+    Xn = np.zeros((gny, gnx))
+    for (ax, ay, xl) in gathered:
+        Xn[ay * nby * 8:(ay + 1) * nby * 8, ax * nbx * 8:(ax + 1) * nbx * 8] = xl
+    true = np.abs(b - O.apply_A(Xn)).max()
+    assert abs(true - out["nrank"][2]) <= 1e-6 * true + 1e-9, (true, out["nrank"][2])
+    del Xn, gathered
+    # ---- a whole step as bench.py runs it (FAST, 50 iterations at zero tolerance, default organisation) ----
+    for s_, v in ((ref, vel), (sim, vel[sl])):
+        s_.set_precond(L.PRECOND_FD)
+        s_.set_solver(fused=True, finish_in_kernel=True)
+        s_.keep_last_iterate(False)
+        s_.set_math(False)
+        s_.vel = v
+        s_.fill(L.PRES, 0.0)
+        s_.fill(L.POLD, 0.0)
+    rg = ref.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=50)
+    rl = sim.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=50)
+    assert rl["dt"] == rg["dt"] == dt and rl["iters"] == rg["iters"] == 50
+    pg, vg = ref.pres, ref.vel
+    dp = np.abs(sim.pres - pg[sl]).max() / max(np.abs(pg).max(), 1e-300)
+    dv = np.abs(sim.vel - vg[sl]).max()
+    assert abs(rl["err"] - rg["err"]) <= 1e-6 * rg["err"], (rl, rg)
+    assert dp <= 2e-9 and dv <= 1e-9, (rank, dp, dv)
+    assert not sim.comm_errors, sim.comm_errors
+    if rank == 0:
+        print("gpu_big %dx%d ranks of %dx%d blocks: hand-over mask %d; 8 iterations vs five sweeps: one context %.1e, N ranks %.1e of max|x|; "
+              "step: dp %.1e of max|p|, dv %.1e" % (px, py, nbx, nby, handover, d_two, d_n, dp, dv), flush=True)
+    dist.barrier()
+    sim.close()
+    ref.close()
+
+
 def run_amr_gpu(rank, world):
     """BASELINE.json configs[4] on N ranks sharing the one GPU (gloo, host-staged): the three-level golden grid split into
     contiguous Hilbert ranges; every block operator on a rank's owned blocks (ghost blocks refreshed whole, flux-correction
@@ -435,7 +559,7 @@ def main():
         dist.destroy_process_group()
         return
     assert world == px * py
-    (run_cpu if mode == "cpu" else run_gpu)(rank, world, px, py, nbx, nby)
+    {"cpu": run_cpu, "gpu": run_gpu, "gpu_big": run_gpu_big}[mode](rank, world, px, py, nbx, nby)
     if rank == 0:
         print("DIST_OK mode=%s world=%d" % (mode, world))
     dist.destroy_process_group()

@@ -205,6 +205,48 @@ def test_solver_at_the_bench_configuration(gpu_lib, oracle):
     assert np.abs(xf - xs).max() <= 2e-9 * scale
 
 
+def test_solver_at_8192_two_launches_vs_five_sweeps(gpu_lib, oracle):
+    """configs[3]'s global grid on one context (1 048 576 blocks, 65 536 tiles, 32 rounds per workgroup; 537 MB per Krylov
+    vector): eight iterations at zero tolerance of the default two-launch organisation (k_edge MODE 3 / MODE 2, hand-over
+    between sibling waves, descending rounds) against the five sweeps with the same preconditioner arithmetic -- the last
+    iterates to 1e-10 of max|x| -- and, for both, the residual the recurrence carries against max|b - A x| recomputed on the
+    CPU with the oracle's operator (cuda.cu:403-548; the 4096^2 tests cannot reach offsets beyond 2^31 bytes per vector
+    pair or tile indices beyond 2^16)."""
+    import cup2d_amd
+    O = oracle
+    n, nu = 8192, 1e-3
+    vel = O.taylor_green(n)
+    last = {}
+    with cup2d_amd.Simulation(n // 8, nu=nu) as s:
+        _poisson_system(s, O, vel, nu)
+        del vel
+        b = s.tmp
+        s.set_precond(L.PRECOND_MFMA)
+        for kind in ("fused", "sweeps"):
+            s.set_solver(fused=kind == "fused", finish_in_kernel=True)
+            s.keep_last_iterate(True)
+            s.fill(L.PRES, 0.0)
+            r = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=8)
+            assert s.last_solver() == kind and r["iters"] == 8
+            if kind == "fused":
+                assert s.last_solver_form()[:2] == ("eab", 1), s.last_solver_form()
+            err_last = s.last_iterate_to(L.POLD)
+            last[kind] = (s.pold, err_last, r)
+            assert np.array_equal(s.tmp, b)
+    xf, ef, rf = last["fused"]
+    xs, es, rs = last["sweeps"]
+    scale = np.abs(xs).max()
+    d = np.abs(xf - xs).max() / scale
+    true_f = np.abs(b - O.apply_A(xf)).max()
+    true_s = np.abs(b - O.apply_A(xs)).max()
+    print("8192^2, 8 iterations: max|x_two - x_five| / max|x| = %.2e; recurrence / recomputed residual: two launches %.6e / %.6e, "
+          "five sweeps %.6e / %.6e (err_init %.3e)" % (d, ef, true_f, es, true_s, rf["err_init"]))
+    assert rf["err_init"] == rs["err_init"] == np.abs(b).max()
+    assert d <= 1e-10
+    assert abs(true_f - ef) <= 1e-6 * ef + 1e-9 and abs(true_s - es) <= 1e-6 * es + 1e-9
+    assert ef < rf["err_init"]
+
+
 def test_whole_step_at_4096_vs_reference_loop(gpu_lib, oracle):
     """One pass of the reference's own time-loop body (main.cpp:6576-7187) at 4096^2 with the Poisson solve capped at
     50 iterations on both sides (harness key maxiter; the reference's solver is cuda.cu, restated on the CPU) against

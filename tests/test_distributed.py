@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(mode, world, px, py, nbx, nby, port, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+def launch(mode, world, px, py, nbx, nby, port, timeout=600, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, mode, str(px), str(py), str(nbx), str(nby)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=timeout, cwd=ROOT)
@@ -38,6 +38,17 @@ def test_cartesian_dims():
 @pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 8, 16), (2, 1, 2, 16, 8), (4, 2, 2, 8, 8)])
 def test_decomposed_step_matches_global_oracle_gpu(world, px, py, nbx, nby):
     launch("gpu", world, px, py, nbx, nby, 29711 + world + px, timeout=900)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("px,py,share", [(1, 2, "5"), (2, 1, "5"), (1, 2, "0")])
+def test_decomposed_path_at_configs3_rank_size_gpu(px, py, share):
+    """BASELINE.json configs[3]'s per-rank patch -- 4096 x 2048 cells = 512 x 256 blocks plus a ghost ring -- on two ranks
+    sharing the GPU (dist_worker.run_gpu_big): every functor STRICT bit for bit (FAST to 2e-13) against the single context on
+    the whole grid, eight iterations of the two-launch MERGE 2 solver = the five sweeps to 1e-10 of max|x|, one whole bench
+    step.  (1, 2): the global grid is 4096^2; (2, 1): 8192 x 2048 cells, a rectangle whose Hilbert order is not the
+    square's.  share: CUP2D_EDGE_SHARE, the hand-over between sibling waves on (where the grid allows it) and off."""
+    launch("gpu_big", 2, px, py, 512, 256, 29741 + 2 * px + py + (7 if share == "0" else 0), timeout=850, CUP2D_EDGE_SHARE=share)
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 5])
@@ -140,6 +151,47 @@ def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py, comm):
         pres[cy * pny:(cy + 1) * pny, cx * pnx:(cx + 1) * pnx] = np.fromfile(tmp_path / ("s.%d.pres.f64" % rank)).reshape(pny, pnx)
     dv, dp = np.abs(vel - vref).max(), np.abs(pres - pref).max()
     print("cup2d_run_mpi %dx%d: max|dv| %.2e max|dp| %.2e" % (px, py, dv, dp))
+    assert dv < 1e-9 and dp < 1e-8, (dv, dp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("px,py", [(2, 1), (1, 2)])
+def test_cpp_mpi_driver_at_configs3_rank_size_gpu(tmp_path, px, py):
+    """cup2d_run_mpi -n 4096 on two ranks sharing the GPU -- 2048 x 4096 or 4096 x 2048 cells per rank, the per-rank patch of
+    BASELINE.json configs[3] -- against cup2d_run on one rank: one step as bench.py runs it (FAST, 50 iterations at zero
+    tolerance, main.cpp:7028-7030): dt exact, velocity to 1e-9, pressure to 1e-8 of max|p| (fifty unconverged BiCGSTAB
+    iterations amplify the two summation orders of the dot products)."""
+    import shutil
+    import numpy as np
+    exe = os.path.join(ROOT, "cup2d_amd", "cup2d_run_mpi")
+    one = os.path.join(ROOT, "cup2d_amd", "cup2d_run")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    assert os.path.exists(exe) and os.path.exists(one) and os.path.exists(mpiexec), "drivers / mpiexec not shipped"
+    n = 4096
+    common = ["-n", str(n), "-steps", "1", "-maxiter", "50", "-math", "fast"]
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r1 = subprocess.run([one] + common + ["-state", str(tmp_path / "one")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stdout.decode()[-3000:]
+    rn = subprocess.run([mpiexec, "-n", "2", exe] + common + ["-px", str(px), "-py", str(py), "-comm", "mpi", "-state", str(tmp_path / "n")],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=800, cwd=ROOT, env=env)
+    out = rn.stdout.decode()
+    assert rn.returncode == 0 and "done: 1 steps on 2 ranks" in out, out[-3000:]
+    s1 = [l.split() for l in r1.stdout.decode().splitlines() if l.startswith("step ")]
+    sn = [l.split() for l in out.splitlines() if l.startswith("step ")]
+    assert len(s1) == len(sn) == 1 and float(s1[0][5]) == float(sn[0][5]), (s1, sn)    # dt from max|u| of the same field: exact
+    assert int(s1[0][7]) == int(sn[0][7]) == 50
+    vref = np.fromfile(tmp_path / "one.vel.f64").reshape(n, n, 2)
+    pref = np.fromfile(tmp_path / "one.pres.f64").reshape(n, n)
+    pnx, pny = n // px, n // py
+    dv = dp = 0.0
+    for rank in range(2):
+        cx, cy = rank % px, rank // px
+        sl = (slice(cy * pny, (cy + 1) * pny), slice(cx * pnx, (cx + 1) * pnx))
+        v = np.fromfile(tmp_path / ("n.%d.vel.f64" % rank)).reshape(pny, pnx, 2)
+        p = np.fromfile(tmp_path / ("n.%d.pres.f64" % rank)).reshape(pny, pnx)
+        dv, dp = max(dv, np.abs(v - vref[sl]).max()), max(dp, np.abs(p - pref[sl]).max())
+    dp /= max(np.abs(pref).max(), 1e-300)
+    print("cup2d_run_mpi -n 4096 %dx%d vs cup2d_run: max|dv| %.2e  max|dp| / max|p| %.2e" % (px, py, dv, dp))
     assert dv < 1e-9 and dp < 1e-8, (dv, dp)
 
 

@@ -99,6 +99,10 @@ class AmrSimulation(BodyOps):
         if self._timing is not None:
             self.set_timing(self._timing)
 
+    def ctx_ptr(self):
+        """the cup2d_ctx* of this simulation (for C-ABI calls that take two contexts)"""
+        return self._ctx
+
     def set_solver(self, fused=False, finish_in_kernel=False):
         self._solver = (bool(fused), bool(finish_in_kernel))
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)), "set_solver")
@@ -219,25 +223,43 @@ class AmrSimulation(BodyOps):
         _l.check(self.L.cup2d_project(self._ctx, dt), "project")
         return dict(dt=dt, iters=it.value, err=e.value)
 
-    def adapt(self, rtol, ctol, level_max, host_fields=None):
+    def adapt(self, rtol, ctol, level_max, host_fields=None, route=None):
         """The reference's adapt() (main.cpp:4657-5440) for this simulation: tag by max|vorticity| per block (GPU),
-        validate the states, prolong / restrict the blocks that change on the host (regrid-time work, as in the reference;
-        the unchanged blocks never leave the device), then rebuild the device context on the new grid and re-assemble the
-        Poisson operator.  Returns True if the grid
-        changed.  The caller decides WHEN (should_adapt() is the reference's rule, main.cpp:6603).  Body-free: the
-        reference also runs GradChiOnTmp on chi before tagging (main.cpp:4660), which only matters with bodies."""
+        validate the states, prolong / restrict / copy the fields, rebuild the device context on the new grid and re-assemble
+        the Poisson operator.  Returns True if the grid changed.  The caller decides WHEN (should_adapt() is the reference's
+        rule, main.cpp:6603).  Body-free: the reference also runs GradChiOnTmp on chi before tagging (main.cpp:4660), which
+        only matters with bodies.
+        route: 'device' (default) -- prolongation (main.cpp:4981-5032) and restriction (5149-5166) as kernels between the old
+               and the new context, no field crosses PCIe (cup2d_amr_regrid_device);
+               'changed' -- the blocks that change are computed on the host, only they cross PCIe (round 2);
+               'host' -- every field through host memory (round 1).  All three leave the same bits (tests/test_amr.py).
+        host_fields (older spelling): True = 'host', False = 'changed'."""
+        if route is None:
+            route = "device" if host_fields is None else ("host" if host_fields else "changed")
+        if route not in ("device", "changed", "host"):
+            raise ValueError("route must be 'device', 'changed' or 'host'")
+        host_fields = route == "host"
+        import time as _t
+        tm, t0 = {}, _t.perf_counter()
+
+        def lap(name):
+            nonlocal t0
+            t1 = _t.perf_counter()
+            tm[name] = tm.get(name, 0.0) + (t1 - t0) * 1e3
+            t0 = t1
+        self.adapt_stages_ms = tm  # where the last adapt() spent its time (host clock, ms)
         self.vorticity()
         linf = np.empty(self.grid.nblocks)
         _l.check(self.L.cup2d_block_linf(self._ctx, _l.TMP, _p(linf)), "block_linf")  # one double per block crosses PCIe
+        lap("tags")
         st = validate_states(self.grid.blocks, tag_states(linf, self.grid.level, rtol, ctol, level_max), level_max,
                              self.grid.bpdx, self.grid.bpdy)
+        lap("states")
         if not (st != LEAVE).any():
             return False
         G = self.grid
         nbk, vp = G.nblocks, ctypes.c_void_p
         names = {"chi": _l.CHI, "vel": _l.VEL, "vold": _l.VOLD, "pres": _l.PRES, "pold": _l.POLD}
-        if host_fields is None:  # most blocks change (a start-up regrid): everything through host memory is the shorter way
-            host_fields = int((st != LEAVE).sum()) > 0.3 * nbk
         if host_fields:  # every field through host memory (the round-1 form; also the cross-check of the tests)
             fields = {k: (self.get_field(f).reshape(nbk, -1), _l.FIELD_DIM[f], _l.FIELD_DIM[f] == 2) for k, f in names.items()}
             blocks, data = regrid(G.blocks, st, fields, level_max, G.bpdx, G.bpdy)
@@ -262,6 +284,26 @@ class AmrSimulation(BodyOps):
         needed = np.empty(nbk, dtype=np.int32)
         if self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), n_new, _p(new_blocks), _p(src), _p(needed)) != n_new:
             _l.check(-1, "amr_regrid_plan")
+        if route == "device":
+            lap("plan")
+            new_grid = AmrBlockGrid(new_blocks.astype(np.int64), G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)
+            lap("tables")
+            old_ctx = self._ctx
+            self._ctx = ctypes.c_void_p()  # the old context lives on until the kernels have read it
+            try:
+                self.__init__(new_grid, nu=self.nu, cfl=self.cfl, device=self.device, adapt_steps=self.adapt_steps)
+                self.adapt_stages_ms = tm
+                lap("context")
+                flds = np.array(list(names.values()), dtype=np.int32)
+                _l.check(self.L.cup2d_amr_regrid_device(self._ctx, old_ctx, nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), len(flds),
+                                                        _p(flds)), "amr_regrid_device")
+                lap("fields")
+            finally:
+                self.L.cup2d_destroy(old_ctx)
+            lap("destroy_old")
+            self.install_poisson_matrix()
+            lap("operator")
+            return True
         need_idx = np.ascontiguousarray(np.flatnonzero(needed), dtype=np.int32)
         changed = np.ascontiguousarray(np.flatnonzero(src < 0), dtype=np.int32)
         kept_new = np.ascontiguousarray(np.flatnonzero(src >= 0), dtype=np.int32)

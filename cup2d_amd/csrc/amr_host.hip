@@ -288,6 +288,7 @@ void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, c
 #include <limits>
 
 #include "amr_ghost.h"
+#include "block.h"
 
 namespace {
 
@@ -610,26 +611,19 @@ extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int
   return CUP2D_OK;
 }
 
-// src_of_new [cap] (optional): per new block the old block it is an unchanged copy of, or -1 (prolonged / restricted).
-// needed_old [nblocks] (optional): 1 for every old block a prolonged or restricted block is computed from -- the refined
-// parents and every leaf that overlaps the 3 x 3 block neighbourhood of one (the tensorial halo-1 tile: sides, corners,
-// the coarse cells TestInterp looks at), the compressing siblings.  changed_only: unchanged copies are NOT written to
-// new_fields and of `fields` only the needed blocks are read (a host that keeps the fields on the device moves the
-// unchanged blocks there, cup2d_copy_blocks).
-// Ranged form (cup2d_amr_regrid_local): only the new blocks at positions [new_lo, new_hi) of the new leaf list count --
-// needed_old names what THEY are computed from, only they are written, to new_fields[f] + (position - new_lo) * 64 * dim, and
-// `fields` are compact arrays addressed through slot_of_old (halo1_tile).  new_hi < 0: everything, positions as indices.
-static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *st,
-                             int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
-                             long long cap, int32_t *new_blocks, double *const *new_fields, int32_t *src_of_new,
-                             int32_t *needed_old, bool changed_only, long long new_lo = 0, long long new_hi = -1,
-                             const int32_t *slot_of_old = nullptr) {
-  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid")) return CUP2D_ERR_ARG;
-  if (!st || nfields < 0 || (nfields && (!fields || !dims || !is_vector))) {
-    cup2d::set_error("amr_regrid: bad argument");
-    return CUP2D_ERR_ARG;
-  }
-  const Leaves L(nblocks, blocks, bpdx, bpdy);
+// the new leaf list of a regrid: blocks in the order they are produced from the old list, and where each lands in the
+// Hilbert-sorted output
+struct New {
+  int32_t l, i, j;
+  int src, part;  // part -1: copy of src; 0..3: child 2J+I of src; 4: parent of the sibling group whose (0,0) member is src
+  uint64_t key;
+};
+struct RegridPlan {
+  std::vector<New> nb;
+  std::vector<int> where;  // position of produced block k in the output
+  long long n_new = 0;
+};
+static long long make_plan(const Leaves &L, int nblocks, int bpdx, int bpdy, int level_max, const int32_t *st, bool full, RegridPlan &RP) {
   // a Compress state counts only where the four siblings agree (validated states guarantee it)
   long long n_new = 0;
   for (int k = 0; k < nblocks; k++) {
@@ -646,18 +640,10 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
       if ((i & 1) == 0 && (j & 1) == 0) n_new += 1;
     } else n_new += 1;
   }
-  if (!new_blocks) return n_new;
-  if (cap < n_new || (nfields && !new_fields)) {
-    cup2d::set_error("amr_regrid: capacity %lld < %lld new blocks", cap, n_new);
-    return CUP2D_ERR_ARG;
-  }
+  RP.n_new = n_new;
+  if (!full) return n_new;
   // new blocks in the order they are produced, then sorted along the Hilbert curve of the finest level
-  struct New {
-    int32_t l, i, j;
-    int src, part;  // part -1: copy of src; 0..3: child 2J+I of src; 4: parent of the sibling group whose (0,0) member is src
-    uint64_t key;
-  };
-  std::vector<New> nb;
+  std::vector<New> &nb = RP.nb;
   nb.reserve(n_new);
   int lmax_new = 0;
   for (int k = 0; k < nblocks; k++) {
@@ -682,10 +668,47 @@ static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int b
   std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
     return nb[a].key != nb[c].key ? nb[a].key < nb[c].key : nb[a].l < nb[c].l;
   });
-  std::vector<int> where(nb.size());  // position of produced block k in the output
-  for (size_t p = 0; p < order.size(); p++) {
-    where[order[p]] = (int)p;
-    const New &b = nb[order[p]];
+  RP.where.resize(nb.size());
+  for (size_t p = 0; p < order.size(); p++) RP.where[order[p]] = (int)p;
+  return n_new;
+}
+
+// src_of_new [cap] (optional): per new block the old block it is an unchanged copy of, or -1 (prolonged / restricted).
+// needed_old [nblocks] (optional): 1 for every old block a prolonged or restricted block is computed from -- the refined
+// parents and every leaf that overlaps the 3 x 3 block neighbourhood of one (the tensorial halo-1 tile: sides, corners,
+// the coarse cells TestInterp looks at), the compressing siblings.  changed_only: unchanged copies are NOT written to
+// new_fields and of `fields` only the needed blocks are read (a host that keeps the fields on the device moves the
+// unchanged blocks there, cup2d_copy_blocks).
+// Ranged form (cup2d_amr_regrid_local): only the new blocks at positions [new_lo, new_hi) of the new leaf list count --
+// needed_old names what THEY are computed from, only they are written, to new_fields[f] + (position - new_lo) * 64 * dim, and
+// `fields` are compact arrays addressed through slot_of_old (halo1_tile).  new_hi < 0: everything, positions as indices.
+static long long regrid_impl(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *st,
+                             int nfields, const double *const *fields, const int32_t *dims, const int32_t *is_vector,
+                             long long cap, int32_t *new_blocks, double *const *new_fields, int32_t *src_of_new,
+                             int32_t *needed_old, bool changed_only, long long new_lo = 0, long long new_hi = -1,
+                             const int32_t *slot_of_old = nullptr) {
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid")) return CUP2D_ERR_ARG;
+  if (!st || nfields < 0 || (nfields && (!fields || !dims || !is_vector))) {
+    cup2d::set_error("amr_regrid: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  RegridPlan RP;
+  {
+    const long long rc = make_plan(L, nblocks, bpdx, bpdy, level_max, st, new_blocks != nullptr, RP);
+    if (rc < 0) return rc;
+  }
+  const long long n_new = RP.n_new;
+  if (!new_blocks) return n_new;
+  if (cap < n_new || (nfields && !new_fields)) {
+    cup2d::set_error("amr_regrid: capacity %lld < %lld new blocks", cap, n_new);
+    return CUP2D_ERR_ARG;
+  }
+  const std::vector<New> &nb = RP.nb;
+  const std::vector<int> &where = RP.where;
+  for (size_t k = 0; k < nb.size(); k++) {
+    const size_t p = (size_t)where[k];
+    const New &b = nb[k];
     new_blocks[3 * p] = b.l;
     new_blocks[3 * p + 1] = b.i;
     new_blocks[3 * p + 2] = b.j;
@@ -817,4 +840,277 @@ extern "C" long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks
                                               int32_t *new_blocks, double *const *new_fields) {
   return regrid_impl(nblocks, blocks, bpdx, bpdy, level_max, st, nfields, fields, dims, is_vector, cap, new_blocks, new_fields,
                      nullptr, nullptr, true);
+}
+
+// ---- regrid with the fields on the device (BASELINE.json configs[4] "restriction/prolongation kernels") ----
+//
+// Reference: refinement main.cpp:4981-5032 (child = second-order Taylor expansion about the parent cell on a tensorial
+// halo-1 lab), compression main.cpp:5149-5166 (parent = mean of 2 x 2), unchanged blocks keep their data.  The host side
+// above does the same arithmetic on host arrays; here the old and the new slabs are both resident and no field crosses
+// PCIe: the host derives, from the LEAF LISTS alone, one job per source unit --
+//   COPY      new block p = old block k
+//   RESTRICT  new block p = 2 x 2 means of the four siblings s00, s10, s01, s11
+//   PROLONG   new blocks d0..d3 = the children of old block k, from its halo-1 tile: the 32 side cells by amr_ghost (the
+//             closed forms of the block operators, from the OLD context's device tables), the 4 corner cells by a
+//             10-int descriptor each (wall / same-level cell / 2 x 2 mean of a finer corner block / TestInterp on 3 x 3
+//             coarse cells, every coarse cell a leaf of level l - 1 or the 2 x 2 mean of a leaf of level l)
+// -- and one launch per field runs them, a wave per job.  Operand order as in halo1_tile / prolong above (the translation
+// unit is built with -ffp-contract=off): bit-identical to the host routine, which tests/test_amr.py pins to the reference.
+namespace cup2d {
+
+enum { JOB_COPY = 0, JOB_RESTRICT = 1, JOB_PROLONG = 2 };
+constexpr int JOB_INTS = 8;      // type, a[0..4], i0, j0
+constexpr int CORNER_INTS = 12;  // kind, flags, nine coarse cells (block << 1 | mode, -1: none), pad
+enum { CORNER_WALL = 0, CORNER_SAME = 1, CORNER_COARSE = 2, CORNER_FINE = 3, CORNER_NAN = 4 };
+
+template <int DIM>
+__global__ __launch_bounds__(WG) void k_amr_regrid(const double *__restrict__ fo, double *__restrict__ fn,
+                                                   const int32_t *__restrict__ jobs, const int32_t *__restrict__ corners,
+                                                   int njobs, const int32_t *__restrict__ kind, const int32_t *__restrict__ nbr2,
+                                                   const int32_t *__restrict__ half, int is_vector) {
+  constexpr int W = BS + 2;
+  __shared__ double tiles[WPG][W * W * DIM];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *T = tiles[wave];
+  const double nan = __builtin_nan("");
+  for (int job = blockIdx.x * WPG + wave; job < njobs; job += gridDim.x * WPG) {
+    const int32_t *J = jobs + (size_t)job * JOB_INTS;
+    const int type = J[0];
+    if (type == JOB_COPY) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) fn[((size_t)J[1] * BC) * DIM + lane + 64 * d] = fo[((size_t)J[2] * BC) * DIM + lane + 64 * d];
+      continue;
+    }
+    if (type == JOB_RESTRICT) {  // main.cpp:5149-5166
+      const int X = lane & 7, Y = lane >> 3, x = X & 3, y = Y & 3;
+      const double *kid = fo + (size_t)J[2 + 2 * (Y >> 2) + (X >> 2)] * BC * DIM;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const auto q = [&](int yy, int xx) { return kid[(yy * BS + xx) * DIM + d]; };
+        fn[((size_t)J[1] * BC + lane) * DIM + d] = (q(2 * y, 2 * x) + q(2 * y + 1, 2 * x) + q(2 * y, 2 * x + 1) + q(2 * y + 1, 2 * x + 1)) / 4;
+      }
+      continue;
+    }
+    // ---- PROLONG: the tensorial halo-1 tile of old block b (halo1_tile above) ----
+    const int b = J[1], i0 = J[6], j0 = J[7];
+    const auto at = [&](int ix, int iy, int d) -> double & { return T[((iy + 1) * W + ix + 1) * DIM + d]; };
+#pragma unroll
+    for (int d = 0; d < DIM; d++) at(lane & 7, lane >> 3, d) = fo[((size_t)b * BC + lane) * DIM + d];
+    wave_lds_sync();
+    if (lane < 32) {
+      const int s = lane >> 3, q = lane & 7;
+      const int gx = s == 0 ? -1 : s == 1 ? BS : q, gy = s == 2 ? -1 : s == 3 ? BS : q;
+      const int ex = s == 0 ? 0 : s == 1 ? BS - 1 : q, ey = s == 2 ? 0 : s == 3 ? BS - 1 : q;
+      const int fx = s == 0 ? 1 : s == 1 ? BS - 2 : q, fy = s == 2 ? 1 : s == 3 ? BS - 2 : q;
+      const int kd = kind[4 * b + s], n0 = nbr2[(4 * b + s) * 2], n1 = nbr2[(4 * b + s) * 2 + 1], hf = half[4 * b + s];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const auto get = [&](int blk, int cell) { return fo[((size_t)blk * BC + cell) * DIM + d]; };
+        const double sign = (is_vector && d == (s < 2 ? 0 : 1)) ? -1.0 : 1.0;
+        at(gx, gy, d) = amr_ghost(get, kd, n0, n1, hf, s, q, at(ex, ey, d), at(fx, fy, d), sign);
+      }
+    }
+    wave_lds_sync();
+    if (lane < 4) {  // the four corners
+      const int cx = (lane & 1) ? 1 : -1, cy = (lane >> 1) ? 1 : -1;
+      const int gx = cx < 0 ? -1 : BS, gy = cy < 0 ? -1 : BS, ex = cx < 0 ? 0 : BS - 1, ey = cy < 0 ? 0 : BS - 1;
+      const int32_t *C = corners + ((size_t)J[5] * 4 + lane) * CORNER_INTS;
+      const int ck = C[0];
+      if (ck == CORNER_WALL) {
+        const bool ywall = (C[1] & 2) != 0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          double v = ywall ? at(gx, ey, d) : at(ex, gy, d);
+          if (is_vector && ((ywall && d == 1) || (!ywall && d == 0))) v = -v;
+          at(gx, gy, d) = v;
+        }
+      } else if (ck == CORNER_SAME) {
+        const int cell = (cy < 0 ? BS - 1 : 0) * BS + (cx < 0 ? BS - 1 : 0);
+#pragma unroll
+        for (int d = 0; d < DIM; d++) at(gx, gy, d) = fo[((size_t)C[2] * BC + cell) * DIM + d];
+      } else if (ck == CORNER_COARSE) {  // TestInterp (main.cpp:2219-2230) on component 0 of the 3 x 3 coarse cells (2753-2763)
+        const int XX = 4 * i0 + (cx < 0 ? -1 : 4), YY = 4 * j0 + (cy < 0 ? -1 : 4);
+        const double dx = cx < 0 ? 0.25 : -0.25, dy = cy < 0 ? 0.25 : -0.25;
+        double Cc[3][3];
+        for (int a = 0; a < 3; a++)
+          for (int c = 0; c < 3; c++) {
+            const int e = C[2 + 3 * a + c], GX = XX - 1 + a, GY = YY - 1 + c;
+            double v = nan;
+            if (e >= 0) {
+              const size_t k = (size_t)(e >> 1);
+              if ((e & 1) == 0) v = fo[(k * BC + (GY & 7) * BS + (GX & 7)) * DIM];
+              else {
+                const int x = 2 * (GX & 3), y = 2 * (GY & 3);
+                const auto q = [&](int yy, int xx) { return fo[(k * BC + yy * BS + xx) * DIM]; };
+                v = (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
+              }
+            }
+            Cc[a][c] = v;
+          }
+        const double dudx = 0.5 * (Cc[2][1] - Cc[0][1]);
+        const double dudy = 0.5 * (Cc[1][2] - Cc[1][0]);
+        const double dudxdy = 0.25 * ((Cc[0][0] + Cc[2][2]) - (Cc[2][0] + Cc[0][2]));
+        const double dudx2 = (Cc[0][1] + Cc[2][1]) - 2.0 * Cc[1][1];
+        const double dudy2 = (Cc[1][0] + Cc[1][2]) - 2.0 * Cc[1][1];
+        const double v = (Cc[1][1] + (dx * dudx + dy * dudy)) + (((0.5 * dx * dx) * dudx2 + (0.5 * dy * dy) * dudy2) + (dx * dy) * dudxdy);
+#pragma unroll
+        for (int d = 0; d < DIM; d++) at(gx, gy, d) = v;
+      } else if (ck == CORNER_FINE) {
+        const int x = cx < 0 ? BS - 2 : 0, y = cy < 0 ? BS - 2 : 0;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const auto q = [&](int yy, int xx) { return fo[(((size_t)C[2]) * BC + yy * BS + xx) * DIM + d]; };
+          at(gx, gy, d) = (q(y, x) + q(y + 1, x) + q(y, x + 1) + q(y + 1, x + 1)) / 4;
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIM; d++) at(gx, gy, d) = nan;
+      }
+    }
+    wave_lds_sync();
+    {  // main.cpp:4981-5032: this lane's parent cell -> 2 x 2 cells of child 2J+I
+      const int pi = lane & 7, pj = lane >> 3, I = pi >> 2, Jc = pj >> 2, i = 2 * (pi & 3), j = 2 * (pj & 3);
+      double *kid = fn + (size_t)J[2 + 2 * Jc + I] * BC * DIM;
+      const int ic = pi + 1, jc = pj + 1;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const auto u = [&](int dj, int di) { return T[((jc + dj) * W + ic + di) * DIM + d]; };
+        const double l00 = u(0, 0), l0p = u(1, 0), l0m = u(-1, 0), lm0 = u(0, -1), lmm = u(-1, -1), lmp = u(1, -1);
+        const double lp0 = u(0, 1), lpm = u(-1, 1), lpp = u(1, 1);
+        const double x = 0.5 * (lp0 - lm0), y = 0.5 * (l0p - l0m);
+        const double x2 = (lp0 + lm0) - 2.0 * l00, y2 = (l0p + l0m) - 2.0 * l00;
+        const double xy = 0.25 * ((lpp + lmm) - (lpm + lmp));
+        const double c2 = 0.03125 * x2 + 0.03125 * y2;
+        kid[(j * BS + i) * DIM + d] = (l00 + (-0.25 * x - 0.25 * y)) + (c2 + 0.0625 * xy);
+        kid[(j * BS + i + 1) * DIM + d] = (l00 + (+0.25 * x - 0.25 * y)) + (c2 - 0.0625 * xy);
+        kid[((j + 1) * BS + i) * DIM + d] = (l00 + (-0.25 * x + 0.25 * y)) + (c2 - 0.0625 * xy);
+        kid[((j + 1) * BS + i + 1) * DIM + d] = (l00 + (+0.25 * x + 0.25 * y)) + (c2 + 0.0625 * xy);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+}  // namespace cup2d
+
+// The job and corner tables of a regrid, from the leaf lists alone (host; no field data).  corner descriptors follow
+// halo1_tile's four cases in its order of tests.
+static long long regrid_jobs(const Leaves &L, const RegridPlan &RP, std::vector<int32_t> &jobs, std::vector<int32_t> &corners) {
+  using namespace cup2d;
+  const std::vector<New> &nb = RP.nb;
+  long long njobs = 0, nprol = 0;
+  for (const New &b : nb) {
+    njobs += b.part == -1 || b.part == 4 || b.part == 0;
+    nprol += b.part == 0;
+  }
+  jobs.assign((size_t)njobs * JOB_INTS, 0);
+  corners.assign((size_t)nprol * 4 * CORNER_INTS, -1);
+  // prolong jobs first: the long ones start early
+  long long jp = 0, jo = nprol;
+  for (size_t p = 0; p < nb.size(); p++) {
+    const New &b = nb[p];
+    if (b.part == -1) {
+      int32_t *J = &jobs[(size_t)jo++ * JOB_INTS];
+      J[0] = JOB_COPY; J[1] = RP.where[p]; J[2] = b.src;
+    } else if (b.part == 4) {
+      int32_t *J = &jobs[(size_t)jo++ * JOB_INTS];
+      const int l = L.level(b.src), i = L.bi(b.src), j = L.bj(b.src);
+      J[0] = JOB_RESTRICT; J[1] = RP.where[p];
+      for (int a = 0; a < 4; a++) J[2 + a] = L.find(l, i + (a & 1), j + (a >> 1));  // [2 J + I]
+    } else if (b.part == 0) {
+      int32_t *J = &jobs[(size_t)jp * JOB_INTS];
+      const int k = b.src, l = L.level(k), i0 = L.bi(k), j0 = L.bj(k);
+      J[0] = JOB_PROLONG; J[1] = k;
+      for (int c = 0; c < 4; c++) J[2 + c] = RP.where[p + c];  // the four children are produced consecutively, child 2J+I
+      J[6] = i0; J[7] = j0;
+      const int NX = L.bpdx << l, NY = L.bpdy << l;
+      for (int cn = 0; cn < 4; cn++) {
+        const int cx = (cn & 1) ? 1 : -1, cy = (cn >> 1) ? 1 : -1;
+        int32_t *C = &corners[((size_t)jp * 4 + cn) * CORNER_INTS];
+        const bool xwall = cx < 0 ? i0 == 0 : i0 == NX - 1, ywall = cy < 0 ? j0 == 0 : j0 == NY - 1;
+        if (xwall || ywall) { C[0] = CORNER_WALL; C[1] = (xwall ? 1 : 0) | (ywall ? 2 : 0); continue; }
+        const int ni = i0 + cx, nj = j0 + cy;
+        int kk = L.find(l, ni, nj);
+        if (kk >= 0) { C[0] = CORNER_SAME; C[2] = kk; continue; }
+        if (l > 0 && L.find(l - 1, ni >> 1, nj >> 1) >= 0) {
+          C[0] = CORNER_COARSE;
+          const int XX = 4 * i0 + (cx < 0 ? -1 : 4), YY = 4 * j0 + (cy < 0 ? -1 : 4);
+          for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) {
+              const int GX = XX - 1 + a, GY = YY - 1 + c;
+              int e = L.find(l - 1, GX >> 3, GY >> 3);
+              if (e >= 0) e = e << 1;
+              else {
+                e = L.find(l, GX >> 2, GY >> 2);
+                e = e >= 0 ? ((e << 1) | 1) : -1;
+              }
+              C[2 + 3 * a + c] = e;
+            }
+          continue;
+        }
+        kk = L.find(l + 1, 2 * i0 + (cx > 0 ? 2 : -1), 2 * j0 + (cy > 0 ? 2 : -1));
+        if (kk >= 0) { C[0] = CORNER_FINE; C[2] = kk; }
+        else C[0] = CORNER_NAN;
+      }
+      J[5] = (int32_t)jp;
+      jp++;
+    }
+  }
+  return njobs;
+}
+
+extern "C" int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nblocks, const int32_t *blocks, int bpdx, int bpdy,
+                                       int level_max, const int32_t *st, int nfields, const int32_t *fields) {
+  using namespace cup2d;
+  if (!dst || !src || dst == src) { set_error("amr_regrid_device: two contexts expected"); return CUP2D_ERR_ARG; }
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid_device")) return CUP2D_ERR_ARG;
+  if (!st || nfields < 0 || (nfields && !fields)) { set_error("amr_regrid_device: bad argument"); return CUP2D_ERR_ARG; }
+  if (src->device != dst->device) { set_error("amr_regrid_device: both contexts must live on the same device"); return CUP2D_ERR_ARG; }
+  if (!src->amr.active || src->nblocks != nblocks || src->nghost != 0 || dst->nghost != 0) {
+    set_error("amr_regrid_device: the source context must hold the %d blocks of the old leaf list with its tables set (cup2d_set_amr), no ghost blocks", nblocks);
+    return CUP2D_ERR_ARG;
+  }
+  for (int f = 0; f < nfields; f++)
+    if (!field_ok(fields[f])) { set_error("amr_regrid_device: field %d", fields[f]); return CUP2D_ERR_ARG; }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  RegridPlan RP;
+  const long long n_new = make_plan(L, nblocks, bpdx, bpdy, level_max, st, true, RP);
+  if (n_new < 0) return (int)n_new;
+  if (n_new != dst->nblocks) {
+    set_error("amr_regrid_device: the destination context holds %d blocks, the new leaf list %lld", dst->nblocks, n_new);
+    return CUP2D_ERR_ARG;
+  }
+  std::vector<int32_t> jobs, corners;
+  const long long njobs = regrid_jobs(L, RP, jobs, corners);
+  CUP2D_HIP_CHECK(hipSetDevice(dst->device));
+  int32_t *d_jobs = nullptr, *d_corners = nullptr;
+  CUP2D_HIP_CHECK(dev_malloc(&d_jobs, jobs.size() * sizeof(int32_t) + 16));
+  CUP2D_HIP_CHECK(dev_malloc(&d_corners, corners.size() * sizeof(int32_t) + 16));
+  int rc = CUP2D_OK;
+  do {
+    if (hipStreamSynchronize(src->stream) != hipSuccess) { rc = CUP2D_ERR_HIP; break; }  // what the old context has enqueued is done
+    if (hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, dst->stream) != hipSuccess) { rc = CUP2D_ERR_HIP; break; }
+    if (!corners.empty() && hipMemcpyAsync(d_corners, corners.data(), corners.size() * sizeof(int32_t), hipMemcpyHostToDevice, dst->stream) != hipSuccess) { rc = CUP2D_ERR_HIP; break; }
+    int grid = (int)((njobs + WPG - 1) / WPG);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    for (int f = 0; f < nfields && njobs > 0; f++) {
+      const int fld = fields[f], dim = dim_of(fld);
+      const AmrTopo &A = src->amr;
+      if (dim == 1)
+        hipLaunchKernelGGL(k_amr_regrid<1>, dim3(grid), dim3(WG), 0, dst->stream, (const double *)src->d_field[fld], dst->d_field[fld],
+                           (const int32_t *)d_jobs, (const int32_t *)d_corners, (int)njobs, (const int32_t *)A.d_kind,
+                           (const int32_t *)A.d_nbr2, (const int32_t *)A.d_half, 0);
+      else
+        hipLaunchKernelGGL(k_amr_regrid<2>, dim3(grid), dim3(WG), 0, dst->stream, (const double *)src->d_field[fld], dst->d_field[fld],
+                           (const int32_t *)d_jobs, (const int32_t *)d_corners, (int)njobs, (const int32_t *)A.d_kind,
+                           (const int32_t *)A.d_nbr2, (const int32_t *)A.d_half, 1);
+      if (hipGetLastError() != hipSuccess) { rc = CUP2D_ERR_HIP; break; }
+    }
+    if (rc == CUP2D_OK && hipStreamSynchronize(dst->stream) != hipSuccess) rc = CUP2D_ERR_HIP;  // the tables go back to the pool
+  } while (0);
+  dev_free(d_jobs);
+  dev_free(d_corners);
+  if (rc != CUP2D_OK) set_error("amr_regrid_device: HIP error: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
 }

@@ -15,8 +15,8 @@
 // reference's dump() files (main.cpp:3367-3466: <prefix>.<step>.xyz.raw / .attr.raw / .xdmf2) every k-th step.
 // With -levelMax the grid is the reference's block-AMR grid (one level-0 block as base, uniform at -levelStart to begin
 // with): every step computes dt, regrids (adapt(), main.cpp:4657-5440: vorticity and its per-block max on the GPU,
-// states validated, fields prolonged / restricted and the Poisson rows re-assembled by the library's host routines,
-// the device context rebuilt on the new leaves) and advances (main.cpp:6579-7187).  -init is then a block-ordered slab
+// states validated by the library's host routines, fields prolonged / restricted by kernels between the old and the new
+// context, the Poisson rows re-assembled on the new leaves) and advances (main.cpp:6579-7187).  -init is then a block-ordered slab
 // [nblocks][64][2] of the start grid (blocks row-major), default two Gaussian vortices; -state writes
 // <prefix>.blocks.i32, .vel.f64, .pres.f64 at the end.
 // Only host code here: no kernels and no CPU fallback -- without the library's GPU path it fails.
@@ -185,30 +185,24 @@ struct AmrRun {
     RUN(cup2d_amr_validate_states(n, blocks.data(), 1, 1, level_max, st.data()));
     for (int b = 0; b < n; b++) any = any || st[b] != 0;
     if (!any) return false;
-    static const int fields[5] = {CUP2D_CHI, CUP2D_VEL, CUP2D_VOLD, CUP2D_PRES, CUP2D_POLD};
-    static const int32_t dims[5] = {1, 2, 2, 1, 1}, vec[5] = {0, 1, 1, 0, 0};
-    std::vector<std::vector<double>> src(5), dst(5);
-    const double *sp[5];
-    double *dp[5];
-    for (int f = 0; f < 5; f++) {
-      src[f].resize((size_t)n * BC * dims[f]);
-      RUN(cup2d_download_slab(ctx, fields[f], src[f].data()));
-      sp[f] = src[f].data();
-    }
-    const long long n2 = cup2d_amr_regrid(n, blocks.data(), 1, 1, level_max, st.data(), 5, sp, dims, vec, 0, nullptr, nullptr);
-    if (n2 < 0) { std::fprintf(stderr, "cup2d_run: amr_regrid: %s\n", cup2d_last_error()); std::exit(1); }
+    // the fields stay on the device: the plan gives the new leaf list, a context is built on it, and one kernel per field
+    // copies / restricts / prolongs between the old and the new slabs (cup2d_amr_regrid_device; main.cpp:4981-5032, 5149-5166)
+    static const int32_t fields[5] = {CUP2D_CHI, CUP2D_VEL, CUP2D_VOLD, CUP2D_PRES, CUP2D_POLD};
+    const long long n2 = cup2d_amr_regrid_plan(n, blocks.data(), 1, 1, level_max, st.data(), 0, nullptr, nullptr, nullptr);
+    if (n2 < 0) { std::fprintf(stderr, "cup2d_run: amr_regrid_plan: %s\n", cup2d_last_error()); std::exit(1); }
     std::vector<int32_t> nblocks2((size_t)3 * n2);
-    for (int f = 0; f < 5; f++) {
-      dst[f].resize((size_t)n2 * BC * dims[f]);
-      dp[f] = dst[f].data();
-    }
-    if (cup2d_amr_regrid(n, blocks.data(), 1, 1, level_max, st.data(), 5, sp, dims, vec, n2, nblocks2.data(), dp) != n2) {
-      std::fprintf(stderr, "cup2d_run: amr_regrid: %s\n", cup2d_last_error());
+    if (cup2d_amr_regrid_plan(n, blocks.data(), 1, 1, level_max, st.data(), n2, nblocks2.data(), nullptr, nullptr) != n2) {
+      std::fprintf(stderr, "cup2d_run: amr_regrid_plan: %s\n", cup2d_last_error());
       std::exit(1);
     }
+    cup2d_ctx *old = ctx;
+    std::vector<int32_t> old_blocks;
+    old_blocks.swap(blocks);
     blocks.swap(nblocks2);
+    ctx = nullptr;
     build();
-    for (int f = 0; f < 5; f++) RUN(cup2d_upload_slab(ctx, fields[f], dst[f].data()));
+    RUN(cup2d_amr_regrid_device(ctx, old, n, old_blocks.data(), 1, 1, level_max, st.data(), 5, fields));
+    cup2d_destroy(old);
     return true;
   }
 };

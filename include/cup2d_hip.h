@@ -342,6 +342,16 @@ long long cup2d_amr_regrid_local(int nblocks, const int32_t *blocks, int bpdx, i
                                  long long new_lo, long long new_hi, long long cap, int32_t *new_blocks, int32_t *src_of_new,
                                  int32_t *needed_old, int nfields, const double *const *fields, const int32_t *slot_of_old,
                                  const int32_t *dims, const int32_t *is_vector, double *const *new_fields);
+/* The regrid with the fields ON THE DEVICE (prolongation main.cpp:4981-5032, restriction 5149-5166 as
+ * kernels).  src: the context on the old leaf list blocks[nblocks][3] with its tables set (cup2d_set_amr); dst: a context
+ * created on the NEW leaf list in cup2d_amr_regrid_plan's order (same device).  For every field listed in fields[nfields]
+ * (CUP2D_VEL, ...) the new slab is written by one launch: unchanged blocks copied, compressed sibling groups averaged, the
+ * four children of every refined block prolonged from the parent's tensorial halo-1 tile (side cells by the closed forms
+ * of the block operators from src's device tables, corner cells from descriptors the host derives from the leaf list).
+ * No field crosses PCIe; bit-identical to cup2d_amr_regrid (same expressions, -ffp-contract=off).  One rank (no ghost
+ * blocks); the N-rank regrid is cup2d_amr_regrid_local.  The caller destroys src afterwards. */
+int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nblocks, const int32_t *blocks, int bpdx, int bpdy,
+                            int level_max, const int32_t *states, int nfields, const int32_t *fields);
 int cup2d_download_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, double *host);
 int cup2d_upload_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, const double *host);
 int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks);

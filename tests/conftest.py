@@ -102,6 +102,11 @@ def pytest_runtest_protocol(item, nextitem):
     last = [l for l in text.strip().splitlines() if l.strip()][-1:] or [""]
     if rc == 0 and " passed" in last[0]:
         outcome, longrepr = "passed", None
+        if "-s" in opts:  # the parent was asked not to capture: what the test printed in its child is shown here
+            shown = [l for l in text.splitlines() if l.strip() and not l.startswith("[cup2d] start") and l.strip() != "."
+                     and " passed" not in l]
+            if shown:
+                _say(item.config, "\n".join(shown) + "\n")
     elif rc in (0, 5) and " skipped" in last[0] and " passed" not in last[0] and " failed" not in last[0]:
         outcome, longrepr = "skipped", (str(item.fspath), 0, "skipped in the child process:\n" + tail[-1500:])
     else:

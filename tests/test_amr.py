@@ -406,16 +406,71 @@ def test_block_linf_is_the_tagging_norm_gpu(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_amr_adapt_then_step_gpu(gpu_lib, oracle):
-    """AmrSimulation.adapt (vorticity tags on the GPU, host regrid, new context + operator) lands on the reference's
-    post-adapt grid and fields; a time step on the new grid then runs and stays finite and divergence-reducing"""
+def test_amr_regrid_kernels_vs_host_regrid_gpu(gpu_lib):
+    """SURVEY.md row a21 on the device (cup2d_amr_regrid_device: k_amr_regrid -- copy / restrict main.cpp:5149-5166 / prolong
+    4981-5032 from the tensorial halo-1 tile, side cells by the block operators' closed forms, corner cells from host-built
+    descriptors) against the library's host regrid, which test_amr_host_regrid_library_vs_python_statement pins to the
+    statement-for-statement BlockLab and test_amr_regrid_vs_reference_adapt to the reference's adapt(): random tags on random
+    balanced grids, all five fields of a regrid, bit for bit, every kind of side and corner visited (walls, same level,
+    coarser with TestInterp on leaf and averaged coarse cells, finer)."""
+    import ctypes
+    from cup2d_amd import amr as A, lib as L
+    lib = L.load_library()
+    names = {"chi": L.CHI, "vel": L.VEL, "vold": L.VOLD, "pres": L.PRES, "pold": L.POLD}
+    seen = dict(refine=0, compress=0, regrids=0)
+    for seed in range(6):
+        rng = np.random.default_rng(300 + seed)
+        level_max, l0 = 4 + seed % 3, 1 + seed % 2
+        blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
+        data = {k: rng.uniform(-1, 1, (len(blocks), 64 * L.FIELD_DIM[f])) for k, f in names.items()}
+        pr, pc = [0.15, 0.3, 0.1][seed % 3], [0.3, 0.15, 0.5][seed % 3]
+        for it in range(6):
+            nb = len(blocks)
+            if nb > 600:
+                break
+            st = A.validate_states(blocks, rng.choice([0, 1, 2], size=nb, p=[1 - pr - pc, pr, pc]).astype(np.int32), level_max)
+            if not (st != A.LEAVE).any():
+                continue
+            fields = {k: (data[k], L.FIELD_DIM[f], L.FIELD_DIM[f] == 2) for k, f in names.items()}
+            b_host, d_host = A.regrid(blocks, st, fields, level_max)
+            b32 = np.ascontiguousarray(blocks, dtype=np.int32)
+            st32 = np.ascontiguousarray(st, dtype=np.int32)
+            flds = np.array(list(names.values()), dtype=np.int32)
+            with A.AmrSimulation(A.AmrBlockGrid(blocks)) as old, A.AmrSimulation(A.AmrBlockGrid(b_host)) as new:
+                for k, f in names.items():
+                    old.set_field(f, data[k])
+                    new.set_field(f, np.full_like(d_host[k], np.nan))
+                L.check(lib.cup2d_amr_regrid_device(new.ctx_ptr(), old.ctx_ptr(), nb, b32.ctypes.data_as(ctypes.c_void_p), 1, 1, level_max,
+                                                    st32.ctypes.data_as(ctypes.c_void_p), len(flds), flds.ctypes.data_as(ctypes.c_void_p)),
+                        "amr_regrid_device")
+                for k, f in names.items():
+                    got = new.get_field(f).reshape(len(b_host), -1)
+                    assert not np.isnan(got).any(), (seed, it, k)
+                    assert np.array_equal(got, d_host[k]), (seed, it, k, int((got != d_host[k]).any(axis=1).sum()))
+                # argument checks: a destination of the wrong size, a source without tables
+                assert lib.cup2d_amr_regrid_device(old.ctx_ptr(), old.ctx_ptr(), nb, b32.ctypes.data_as(ctypes.c_void_p), 1, 1, level_max,
+                                                   st32.ctypes.data_as(ctypes.c_void_p), 0, None) == L.ERR_ARG
+            seen["refine"] += int((st == A.REFINE).sum())
+            seen["compress"] += int((st == A.COMPRESS).sum())
+            seen["regrids"] += 1
+            blocks, data = b_host, d_host
+    assert seen["regrids"] >= 12 and seen["refine"] > 100 and seen["compress"] > 100, seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["device", "changed", "host"])
+def test_amr_adapt_then_step_gpu(gpu_lib, oracle, route):
+    """AmrSimulation.adapt (vorticity tags on the GPU, regrid, new context + operator) lands on the reference's post-adapt
+    grid and fields, by every route -- 'device': prolongation / restriction kernels, no field crosses PCIe; 'changed': the
+    changed blocks computed on the host; 'host': everything through host memory --; a time step on the new grid then runs
+    and stays finite and divergence-reducing"""
     from cup2d_amd import lib as L
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
     G = golden("amr_adapt.npz")
     with AmrSimulation(AmrBlockGrid(G["pre_blocks"])) as s:
         s.set_field(L.VEL, G["pre_vel"])
         s.set_field(L.PRES, G["pre_pres"])
-        assert s.adapt(float(G["rtol"]), float(G["ctol"]), int(G["level_max"]))
+        assert s.adapt(float(G["rtol"]), float(G["ctol"]), int(G["level_max"]), route=route)
         assert set(map(tuple, s.grid.blocks.tolist())) == set(map(tuple, G["post_blocks"].tolist()))
         ref_v = _by_block(G["post_blocks"], G["post_vel"].reshape(len(G["post_blocks"]), -1))
         ref_p = _by_block(G["post_blocks"], G["post_pres"])
@@ -696,11 +751,13 @@ def test_amr_operator_installed_from_the_tables_equals_the_triplet_route_gpu(gpu
 
 
 @pytest.mark.gpu
-def test_amr_adapt_at_configs4_scale_vs_reference_gpu(gpu_lib, oracle):
-    """AmrSimulation.adapt() -- tags from max|vorticity| per block on the GPU, the library's state validation and
-    (threaded) prolongation / restriction, new context, operator from the tables -- against the reference's own adapt()
-    (main.cpp:4657-5440) on the ~39 k-block, seven-level grid of a live run: same leaves afterwards, all five fields bit
-    for bit."""
+@pytest.mark.parametrize("route", ["device", "changed"])
+def test_amr_adapt_at_configs4_scale_vs_reference_gpu(gpu_lib, oracle, route):
+    """AmrSimulation.adapt() -- tags from max|vorticity| per block on the GPU, the library's state validation,
+    prolongation / restriction ('device': k_amr_regrid between the old and the new context, row a21 as kernels; 'changed':
+    the threaded host routine on the blocks the plan names), new context, operator from the tables -- against the
+    reference's own adapt() (main.cpp:4657-5440) on the ~39 k-block, seven-level grid of a live run: same leaves
+    afterwards, all five fields bit for bit."""
     if not oracle.have_reference():
         pytest.skip("reference harness not built")
     from cup2d_amd import lib as L
@@ -710,7 +767,7 @@ def test_amr_adapt_at_configs4_scale_vs_reference_gpu(gpu_lib, oracle):
     with AmrSimulation(AmrBlockGrid(pre["blocks"])) as s:
         for k, f in names.items():
             s.set_field(f, pre[k])
-        assert s.adapt(0.5, 0.1, 10)
+        assert s.adapt(0.5, 0.1, 10, route=route)
         blocks = s.grid.blocks
         print("reference adapt: %d -> %d blocks; here %d" % (len(pre["blocks"]), len(post["blocks"]), len(blocks)))
         assert len(blocks) == len(post["blocks"]) != len(pre["blocks"])

@@ -276,14 +276,14 @@ class AmrSimulation(BodyOps):
         # computed from; only those come to the host, only the changed blocks go back.
         b32 = np.ascontiguousarray(G.blocks, dtype=np.int32).reshape(-1, 3)
         st32 = np.ascontiguousarray(st, dtype=np.int32)
-        n_new = self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), 0, None, None, None)
+        cap = 4 * nbk  # every block refined: one call instead of count + fill
+        new_blocks = np.empty((cap, 3), dtype=np.int32)
+        src = np.empty(cap, dtype=np.int32)
+        needed = np.empty(nbk, dtype=np.int32)
+        n_new = self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), cap, _p(new_blocks), _p(src), _p(needed))
         if n_new < 0:
             _l.check(int(n_new), "amr_regrid_plan")
-        new_blocks = np.empty((n_new, 3), dtype=np.int32)
-        src = np.empty(n_new, dtype=np.int32)
-        needed = np.empty(nbk, dtype=np.int32)
-        if self.L.cup2d_amr_regrid_plan(nbk, _p(b32), G.bpdx, G.bpdy, level_max, _p(st32), n_new, _p(new_blocks), _p(src), _p(needed)) != n_new:
-            _l.check(-1, "amr_regrid_plan")
+        new_blocks, src = new_blocks[:n_new], src[:n_new]
         if route == "device":
             lap("plan")
             new_grid = AmrBlockGrid(new_blocks.astype(np.int64), G.bpdx, G.bpdy, G.h0 * max(G.bpdx, G.bpdy) * BS)

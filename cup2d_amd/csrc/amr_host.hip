@@ -16,43 +16,9 @@ namespace {
 
 constexpr int BS = CUP2D_BS;
 
-// regrid-time host loops over independent blocks run on a few threads (CUP2D_HOST_THREADS, default min(16, cores)):
-// n items in chunk_count(n, grain) contiguous chunks, fn(lo, hi, chunk)
-int host_threads() {
-  static const int want = [] {
-    const char *e = getenv("CUP2D_HOST_THREADS");
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int v = e ? atoi(e) : (int)(hw ? (hw < 16u ? hw : 16u) : 1u);
-    return v < 1 ? 1 : v;
-  }();
-  return want;
-}
-int chunk_count(long long n, long long grain) {
-  long long nt = (n + grain - 1) / grain;
-  if (nt > host_threads()) nt = host_threads();
-  return (int)(nt < 1 ? 1 : nt);
-}
-template <class F>
-void parallel_chunks(long long n, long long grain, F fn) {
-  const long long nt = chunk_count(n, grain);
-  if (nt <= 1) {
-    fn(0LL, n, 0);
-    return;
-  }
-  // a thread that cannot be created (std::system_error: the process is out of threads) must not take the process down from
-  // inside a C ABI call: the chunks that found no thread run here, serially
-  std::vector<std::thread> th;
-  long long started = 0;
-  try {
-    for (; started < nt; started++) {
-      const long long t = started;
-      th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
-    }
-  } catch (const std::system_error &) {
-  }
-  for (long long t = started; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, (int)t);
-  for (auto &x : th) x.join();
-}
+using cup2d::chunk_count;
+using cup2d::host_threads;
+using cup2d::parallel_chunks;
 
 struct Row {  // a row under construction: duplicate columns are summed in the order they arrive (mapColVal)
   int n = 0;
@@ -556,8 +522,12 @@ extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int
     if (L.level(k) < level_max) of_level[L.level(k)].push_back(k);
   for (int m = level_max - 1; m >= 0; m--) {
     // next to finer blocks: may not compress; refines if one of those is refining (main.cpp:4734-4803)
+    // (every block of a pass writes its OWN state only and reads states of the finer level, final since the previous pass:
+    // the blocks of a level are independent -- chunks on the host threads)
     if (m < level_max - 1)
-      for (int k : of_level[m]) {
+      parallel_chunks((long long)of_level[m].size(), 2048, [&](long long lo_, long long hi_, int) {
+      for (long long q_ = lo_; q_ < hi_; q_++) {
+        const int k = of_level[m][(size_t)q_];
         if (st[k] == REFINE) continue;
         const int i = L.bi(k), j = L.bj(k);
         bool done = false;
@@ -580,34 +550,45 @@ extern "C" int cup2d_amr_validate_states(int nblocks, const int32_t *blocks, int
             }
           }
       }
+      });
     if (m == 0) break;
-    // a compressing block next to a same-level refining block stays (main.cpp:4804-4830)
-    for (int k : of_level[m]) {
+    // a compressing block next to a same-level refining block stays (main.cpp:4804-4830): Refine states of the level are
+    // final here; the verdicts are collected in parallel (reads only) and applied afterwards
+    std::vector<unsigned char> keep(of_level[m].size(), 0);
+    parallel_chunks((long long)of_level[m].size(), 2048, [&](long long lo_, long long hi_, int) {
+    for (long long q_ = lo_; q_ < hi_; q_++) {
+      const int k = of_level[m][(size_t)q_];
       if (st[k] != COMPRESS) continue;
       const int i = L.bi(k), j = L.bj(k);
       for (int x = -1; x <= 1; x++)
         for (int y = -1; y <= 1; y++) {
           if ((x == 0 && y == 0) || !L.inside(m, i + x, j + y)) continue;
           const int nk = L.find(m, i + x, j + y);
-          if (nk >= 0 && st[nk] == REFINE) st[k] = LEAVE;
+          if (nk >= 0 && st[nk] == REFINE) keep[(size_t)q_] = 1;
         }
     }
+    });
+    for (size_t q_ = 0; q_ < keep.size(); q_++)
+      if (keep[q_]) st[of_level[m][q_]] = LEAVE;
   }
-  // four siblings compress together or not at all (main.cpp:4831-4861)
-  for (int k = 0; k < nblocks; k++) {
-    const int l = L.level(k), i = L.bi(k), j = L.bj(k);
-    int sib[4];
-    bool all = true;
-    for (int a = 0; a < 2; a++)
-      for (int c = 0; c < 2; c++) {
-        const int s = L.find(l, 2 * (i >> 1) + a, 2 * (j >> 1) + c);
-        sib[2 * a + c] = s;
-        all = all && s >= 0 && st[s] == COMPRESS;
-      }
-    if (!all)
-      for (int s : sib)
-        if (s >= 0 && st[s] == COMPRESS) st[s] = LEAVE;
-  }
+  // four siblings compress together or not at all (main.cpp:4831-4861): every compressing block looks at its group (reads
+  // only, in parallel), then the verdicts are applied
+  std::vector<unsigned char> stays((size_t)nblocks, 0);
+  parallel_chunks(nblocks, 4096, [&](long long lo_, long long hi_, int) {
+    for (int k = (int)lo_; k < (int)hi_; k++) {
+      if (st[k] != COMPRESS) continue;
+      const int l = L.level(k), i = L.bi(k), j = L.bj(k);
+      bool all = true;
+      for (int a = 0; a < 2; a++)
+        for (int c = 0; c < 2; c++) {
+          const int s = L.find(l, 2 * (i >> 1) + a, 2 * (j >> 1) + c);
+          all = all && s >= 0 && st[s] == COMPRESS;
+        }
+      stays[k] = all ? 0 : 1;
+    }
+  });
+  for (int k = 0; k < nblocks; k++)
+    if (stays[k]) st[k] = LEAVE;
   return CUP2D_OK;
 }
 
@@ -665,9 +646,18 @@ static long long make_plan(const Leaves &L, int nblocks, int bpdx, int bpdy, int
   for (New &b : nb) b.key = hilbert(bits, (uint64_t)b.i << (Lf - b.l), (uint64_t)b.j << (Lf - b.l));
   std::vector<int> order(nb.size());
   for (size_t k = 0; k < nb.size(); k++) order[k] = (int)k;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
-    return nb[a].key != nb[c].key ? nb[a].key < nb[c].key : nb[a].l < nb[c].l;
-  });
+  const auto before = [&](int a, int c) { return nb[a].key != nb[c].key ? nb[a].key < nb[c].key : nb[a].l < nb[c].l; };
+  // A leaf list that came out of a regrid is in Hilbert order already, and a regrid substitutes in place (the children where
+  // the parent was, the parent where its (even, even) child was): only the four children of a refined block need ordering
+  // among themselves.  Any other input order (a caller's first grid) takes the full sort.
+  for (size_t k = 0; k + 3 < nb.size(); k++)
+    if (nb[k].part == 0) std::sort(order.begin() + k, order.begin() + k + 4, before), k += 3;
+  bool sorted = true;
+  for (size_t p = 1; p < order.size() && sorted; p++) sorted = !before(order[p], order[p - 1]);
+  if (!sorted) {
+    for (size_t k = 0; k < nb.size(); k++) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), before);
+  }
   RP.where.resize(nb.size());
   for (size_t p = 0; p < order.size(); p++) RP.where[order[p]] = (int)p;
   return n_new;
@@ -859,7 +849,7 @@ extern "C" long long cup2d_amr_regrid_changed(int nblocks, const int32_t *blocks
 namespace cup2d {
 
 enum { JOB_COPY = 0, JOB_RESTRICT = 1, JOB_PROLONG = 2 };
-constexpr int JOB_INTS = 8;      // type, a[0..4], i0, j0
+constexpr int JOB_INTS = 8;      // type | COPY: dst, src | RESTRICT: dst, s00, s10, s01, s11 | PROLONG: src, d0..d3, i0, j0
 constexpr int CORNER_INTS = 12;  // kind, flags, nine coarse cells (block << 1 | mode, -1: none), pad
 enum { CORNER_WALL = 0, CORNER_SAME = 1, CORNER_COARSE = 2, CORNER_FINE = 3, CORNER_NAN = 4 };
 
@@ -914,7 +904,7 @@ __global__ __launch_bounds__(WG) void k_amr_regrid(const double *__restrict__ fo
     if (lane < 4) {  // the four corners
       const int cx = (lane & 1) ? 1 : -1, cy = (lane >> 1) ? 1 : -1;
       const int gx = cx < 0 ? -1 : BS, gy = cy < 0 ? -1 : BS, ex = cx < 0 ? 0 : BS - 1, ey = cy < 0 ? 0 : BS - 1;
-      const int32_t *C = corners + ((size_t)J[5] * 4 + lane) * CORNER_INTS;
+      const int32_t *C = corners + ((size_t)job * 4 + lane) * CORNER_INTS;  // prolong jobs come first: job index = corner record
       const int ck = C[0];
       if (ck == CORNER_WALL) {
         const bool ywall = (C[1] & 2) != 0;
@@ -1052,8 +1042,7 @@ static long long regrid_jobs(const Leaves &L, const RegridPlan &RP, std::vector<
         if (kk >= 0) { C[0] = CORNER_FINE; C[2] = kk; }
         else C[0] = CORNER_NAN;
       }
-      J[5] = (int32_t)jp;
-      jp++;
+      jp++;  // (its corner record is number jp: the prolong jobs come first, in this order)
     }
   }
   return njobs;
@@ -1072,9 +1061,12 @@ extern "C" int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nbloc
   }
   for (int f = 0; f < nfields; f++)
     if (!field_ok(fields[f])) { set_error("amr_regrid_device: field %d", fields[f]); return CUP2D_ERR_ARG; }
+  StageClock clk("amr_regrid_device");
   const Leaves L(nblocks, blocks, bpdx, bpdy);
+  clk.lap("leaf table");
   RegridPlan RP;
   const long long n_new = make_plan(L, nblocks, bpdx, bpdy, level_max, st, true, RP);
+  clk.lap("plan");
   if (n_new < 0) return (int)n_new;
   if (n_new != dst->nblocks) {
     set_error("amr_regrid_device: the destination context holds %d blocks, the new leaf list %lld", dst->nblocks, n_new);
@@ -1082,6 +1074,7 @@ extern "C" int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nbloc
   }
   std::vector<int32_t> jobs, corners;
   const long long njobs = regrid_jobs(L, RP, jobs, corners);
+  clk.lap("jobs");
   CUP2D_HIP_CHECK(hipSetDevice(dst->device));
   int32_t *d_jobs = nullptr, *d_corners = nullptr;
   CUP2D_HIP_CHECK(dev_malloc(&d_jobs, jobs.size() * sizeof(int32_t) + 16));
@@ -1111,6 +1104,7 @@ extern "C" int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nbloc
   } while (0);
   dev_free(d_jobs);
   dev_free(d_corners);
+  clk.lap("upload + kernels + sync");
   if (rc != CUP2D_OK) set_error("amr_regrid_device: HIP error: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }

@@ -130,6 +130,37 @@ DevPool &pool() {
 }
 }  // namespace
 
+// Streams, events and pinned words of a context, recycled like the device buffers: a regrid destroys one context and
+// creates another (adapt(), main.cpp:4657-5440), and hipHostMalloc / hipHostFree / stream and event create / destroy cost
+// 3 ms each way (measured, 63 k-block grid: cup2d_destroy "events, stream, delete" 3.2 ms)
+namespace {
+struct HostRes {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[cup2d_ctx::SOLVE_AHEAD] = {nullptr};
+  KrylovScalars *h_sc = nullptr;
+  double *h_red = nullptr;
+  int *h_status = nullptr;
+};
+struct HostResPool {
+  std::mutex mu;
+  std::map<int, std::vector<HostRes>> idle;  // per device
+  std::map<int, int> num_cus;                // hipGetDeviceProperties is slow: once per device
+};
+HostResPool &host_pool() {
+  static HostResPool P;
+  return P;
+}
+void host_res_destroy(HostRes &r) {
+  for (auto &e : r.ev)
+    if (e) (void)hipEventDestroy(e);
+  if (r.stream) (void)hipStreamDestroy(r.stream);
+  if (r.h_sc) (void)hipHostFree(r.h_sc);
+  if (r.h_red) (void)hipHostFree(r.h_red);
+  if (r.h_status) (void)hipHostFree(r.h_status);
+  r = HostRes();
+}
+}  // namespace
+
 hipError_t dev_malloc_raw(void **p, size_t bytes) {
   DevPool &P = pool();
   if (!P.on) return hipMalloc(p, bytes);
@@ -221,6 +252,15 @@ struct DevTmp {
 using namespace cup2d;
 
 extern "C" int cup2d_trim_pool(void) {
+  {
+    HostResPool &HP = host_pool();
+    std::lock_guard<std::mutex> g(HP.mu);
+    for (auto &kv : HP.idle) {
+      (void)hipSetDevice(kv.first);
+      for (HostRes &r : kv.second) host_res_destroy(r);
+      kv.second.clear();
+    }
+  }
   auto &P = cup2d::pool();
   std::vector<void *> drop;
   {
@@ -267,7 +307,9 @@ int cup2d_create(cup2d_ctx **out, int nblocks, int nghost, int n_inner, const in
   }
   CUP2D_HIP_CHECK(hipSetDevice(device));
   cup2d_ctx *c = new cup2d_ctx;
+  StageClock clk("cup2d_create");
   const int st = create_impl(c, nblocks, nghost, n_inner, nbr, h, device);
+  clk.lap("create_impl");
   if (st != CUP2D_OK) {  // nothing of a half-built context leaks: cup2d_destroy frees whatever was allocated
     cup2d_destroy(c);
     return st;
@@ -287,12 +329,37 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   if (const char *e = getenv("CUP2D_FINISH_IN_KERNEL")) c->finish_in_kernel = atoi(e) != 0;
   if (const char *e = getenv("CUP2D_PRECOND"))  // A/B timing aid; cup2d_set_precond is the API
     c->precond = e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD);
+  HostRes res;
+  bool recycled = false;
   {
+    HostResPool &HP = host_pool();
+    std::lock_guard<std::mutex> g(HP.mu);
+    auto it = HP.num_cus.find(device);
+    if (it != HP.num_cus.end()) c->num_cus = it->second;
+    auto &v = HP.idle[device];
+    if (!v.empty()) {
+      res = v.back();
+      v.pop_back();
+      recycled = true;
+    }
+  }
+  if (c->num_cus <= 0) {
     hipDeviceProp_t prop;
     CUP2D_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
+    HostResPool &HP = host_pool();
+    std::lock_guard<std::mutex> g(HP.mu);
+    HP.num_cus[device] = c->num_cus;
   }
-  CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  if (recycled) {  // handed over whole: cup2d_destroy returns (or frees) whatever the context holds
+    c->own_stream = res.stream;
+    c->h_sc = res.h_sc;
+    c->h_red = res.h_red;
+    c->h_status = res.h_status;
+    for (int i = 0; i < cup2d_ctx::SOLVE_AHEAD; i++) c->solve_ev[i] = res.ev[i];
+  } else {
+    CUP2D_HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  }
   c->stream = c->own_stream;
   CUP2D_HIP_CHECK(dev_malloc(&c->d_nbr, sizeof(int32_t) * 4 * nblocks));
   CUP2D_HIP_CHECK(hipMemcpy(c->d_nbr, nbr, sizeof(int32_t) * 4 * nblocks, hipMemcpyHostToDevice));
@@ -333,17 +400,24 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   CUP2D_HIP_CHECK(dev_malloc(&c->d_ticket, sizeof(unsigned)));
   CUP2D_HIP_CHECK(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
   CUP2D_HIP_CHECK(dev_malloc(&c->d_sc, sizeof(KrylovScalars)));
-  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
-  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
-  CUP2D_HIP_CHECK(hipHostMalloc(&c->h_status, sizeof(int) * cup2d_ctx::SOLVE_AHEAD));
-  for (auto &e : c->solve_ev) CUP2D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!recycled) {
+    CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
+    CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
+    CUP2D_HIP_CHECK(hipHostMalloc(&c->h_status, sizeof(int) * cup2d_ctx::SOLVE_AHEAD));
+    for (auto &e : c->solve_ev) CUP2D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ::memset(c->h_sc, 0, sizeof(KrylovScalars));
+  ::memset(c->h_red, 0, sizeof(double) * 8);
+  ::memset(c->h_status, 0, sizeof(int) * cup2d_ctx::SOLVE_AHEAD);
   return CUP2D_OK;
 }
 
 void cup2d_destroy(cup2d_ctx *c) {
   if (!c) return;
+  StageClock clk("cup2d_destroy");
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  clk.lap("device sync");
   (void)comm_finalize_impl(c);
   bodies_release(c);
   walk_plans_release(c);
@@ -358,19 +432,41 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->d_fault);
   dev_free(c->d_ticket);
   dev_free(c->d_sc);
-  (void)hipHostFree(c->h_sc);
-  (void)hipHostFree(c->h_red);
-  (void)hipHostFree(c->h_status);
-  for (auto &e : c->solve_ev) if (e) (void)hipEventDestroy(e);
+  {  // stream, events and pinned words go back to the per-device free list (complete sets only; a few are kept)
+    HostRes res;
+    res.stream = c->own_stream;
+    res.h_sc = c->h_sc;
+    res.h_red = c->h_red;
+    res.h_status = c->h_status;
+    bool complete = res.stream && res.h_sc && res.h_red && res.h_status;
+    for (int i = 0; i < cup2d_ctx::SOLVE_AHEAD; i++) {
+      res.ev[i] = c->solve_ev[i];
+      complete = complete && res.ev[i];
+    }
+    bool kept = false;
+    if (complete) {
+      HostResPool &HP = host_pool();
+      std::lock_guard<std::mutex> g(HP.mu);
+      auto &v = HP.idle[c->device];
+      if (v.size() < 8) {
+        v.push_back(res);
+        kept = true;
+      }
+    }
+    if (!kept) host_res_destroy(res);
+    c->own_stream = nullptr;
+  }
   dev_free(c->mat.d_ptr); dev_free(c->mat.d_col); dev_free(c->mat.d_val); dev_free(c->mat.d_gather);
   dev_free(c->mat.d_reg);
   dev_free(c->amr.d_level); dev_free(c->amr.d_kind); dev_free(c->amr.d_nbr2); dev_free(c->amr.d_half);
   dev_free(c->amr.d_faces); dev_free(c->amr.d_faces2);
   dev_free(c->plan.d_send_block); dev_free(c->plan.d_send_face);
   dev_free(c->plan.d_recv_block); dev_free(c->plan.d_recv_face);
+  clk.lap("frees");
   for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  clk.lap("events, stream, delete");
 }
 
 int cup2d_set_stream(cup2d_ctx *c, void *s) {
@@ -577,6 +673,7 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
       if (!ok) { set_error("set_amr: block %d side %d: kind %d neighbours %d %d", b, s, k, n0, n1); return CUP2D_ERR_ARG; }
     }
   }
+  StageClock clk("cup2d_set_amr");
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   cup2d::AmrTopo &A = c->amr;
   dev_free(A.d_level); dev_free(A.d_kind); dev_free(A.d_nbr2); dev_free(A.d_half); dev_free(A.d_faces); dev_free(A.d_faces2);
@@ -601,6 +698,7 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;
   A.h_min = h0 / (double)(1 << lmax);  // N ranks: the finest level of the WHOLE grid, cup2d_amr_set_finest_level
   A.active = true;
+  clk.lap("tables to the device");
   return CUP2D_OK;
 }
 int cup2d_amr_set_finest_level(cup2d_ctx *c, int level_finest) {
@@ -898,6 +996,7 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
                         const std::vector<int32_t> &ecol, const std::vector<double> &eval, int nregular) {
   const size_t entries = ecol.size();
   const auto stored = [&](int s) { return reg[(size_t)4 * s] == SELL_STORED; };
+  StageClock clk("install_sell");
   CUP2D_TRY(cup2d_clear_matrix(c));
   SellMatrix &M = c->mat;
   CUP2D_HIP_CHECK(dev_malloc(&M.d_ptr, ptr.size() * sizeof(long long)));
@@ -913,13 +1012,14 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
   M.nregular = nregular;
   M.entries = entries;
   M.halo = halo;
+  clk.lap("upload ptr / col / val / reg");
   if (hybrid) {
     // tables of the tile-fused sweeps (ctx.h SellMatrix): the tiling, which tiles are all plain, whose z the rows of the
     // other tiles read
     const int nbk = c->nblocks;
     std::vector<int> plain_run((size_t)nbk + 1, 0);  // number of consecutive plain slices from s on
     for (int s = nbk - 1; s >= 0; s--) plain_run[s] = stored(s) ? 0 : plain_run[s + 1] + 1;
-    const auto good = [&](int s) {  // 16 plain slices from s on with <= 16 neighbour slots outside the set
+    const auto good_at = [&](int s) {  // 16 plain slices from s on with <= 16 neighbour slots outside the set
       if (plain_run[s] < FUSED_TILE) return false;
       int ring = 0;
       for (int b = s; b < s + FUSED_TILE; b++)
@@ -929,6 +1029,12 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
         }
       return ring <= FUSED_TILE;
     };
+    // (evaluated for every start in parallel: the serial walk below asks for most of them where tiles do not line up)
+    std::vector<unsigned char> good_tab((size_t)nbk, 0);
+    parallel_chunks(nbk, 4096, [&](long long lo, long long hi, int) {
+      for (long long q = lo; q < hi; q++) good_tab[(size_t)q] = good_at((int)q) ? 1 : 0;
+    });
+    const auto good = [&](int s) { return good_tab[(size_t)s] != 0; };
     std::vector<int32_t> tile0;
     for (int s = 0; s < nbk;) {
       tile0.push_back(s);
@@ -964,6 +1070,7 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
       }
     }
     M.ntiles = ntiles;
+    clk.lap("tiling");
     CUP2D_HIP_CHECK(dev_malloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(dev_malloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));
@@ -975,6 +1082,7 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
       CUP2D_HIP_CHECK(dev_malloc(&M.d_gen, gen.size() * sizeof(int32_t)));
       CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    clk.lap("upload tile tables");
   }
   M.active = true;
   return CUP2D_OK;
@@ -1100,8 +1208,12 @@ int cup2d_amr_install_poisson(cup2d_ctx *c) {
   std::vector<long long> ptr;
   std::vector<double> eval;
   int nregular = 0;
+  StageClock clk("amr_install_poisson");
   amr_assemble_hybrid(c->nblocks, c->amr.h_kind.data(), c->amr.h_nbr2.data(), c->amr.h_half.data(), reg, ptr, ecol, eval, &nregular);
-  return install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, nregular);
+  clk.lap("assemble rows");
+  const int rc = install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, nregular);
+  clk.lap("install_sell");
+  return rc;
 }
 int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
   CUP2D_CHECK_CTX(c);

@@ -1,5 +1,10 @@
 // ctx.h -- context object and launch helpers shared by the translation units of libcup2d_hip.so
 #pragma once
+#include <system_error>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -270,6 +275,57 @@ int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the i
 // instead of paying hipFree + hipMalloc (28 ms of a 89 ms regrid on a 63 k-block grid).  Sizes are rounded up to
 // m * 2^k, m in 8..15 (<= 12.5 % slack) so that a grid that grew or shrank a little still finds its buffers; a buffer
 // is ALWAYS handed out zero-filled.  CUP2D_POOL=0 turns the pool off; cup2d_trim_pool() returns the cache to the driver.
+// regrid-time host loops over independent blocks run on a few threads (CUP2D_HOST_THREADS, default min(16, cores)):
+// n items in chunk_count(n, grain) contiguous chunks, fn(lo, hi, chunk)
+inline int host_threads() {
+  static const int want = [] {
+    const char *e = getenv("CUP2D_HOST_THREADS");
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int v = e ? atoi(e) : (int)(hw ? (hw < 16u ? hw : 16u) : 1u);
+    return v < 1 ? 1 : v;
+  }();
+  return want;
+}
+inline int chunk_count(long long n, long long grain) {
+  long long nt = (n + grain - 1) / grain;
+  if (nt > host_threads()) nt = host_threads();
+  return (int)(nt < 1 ? 1 : nt);
+}
+template <class F>
+inline void parallel_chunks(long long n, long long grain, F fn) {
+  const long long nt = chunk_count(n, grain);
+  if (nt <= 1) {
+    fn(0LL, n, 0);
+    return;
+  }
+  // a thread that cannot be created (std::system_error: the process is out of threads) must not take the process down from
+  // inside a C ABI call: the chunks that found no thread run here, serially
+  std::vector<std::thread> th;
+  long long started = 0;
+  try {
+    for (; started < nt; started++) {
+      const long long t = started;
+      th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
+    }
+  } catch (const std::system_error &) {
+  }
+  for (long long t = started; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, (int)t);
+  for (auto &x : th) x.join();
+}
+
+// regrid-time host work, stage by stage, on stderr when CUP2D_HOST_TIMING is set (development aid)
+struct StageClock {
+  const char *what;
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageClock(const char *w) : what(w), on(getenv("CUP2D_HOST_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char *stage) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cup2d timing] %s: %s %.3f ms\n", what, stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 hipError_t dev_malloc_raw(void **p, size_t bytes);
 template <class T>
 inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_raw(reinterpret_cast<void **>(p), bytes); }

@@ -451,12 +451,16 @@ def ref_step_time(n, steps=3, max_iter=50, nu=1e-3, vel=None, threads=None, time
     return json.loads(txt.strip().split("\n")[-1])
 
 
-def ref_bench(n, reps=10, vel=None, dt=1e-4, threads=None):
-    """Time the reference functors (OpenMP) -- CPU baseline, kind='reference'."""
+def ref_bench(n, reps=10, vel=None, dt=1e-4, threads=None, nomatrix=False, timeout=None):
+    """Time the reference functors (OpenMP) -- CPU baseline, kind='reference'.  nomatrix: the harness drops the Poisson
+    triplets the reference's start-up assembles (minutes of serial host work at 4096^2 that no functor reads)."""
     import json
     if vel is None:
         vel = taylor_green(n)
+    kw = dict(reps=int(reps), dt=float(dt))
+    if nomatrix:
+        kw["nomatrix"] = 1
     with tempfile.TemporaryDirectory() as d:
         _c(vel).tofile(os.path.join(d, "vel.in"))
-        txt = _run_ref("bench", n, d, _threads=threads, reps=int(reps), dt=float(dt))
+        txt = _run_ref("bench", n, d, _threads=threads, _timeout=timeout, **kw)
     return json.loads(txt.strip().split("\n")[-1])

@@ -90,9 +90,16 @@ struct Patch {
     while ((1 << bits) < std::max(std::max(nbx, nby), 2)) bits++;
     struct Key { int halo; uint64_t h; int cell; };
     std::vector<Key> key(nblocks);
+    // the halo set is made of whole aligned patches of g x g blocks (cup2d_amd/grid.py BlockGrid has the reasons and the
+    // measurement: the 16-block tiles of the Krylov sweeps stay 4 x 4 patches, the WENO walk finds its 2 x 2 quads)
+    int g = 1;
+    if (side_on[0] || side_on[1] || side_on[2] || side_on[3])
+      for (int cand : {16, 4})
+        if (nbx % cand == 0 && nby % cand == 0 && std::min(nbx, nby) >= 4 * cand) { g = cand; break; }
     for (int y = 0; y < nby; y++)
       for (int x = 0; x < nbx; x++) {
-        const bool t = (x == 0 && side_on[0]) || (x == nbx - 1 && side_on[1]) || (y == 0 && side_on[2]) || (y == nby - 1 && side_on[3]);
+        const int cxg = x / g, cyg = y / g;
+        const bool t = (cxg == 0 && side_on[0]) || (cxg == nbx / g - 1 && side_on[1]) || (cyg == 0 && side_on[2]) || (cyg == nby / g - 1 && side_on[3]);
         key[y * nbx + x] = {t ? 1 : 0, hilbert(bits, x, y), y * nbx + x};
         n_inner += t ? 0 : 1;
       }

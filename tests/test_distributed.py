@@ -18,6 +18,9 @@ def launch(mode, world, px, py, nbx, nby, port, timeout=600, **extra_env):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=timeout, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]
+    for line in out.splitlines():  # what rank 0 measured (shown with -s)
+        if line.startswith(("gpu_big", "amr_big", "amr_regrid_cpu")):
+            print(line)
 
 
 @pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 4, 6), (2, 1, 2, 5, 3), (4, 2, 2, 4, 4)])

@@ -1306,6 +1306,7 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
     CUP2D_HIP_CHECK(dev_malloc(&p.d_recv_face, nrecv * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_block, rb, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_face, rf, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
+    p.h_recv_block.assign(rb, rb + nrecv);
   }
   return CUP2D_OK;
 }

@@ -121,6 +121,8 @@ struct RcclComm {
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   int nranks = 1, rank = 0;
   std::vector<int> peer, soff, roff, cnt, rcnt;   // per peer: rank, first strip in the send / receive list, strips sent / received
+  std::vector<int> rblock0;  // per peer: the first of its ghost blocks
+  bool direct = false;       // every peer's ghost blocks are consecutive: whole blocks can be received in place
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
   long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
 };
@@ -160,6 +162,68 @@ static int rccl_exchange(void *user, double *send, double *recv, int strip_doubl
   CUP2D_NCCL(rc, rc->api->GroupEnd());
   CUP2D_HIP_CB(hipEventRecord(rc->ev_arrived, rc->comm_stream));
   return 0;
+}
+// Whole ghost blocks of the Krylov vectors (krylov_fused.hip, the ghost-block form of the sweeps), the short way.  Measured on
+// a patch that is its own W and E neighbour (tools/gpu_selfperiodic_step.py, tools/kernel_timeline.py; 4096^2 cells): between
+// a sweep and the next one the generic path spends 57 us -- pack 5, 16 idle until the send/recv kernel starts on the
+// communication stream (event record -> wait on the other stream -> launch), the kernel 13, 17 idle until the unpack kernel
+// starts on the compute stream (the same hand-over back), unpack 6 -- to overlap the transfer with 11 us of all-gather and
+// scalar kernel.  There is no inner sweep to hide these exchanges behind (the sweep that follows needs both the ghost blocks
+// and the scalars), so they run on the COMPUTE stream, back to back with the reduction, and the blocks of a peer -- which
+// cup2d_halo_plan numbers consecutively -- are received straight into the vectors' ghost regions: no second stream, no event,
+// no unpack kernel.  The send buffer is vector-major ([vector][strip][64 cells], a whole block in its own cell order) so that
+// what goes to one peer for one vector is one contiguous piece.
+__global__ __launch_bounds__(WG) void k_pack_blocks(const double *__restrict__ v0, const double *__restrict__ v1,
+                                                   const double *__restrict__ v2, double *__restrict__ buf,
+                                                   const int32_t *__restrict__ blocks, int nstrips, int nv) {
+  const size_t per = (size_t)nstrips * BC, total = per * nv;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const int v = (int)(i / per);
+    const size_t q = i - (size_t)v * per;
+    const double *f = v == 0 ? v0 : (v == 1 ? v1 : v2);
+    buf[i] = f[(size_t)blocks[q >> 6] * BC + (q & 63)];
+  }
+}
+bool comm_blocks_direct(const cup2d_ctx *c) {
+  static const bool on = [] { const char *e = getenv("CUP2D_COMM_DIRECT"); return !e || atoi(e) != 0; }();
+  return on && c->rccl && c->comm_user == (void *)c->rccl && c->rccl->direct && c->nghost > 0;
+}
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2) {
+  RcclComm *rc = c->rccl;
+  rc->n_exchange++;
+  if (rc->peer.empty() || nv < 1 || nv > 3) return CUP2D_OK;
+  double *vecs[3] = {v0, v1, v2};
+  const int ns = c->plan.nsend;
+  if (ns > 0) {
+    const size_t total = (size_t)ns * BC * nv;
+    int grid = (int)((total + WG - 1) / WG);
+    if (grid > c->grid) grid = c->grid;
+    ProfScope prof(c, CUP2D_T_HALO);
+    hipLaunchKernelGGL(k_pack_blocks, dim3(grid), dim3(WG), 0, c->stream, (const double *)v0, (const double *)v1, (const double *)v2,
+                       rc->d_send, (const int32_t *)c->plan.d_send_block, ns, nv);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  const auto fail = [&](ncclResult_t r, const char *what) {
+    set_error("comm_exchange_blocks: %s -> %s", what, rc->api->GetErrorString(r));
+    return CUP2D_ERR_COMM;
+  };
+  ncclResult_t r = rc->api->GroupStart();
+  if (r != ncclSuccess) return fail(r, "ncclGroupStart");
+  for (int v = 0; v < nv; v++)  // receives first, vector by vector and peer by peer: the order the peers send in
+    for (size_t i = 0; i < rc->peer.size(); i++)
+      if (rc->rcnt[i] > 0) {
+        r = rc->api->Recv(vecs[v] + (size_t)rc->rblock0[i] * BC, (size_t)rc->rcnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, c->stream);
+        if (r != ncclSuccess) return fail(r, "ncclRecv");
+      }
+  for (int v = 0; v < nv; v++)
+    for (size_t i = 0; i < rc->peer.size(); i++)
+      if (rc->cnt[i] > 0) {
+        r = rc->api->Send(rc->d_send + ((size_t)v * ns + rc->soff[i]) * BC, (size_t)rc->cnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, c->stream);
+        if (r != ncclSuccess) return fail(r, "ncclSend");
+      }
+  r = rc->api->GroupEnd();
+  if (r != ncclSuccess) return fail(r, "ncclGroupEnd");
+  return CUP2D_OK;
 }
 // wait callback: the compute stream goes on once the strips of the last exchange have arrived
 static int rccl_wait(void *user, void *stream) {
@@ -290,6 +354,15 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     if (nstrips[i] == 0 && nstrips_recv[i] == 0) continue;
     rc->peer.push_back(peer_rank[i]); rc->soff.push_back(send_offset[i]);
     rc->roff.push_back(recv_offset[i]); rc->cnt.push_back(nstrips[i]); rc->rcnt.push_back(nstrips_recv[i]);
+  }
+  // whole ghost blocks can be received in place where every peer's ghost blocks are consecutive (cup2d_amd/grid.py and the
+  // C++ plans number them so; a plan that does not keeps the generic path)
+  rc->direct = (int)c->plan.h_recv_block.size() == c->plan.nrecv;
+  for (size_t i = 0; i < rc->peer.size() && rc->direct; i++) {
+    const int r0 = rc->rcnt[i] > 0 ? c->plan.h_recv_block[(size_t)rc->roff[i]] : c->nblocks;
+    rc->rblock0.push_back(r0);
+    for (int k = 0; k < rc->rcnt[i]; k++)
+      if (c->plan.h_recv_block[(size_t)rc->roff[i] + k] != r0 + k) rc->direct = false;
   }
   // widest message: whole blocks of three Krylov vectors = 192 doubles per strip (the WENO halo is 3 x 8 x 2 = 48)
   const size_t strip = 3 * BC;

@@ -55,6 +55,7 @@ struct HaloPlan {
   int nsend = 0, nrecv = 0;
   int32_t *d_send_block = nullptr, *d_send_face = nullptr;
   int32_t *d_recv_block = nullptr, *d_recv_face = nullptr;
+  std::vector<int32_t> h_recv_block;  // host copy: the communicator checks whether a peer's ghost blocks are consecutive
 };
 
 // General sparse Poisson operator (the matrix of main.cpp:7034-7112 as LocalSpMatDnVec hands it over,
@@ -363,6 +364,10 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
+// whole ghost blocks of up to three Krylov vectors straight into the vectors' ghost regions on the compute stream (in-library
+// communicator, comm.hip); false: the caller takes the generic begin / end pair
+bool comm_blocks_direct(const cup2d_ctx *c);
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2);
 int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
 int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);
 void bodies_release(cup2d_ctx *c);  // penalize.hip

@@ -1166,7 +1166,12 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // p, nu and the accumulated correction y start at zero (cuda.cu:436-437): the first AB sweep and the first sweep E
   // know (k_fused: fresh, k_sweepE_y: first) and do not read them; y's first buffer stays "the best iterate" only as
   // long as no iterate has beaten the initial guess (KrylovScalars::best_is_x0) and is not read then either -- no fills
-  if (gb) CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
+  // in-library communicator: the ghost blocks travel on the compute stream and land in place (comm.hip comm_exchange_blocks)
+  const bool direct = gb && comm_blocks_direct(c);
+  if (gb) {
+    if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_r, nullptr, nullptr));
+    else CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
+  }
 
   static const int AHEAD = [] {
     const char *e = getenv("CUP2D_SOLVE_AHEAD");
@@ -1213,9 +1218,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       CUP2D_TRY(eab_sweep<0>(c, a, merge));
     }
     if (merge == 2) {  // N ranks: the ghost blocks of nu' and p' in flight behind the reduction
-      if (gb) CUP2D_TRY(exchange_begin_blocks2(c, N[0], P[0]));
+      if (direct) CUP2D_TRY(comm_exchange_blocks(c, 2, N[0], P[0], nullptr));
+      else if (gb) CUP2D_TRY(exchange_begin_blocks2(c, N[0], P[0]));
       CUP2D_TRY(finish_local(c, 1, 0, 1));
-      if (gb) CUP2D_TRY(exchange_end_blocks2(c, N[0], P[0]));
+      if (gb && !direct) CUP2D_TRY(exchange_end_blocks2(c, N[0], P[0]));
     }
     for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
       const int grp = k / GROUP, slot = grp % AHEAD_G;
@@ -1234,9 +1240,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         CUP2D_TRY(eab_sweep<3>(c, a, merge));
       }
       if (merge == 2) {  // MODE 2 recomputes r' of the blocks around a tile: it needs t in the ghost blocks
-        if (gb) CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
+        if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr));
+        else if (gb) CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
         CUP2D_TRY(finish_local(c, 5, 0, 5));
-        if (gb) CUP2D_TRY(exchange_end(c, c->d_t, 1, BS));
+        if (gb && !direct) CUP2D_TRY(exchange_end(c, c->d_t, 1, BS));
       }
       int *const report = last_of_group ? &c->h_status[slot] : nullptr;
       {
@@ -1248,9 +1255,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         CUP2D_TRY(eab_sweep<2>(c, a, merge));
       }
       if (merge == 2) {
-        if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+        if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n]));
+        else if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
         CUP2D_TRY(finish_local(c, 2, 1, 4, report));
-        if (gb) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
+        if (gb && !direct) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }
@@ -1274,10 +1282,11 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb, stored ? (k == 0 ? 1 : 2) : 0));
     }
     // CD needs the ghost nu', the next AB the ghost p': one message, in flight behind the reduction
-    if (gb) CUP2D_TRY(exchange_begin_blocks2(c, nu_out, p_out));
+    if (direct) CUP2D_TRY(comm_exchange_blocks(c, 2, nu_out, p_out, nullptr));
+    else if (gb) CUP2D_TRY(exchange_begin_blocks2(c, nu_out, p_out));
     if (merge == 0) CUP2D_TRY(finish(c, GP, 1, 0, 1, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 1, 0, 1));
-    if (gb) CUP2D_TRY(exchange_end_blocks2(c, nu_out, p_out));
+    if (gb && !direct) CUP2D_TRY(exchange_end_blocks2(c, nu_out, p_out));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
       const int o = k & 1, n = o ^ 1;
@@ -1299,10 +1308,11 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       else launchE(k_sweepE_y<0>);
     }
     CUP2D_HIP_CHECK(hipGetLastError());
-    if (gb) CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // the new r: in flight behind the reduction of E
+    if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_r, nullptr, nullptr));  // the new r
+    else if (gb) CUP2D_TRY(exchange_begin(c, c->d_r, 1, BS));  // ... in flight behind the reduction of E
     if (merge == 0) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, report));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 1, 3, report));
-    if (gb) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));
+    if (gb && !direct) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));
     if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;

@@ -174,3 +174,59 @@ def test_one_rank_amr_through_the_communicator_equals_the_plain_context(gpu_lib,
             assert np.array_equal(s.get_field(L.VEL), v0) and np.array_equal(s.get_field(L.PRES), p0)
     finally:
         dist.destroy_process_group()
+
+
+_DIRECT_CHILD = r'''
+import sys, os, json, ctypes, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+from cup2d_amd import lib as L
+from test_comm import _self_periodic_sim
+out = {}
+for nbx, nby in ((32, 16), (64, 64)):
+    s, g = _self_periodic_sim(nbx, nby)
+    with s:
+        rng = np.random.default_rng(7)
+        b = rng.uniform(-1, 1, (g.ny, g.nx)); b -= b.mean()
+        s.set_solver(fused=True, finish_in_kernel=True)
+        s.keep_last_iterate(True)
+        s.tmp = b
+        s.fill(L.PRES, 0.0)
+        r = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=6)
+        e = s.last_iterate_to(L.POLD)
+        x = s.pold
+        s.fill(L.PRES, 0.0)
+        conv = s.poisson_solve(tol=1e-8, max_restarts=100, max_iter=2000)
+        n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+        L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "stats")
+        out["%%dx%%d" %% (nbx, nby)] = dict(x=x.tobytes().hex()[:0], sum=float(np.abs(x).sum()), hash=int(np.frombuffer(x.tobytes(), dtype=np.uint64).sum() %% (1 << 62)),
+                                        iters=r["iters"], err=e, conv_err=conv["err"], conv_iters=conv["iters"], form=list(s.last_solver_form()), exchanges=ex.value)
+        L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_ghost_blocks_received_in_place_equal_the_generic_exchange(gpu_lib):
+    """The Krylov ghost-block exchanges of the in-library communicator run on the compute stream and land in the vectors' ghost
+    regions directly (comm.hip comm_exchange_blocks; default) -- against the generic path (pack, second stream, receive buffer,
+    unpack; CUP2D_COMM_DIRECT=0) on a patch that is its own W and E neighbour, bytes through ncclSend / ncclRecv both ways: six
+    iterations of the two-launch MERGE 2 solver leave the same last iterate bit for bit, a converged solve the same counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for direct in ("1", "0"):
+        env = dict(os.environ, CUP2D_COMM_DIRECT=direct, NCCL_SOCKET_IFNAME="lo")
+        r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD % (root, root)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and lines, r.stdout.decode()[-3000:]
+        res[direct] = json.loads(lines[0][7:])
+    for k in res["1"]:
+        a, b = res["1"][k], res["0"][k]
+        assert a["form"] == b["form"] == ["eab", 2, a["form"][2]] and a["iters"] == b["iters"] == 6, (a, b)
+        assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (k, a, b)
+        assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"] <= 1e-8, (a, b)
+        assert a["exchanges"] == b["exchanges"] > 12

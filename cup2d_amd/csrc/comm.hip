@@ -188,10 +188,17 @@ bool comm_blocks_direct(const cup2d_ctx *c) {
   static const bool on = [] { const char *e = getenv("CUP2D_COMM_DIRECT"); return !e || atoi(e) != 0; }();
   return on && c->rccl && c->comm_user == (void *)c->rccl && c->rccl->direct && c->nghost > 0;
 }
-int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2) {
+int comm_blocks_wait(cup2d_ctx *c) {
+  RcclComm *rc = c->rccl;
+  if (rc->peer.empty()) return CUP2D_OK;
+  CUP2D_HIP_CHECK(hipStreamWaitEvent(c->stream, rc->ev_arrived, 0));
+  return CUP2D_OK;
+}
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream) {
   RcclComm *rc = c->rccl;
   rc->n_exchange++;
   if (rc->peer.empty() || nv < 1 || nv > 3) return CUP2D_OK;
+  hipStream_t xs = on_comm_stream ? rc->comm_stream : c->stream;
   double *vecs[3] = {v0, v1, v2};
   const int ns = c->plan.nsend;
   if (ns > 0) {
@@ -207,22 +214,27 @@ int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v
     set_error("comm_exchange_blocks: %s -> %s", what, rc->api->GetErrorString(r));
     return CUP2D_ERR_COMM;
   };
+  if (on_comm_stream) {
+    CUP2D_HIP_CHECK(hipEventRecord(rc->ev_packed, c->stream));
+    CUP2D_HIP_CHECK(hipStreamWaitEvent(rc->comm_stream, rc->ev_packed, 0));
+  }
   ncclResult_t r = rc->api->GroupStart();
   if (r != ncclSuccess) return fail(r, "ncclGroupStart");
   for (int v = 0; v < nv; v++)  // receives first, vector by vector and peer by peer: the order the peers send in
     for (size_t i = 0; i < rc->peer.size(); i++)
       if (rc->rcnt[i] > 0) {
-        r = rc->api->Recv(vecs[v] + (size_t)rc->rblock0[i] * BC, (size_t)rc->rcnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, c->stream);
+        r = rc->api->Recv(vecs[v] + (size_t)rc->rblock0[i] * BC, (size_t)rc->rcnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, xs);
         if (r != ncclSuccess) return fail(r, "ncclRecv");
       }
   for (int v = 0; v < nv; v++)
     for (size_t i = 0; i < rc->peer.size(); i++)
       if (rc->cnt[i] > 0) {
-        r = rc->api->Send(rc->d_send + ((size_t)v * ns + rc->soff[i]) * BC, (size_t)rc->cnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, c->stream);
+        r = rc->api->Send(rc->d_send + ((size_t)v * ns + rc->soff[i]) * BC, (size_t)rc->cnt[i] * BC, ncclDouble, rc->peer[i], rc->p2p, xs);
         if (r != ncclSuccess) return fail(r, "ncclSend");
       }
   r = rc->api->GroupEnd();
   if (r != ncclSuccess) return fail(r, "ncclGroupEnd");
+  if (on_comm_stream) CUP2D_HIP_CHECK(hipEventRecord(rc->ev_arrived, rc->comm_stream));
   return CUP2D_OK;
 }
 // wait callback: the compute stream goes on once the strips of the last exchange have arrived

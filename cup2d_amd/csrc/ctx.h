@@ -367,7 +367,10 @@ int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
 // whole ghost blocks of up to three Krylov vectors straight into the vectors' ghost regions on the compute stream (in-library
 // communicator, comm.hip); false: the caller takes the generic begin / end pair
 bool comm_blocks_direct(const cup2d_ctx *c);
-int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2);
+// on_comm_stream: the transfer runs on the communication stream behind the pack (the caller sweeps on meanwhile) and
+// comm_blocks_wait makes the compute stream wait for its arrival
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream = false);
+int comm_blocks_wait(cup2d_ctx *c);
 int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
 int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);
 void bodies_release(cup2d_ctx *c);  // penalize.hip

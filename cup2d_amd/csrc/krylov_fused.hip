@@ -951,18 +951,24 @@ static int edge_share_mode(cup2d_ctx *c, int mode) {
   static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
   return ((mask >> mode) & 1) && edge_share_of(c);
 }
+// blocks [first, first + count) (a multiple of 16 blocks in front of it: the tiling is the whole range's); merge 0: the launch
+// leaves its partials at [poff, poff + grid) and a later launch of the same sweep finishes over all of them.  *G: its grid.
 template <int MODE>
-static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge) {
-  const int nb = c->nblocks, g = fused_grid(c, nb);
+static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int count, int poff, int *G) {
+  const int g = fused_grid(c, count);
   const auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, 0, nb,
-                       0, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, first, count,
+                       poff, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
   };
   if (merge == 1) go(k_edge<MODE, 1>);
-  else go(k_edge<MODE, 2>);
+  else if (merge == 2) go(k_edge<MODE, 2>);
+  else go(k_edge<MODE, 0>);
   CUP2D_HIP_CHECK(hipGetLastError());
+  if (G) *G = g;
   return CUP2D_OK;
 }
+template <int MODE>
+static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge) { return eab_sweep<MODE>(c, a, merge, 0, c->nblocks, 0, nullptr); }
 
 template <int MODE>
 static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks, int re = 0) {
@@ -1129,7 +1135,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_edge<0, 2>), reinterpret_cast<const void *>(&k_edge<1, 0>),
                         reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>),
                         reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>),
-                        reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>)};
+                        reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>),
+                        reinterpret_cast<const void *>(&k_edge<2, 0>), reinterpret_cast<const void *>(&k_edge<3, 0>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1210,6 +1217,17 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // second one is the s vector this organisation never stores)
     double *P[2] = {c->d_p2, c->d_p}, *N[2] = {c->d_nu2, c->d_nu}, *R[2] = {c->d_r, c->d_s};
     static const int zigzag = [] { const char *e = getenv("CUP2D_EAB_ZIGZAG"); return e ? atoi(e) : 1; }();
+    // N ranks, opt-in (CUP2D_SWEEP_SPLIT=1): sweep the halo set first and the inner blocks while its ghost blocks travel on
+    // the communication stream -- computeA's split (main.cpp:3035-3057) for the Krylov sweeps.  The halo set is a whole number
+    // of tiles when the host orders it in patches (grid.py); the inner blocks never read a ghost block, so the blocks arriving
+    // in place disturb nothing they touch.  Measured on a patch that is its own W and E neighbour (4096^2 cells, bytes through
+    // RCCL on one GPU; tools/gpu_calls/gpu_r04_call8.sh, profiles/r04_nrank_timeline_split.txt): the transfer disappears
+    // behind the inner sweep (13 / 29 us), but the two launches of a sweep take 127 / 247 us where one takes 123 / 234 (a
+    // short first launch on part of the chip, the transfer's kernel beside the second) and two more launch boundaries cost
+    // 12 us: 23.3 ms per step against 21.9 in one launch with the exchange behind it, 14.1 against 13.5 on a 4096 x 2048
+    // patch.  Off by default; what it would gain with a slower link than a copy on one GPU is what an N-GPU run has to show.
+    static const bool split_on = [] { const char *e = getenv("CUP2D_SWEEP_SPLIT"); return e && atoi(e) != 0; }();
+    const bool split = split_on && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       c->prof_sample = true;
@@ -1233,32 +1251,56 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       c->prof_sample = (k % 8 == 0) && k < max_iter;
       const int o = k & 1, n = o ^ 1;
       {
-        ProfScope prof(c, CUP2D_T_SWEEP_C);
         FusedArgs a = {};
         a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t;
         a.rev = zigzag;  // (A+B of iteration 0 and MODE 2 ascend: this one starts where they end, and ends where MODE 2 starts)
-        CUP2D_TRY(eab_sweep<3>(c, a, merge));
+        if (split) {
+          // N ranks, computeA's split (main.cpp:3035-3057) for the sweep: the halo set first, its t on the way to the
+          // neighbours while the inner blocks are swept; the second launch finishes the reduction of both
+          int gh = 0;
+          { ProfScope prof(c, CUP2D_T_SWEEP_C); CUP2D_TRY(eab_sweep<3>(c, a, 0, c->n_inner, nb - c->n_inner, 0, &gh)); }
+          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr, true));
+          else CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
+          { ProfScope prof(c, CUP2D_T_SWEEP_C); CUP2D_TRY(eab_sweep<3>(c, a, 2, 0, c->n_inner, gh, nullptr)); }
+        } else {
+          ProfScope prof(c, CUP2D_T_SWEEP_C);
+          CUP2D_TRY(eab_sweep<3>(c, a, merge));
+        }
       }
       if (merge == 2) {  // MODE 2 recomputes r' of the blocks around a tile: it needs t in the ghost blocks
-        if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr));
-        else if (gb) CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
+        if (!split) {
+          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr));
+          else if (gb) CUP2D_TRY(exchange_begin(c, c->d_t, 1, BS));
+        }
         CUP2D_TRY(finish_local(c, 5, 0, 5));
-        if (gb && !direct) CUP2D_TRY(exchange_end(c, c->d_t, 1, BS));
+        if (split && direct) CUP2D_TRY(comm_blocks_wait(c));
+        else if (gb && !direct) CUP2D_TRY(exchange_end(c, c->d_t, 1, BS));
       }
       int *const report = last_of_group ? &c->h_status[slot] : nullptr;
       {
-        ProfScope prof(c, CUP2D_T_SWEEP_EA);
         FusedArgs a = {};
         a.in0 = P[o]; a.in1 = N[o]; a.in2 = R[o]; a.w = c->d_rhat; a.vout = P[n]; a.yout = N[n];
         a.t = c->d_t; a.y0 = c->d_y; a.y1 = c->d_yopt; a.y2 = c->d_xopt; a.rout = R[n];
         a.host_status = merge == 1 ? report : nullptr;
-        CUP2D_TRY(eab_sweep<2>(c, a, merge));
+        if (split) {
+          int gh = 0;
+          { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 0, c->n_inner, nb - c->n_inner, 0, &gh)); }
+          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n], true));
+          else CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+          { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 2, 0, c->n_inner, gh, nullptr)); }
+        } else {
+          ProfScope prof(c, CUP2D_T_SWEEP_EA);
+          CUP2D_TRY(eab_sweep<2>(c, a, merge));
+        }
       }
       if (merge == 2) {
-        if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n]));
-        else if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+        if (!split) {
+          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n]));
+          else if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+        }
         CUP2D_TRY(finish_local(c, 2, 1, 4, report));
-        if (gb && !direct) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
+        if (split && direct) CUP2D_TRY(comm_blocks_wait(c));
+        else if (gb && !direct) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }

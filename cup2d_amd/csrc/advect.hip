@@ -262,7 +262,7 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
                   double coef, int first, int count) {
   if (count <= 0) return CUP2D_OK;
   const double afac = -dt * c->h, dfac = nu * dt;  // main.cpp:5446-5447
-  ProfScope prof(c, CUP2D_T_ADVECT_STAGE);
+  ProfScope prof(c, (mode == 1 && vold != vel) ? CUP2D_T_ADVECT_STAGE2 : CUP2D_T_ADVECT_STAGE);  // stage 2 reads its own old values: 48 B/cell
   const double2 *v = (const double2 *)vel, *vo = (const double2 *)vold;
   double2 *o = (double2 *)out;
   // groups (of 4 blocks) per workgroup; CUP2D_ADVECT_CHUNK=0 selects the persistent grid

@@ -1384,12 +1384,15 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     }
     c->have_last = true;
   }
-  if (c->h_sc->best_is_x0) {  // the initial guess is the answer: x = x0
-    if (x0_zero) CUP2D_TRY(launch_zero(c, x, n));
-  } else if (x0_zero) {
-    CUP2D_TRY(launch_precond(c, ybest, x, 0, nb));  // x = 0 + P_inv y_opt, written, not added
-  } else {
-    CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
+  {
+    ProfScope prof(c, CUP2D_T_FINAL_X);
+    if (c->h_sc->best_is_x0) {  // the initial guess is the answer: x = x0
+      if (x0_zero) CUP2D_TRY(launch_zero(c, x, n));
+    } else if (x0_zero) {
+      CUP2D_TRY(launch_precond(c, ybest, x, 0, nb));  // x = 0 + P_inv y_opt, written, not added
+    } else {
+      CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
+    }
   }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (iters) *iters = c->h_sc->iter;

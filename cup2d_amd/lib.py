@@ -14,7 +14,7 @@ WALL = -1
 (T_ADVECT_STAGE, T_POISSON_RHS, T_SWEEP_A, T_SWEEP_B, T_SWEEP_C, T_SWEEP_D, T_SWEEP_E, T_SCALARS, T_PROJECT,
  T_REDUCE, T_HALO, T_INIT_RESIDUAL) = range(12)
 TIMER_NAMES = ['advect_stage', 'poisson_rhs', 'sweep_A', 'sweep_B', 'sweep_C', 'sweep_D', 'sweep_E', 'scalars', 'project',
-               'reduce', 'halo', 'init_residual', 'smoother', 'sweep_EA']
+               'reduce', 'halo', 'init_residual', 'smoother', 'sweep_EA', 'advect_stage2', 'final_x']
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 WAIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)

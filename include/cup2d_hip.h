@@ -485,7 +485,10 @@ typedef enum {
   CUP2D_T_INIT_RESIDUAL = 11, /* r = b - A x0 + its reductions (once per solve) */
   CUP2D_T_SMOOTHER = 12,    /* weighted-Jacobi sweep / Poisson residual (k_smoother) */
   CUP2D_T_SWEEP_EA = 13,    /* sweep E + the next iteration's sweeps A, B in one launch (CUP2D_FUSED_FORM=eab) */
-  CUP2D_T_NTIMERS = 14
+  CUP2D_T_ADVECT_STAGE2 = 14, /* RK stage 2 of the fused WENO5 stage (stage 1 stays under CUP2D_T_ADVECT_STAGE when the two are told
+                                 apart: cup2d_advect_diffuse_stage with its own old values, 48 B/cell against 32) */
+  CUP2D_T_FINAL_X = 15,     /* the solve's last pass x = x0 + P_inv y (once per solve) */
+  CUP2D_T_NTIMERS = 16
 } cup2d_timer;
 int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);

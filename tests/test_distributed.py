@@ -44,14 +44,16 @@ def test_decomposed_step_matches_global_oracle_gpu(world, px, py, nbx, nby):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("px,py,share", [(1, 2, "5"), (2, 1, "5"), (1, 2, "0")])
-def test_decomposed_path_at_configs3_rank_size_gpu(px, py, share):
+@pytest.mark.parametrize("px,py,share,split", [(1, 2, "5", "0"), (2, 1, "5", "1"), (1, 2, "0", "0")])
+def test_decomposed_path_at_configs3_rank_size_gpu(px, py, share, split):
     """BASELINE.json configs[3]'s per-rank patch -- 4096 x 2048 cells = 512 x 256 blocks plus a ghost ring -- on two ranks
     sharing the GPU (dist_worker.run_gpu_big): every functor STRICT bit for bit (FAST to 2e-13) against the single context on
     the whole grid, eight iterations of the two-launch MERGE 2 solver = the five sweeps to 1e-10 of max|x|, one whole bench
     step.  (1, 2): the global grid is 4096^2; (2, 1): 8192 x 2048 cells, a rectangle whose Hilbert order is not the
-    square's.  share: CUP2D_EDGE_SHARE, the hand-over between sibling waves on (where the grid allows it) and off."""
-    launch("gpu_big", 2, px, py, 512, 256, 29741 + 2 * px + py + (7 if share == "0" else 0), timeout=850, CUP2D_EDGE_SHARE=share)
+    square's.  share: CUP2D_EDGE_SHARE, the hand-over between sibling waves on (where the grid allows it) and off.  split:
+    CUP2D_SWEEP_SPLIT, the sweeps as halo-set-first + inner launches with the ghost blocks travelling in between (opt-in)."""
+    launch("gpu_big", 2, px, py, 512, 256, 29741 + 2 * px + py + (7 if share == "0" else 0), timeout=850, CUP2D_EDGE_SHARE=share,
+           CUP2D_SWEEP_SPLIT=split)
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 5])

@@ -173,15 +173,35 @@ static int rccl_exchange(void *user, double *send, double *recv, int strip_doubl
 // cup2d_halo_plan numbers consecutively -- are received straight into the vectors' ghost regions: no second stream, no event,
 // no unpack kernel.  The send buffer is vector-major ([vector][strip][64 cells], a whole block in its own cell order) so that
 // what goes to one peer for one vector is one contiguous piece.
+// G (optional, krylov_fused.hip GhostRP): the same launch forms r' and p'' of the ghost blocks from what the rank holds of
+// them -- the elements behind the packed ones; nothing of it touches what is packed (nu'')
 __global__ __launch_bounds__(WG) void k_pack_blocks(const double *__restrict__ v0, const double *__restrict__ v1,
                                                    const double *__restrict__ v2, double *__restrict__ buf,
-                                                   const int32_t *__restrict__ blocks, int nstrips, int nv) {
+                                                   const int32_t *__restrict__ blocks, int nstrips, int nv, GhostRP G) {
   const size_t per = (size_t)nstrips * BC, total = per * nv;
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
-    const int v = (int)(i / per);
-    const size_t q = i - (size_t)v * per;
-    const double *f = v == 0 ? v0 : (v == 1 ? v1 : v2);
-    buf[i] = f[(size_t)blocks[q >> 6] * BC + (q & 63)];
+  const bool ghosts = G.count > 0 && G.sc->status == 0;
+  const size_t all = total + (ghosts ? G.count : 0);
+  double malpha = 0, c1 = 0, beta = 0;
+  bool restart = false;
+  if (ghosts) { malpha = -G.sc->alpha; c1 = -G.sc->omega; beta = G.sc->beta; restart = G.sc->restart_flag != 0; }
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < all; i += (size_t)gridDim.x * WG) {
+    if (i < total) {
+      const int v = (int)(i / per);
+      const size_t q = i - (size_t)v * per;
+      const double *f = v == 0 ? v0 : (v == 1 ? v1 : v2);
+      buf[i] = f[(size_t)blocks[q >> 6] * BC + (q & 63)];
+    } else {  // form_v of krylov_edge.h MODE 2, operation for operation
+      const size_t k = G.first + (i - total);
+      const double sv = G.r[k] + malpha * G.nu[k];
+      const double rn = sv + c1 * G.t[k];
+      G.rout[k] = rn;
+      if (restart) G.pout[k] = rn;
+      else {
+        double v = G.p[k] + c1 * G.nu[k];
+        v = v * beta;
+        G.pout[k] = v + rn;
+      }
+    }
   }
 }
 bool comm_blocks_direct(const cup2d_ctx *c) {
@@ -194,20 +214,21 @@ int comm_blocks_wait(cup2d_ctx *c) {
   CUP2D_HIP_CHECK(hipStreamWaitEvent(c->stream, rc->ev_arrived, 0));
   return CUP2D_OK;
 }
-int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream) {
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream, const GhostRP *ghosts) {
   RcclComm *rc = c->rccl;
   rc->n_exchange++;
   if (rc->peer.empty() || nv < 1 || nv > 3) return CUP2D_OK;
   hipStream_t xs = on_comm_stream ? rc->comm_stream : c->stream;
   double *vecs[3] = {v0, v1, v2};
   const int ns = c->plan.nsend;
-  if (ns > 0) {
-    const size_t total = (size_t)ns * BC * nv;
+  GhostRP G = ghosts ? *ghosts : GhostRP();
+  if (ns > 0 || G.count > 0) {
+    const size_t total = (size_t)ns * BC * nv + G.count;
     int grid = (int)((total + WG - 1) / WG);
     if (grid > c->grid) grid = c->grid;
     ProfScope prof(c, CUP2D_T_HALO);
     hipLaunchKernelGGL(k_pack_blocks, dim3(grid), dim3(WG), 0, c->stream, (const double *)v0, (const double *)v1, (const double *)v2,
-                       rc->d_send, (const int32_t *)c->plan.d_send_block, ns, nv);
+                       rc->d_send, (const int32_t *)c->plan.d_send_block, ns, nv, G);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
   const auto fail = [&](ncclResult_t r, const char *what) {

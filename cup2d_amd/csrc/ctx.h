@@ -369,7 +369,16 @@ int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);
 bool comm_blocks_direct(const cup2d_ctx *c);
 // on_comm_stream: the transfer runs on the communication stream behind the pack (the caller sweeps on meanwhile) and
 // comm_blocks_wait makes the compute stream wait for its arrival
-int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream = false);
+// r' and p'' of the ghost blocks formed by the rank that holds them (krylov_fused.hip k_ghost_rp); passed to
+// comm_exchange_blocks, the pack launch does it on its way
+struct GhostRP {
+  const double *p = nullptr, *nu = nullptr, *r = nullptr, *t = nullptr;
+  double *rout = nullptr, *pout = nullptr;
+  const KrylovScalars *sc = nullptr;
+  size_t first = 0, count = 0;
+};
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream = false,
+                         const GhostRP *ghosts = nullptr);
 int comm_blocks_wait(cup2d_ctx *c);
 int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
 int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);

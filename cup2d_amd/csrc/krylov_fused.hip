@@ -933,11 +933,17 @@ static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
 // full | edge selects the three-launch organisation (k_fused | k_edge MODE 0 / 1), eab (or unset) this one.
 // N ranks (merge 2): in the ghost-block form -- whole boundary blocks of t behind the reduction of C+D, of r', p'', nu'' in one
 // message behind the reduction of the other launch; two reductions over the ranks per iteration instead of three.
+static bool ghost_local_enabled() {
+  static const bool on = [] { const char *e = getenv("CUP2D_GHOST_LOCAL"); return !e || atoi(e) != 0; }();
+  return on;
+}
 static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring, bool ghost_blocks) {
   const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
   const bool ghosts = c->nghost > 0 && c->exchange;
-  // (N ranks: r', p'', nu'' travel as three whole blocks per strip -- the caller's buffers must be that wide, cup2d_set_comm_strip_capacity)
-  const bool wide = !ghosts || c->strip_cap >= 3 * BC;
+  // (N ranks: the widest message is two whole blocks per strip -- nu' and p' behind the A+B of iteration 0 -- when r' and p'' of
+  // the ghost blocks are formed locally (k_ghost_rp, the default), three with CUP2D_GHOST_LOCAL=0: the caller's buffers must
+  // be that wide, cup2d_set_comm_strip_capacity)
+  const bool wide = !ghosts || c->strip_cap >= (ghost_local_enabled() ? 2 : 3) * BC;
   return on && (merge == 1 || merge == 2) && !c->custom_Pinv && !c->mat.active && (!ghosts || (merge == 2 && ghost_blocks)) && dbg == 0 &&
          !stored_ring && wide;
 }
@@ -951,6 +957,43 @@ static int edge_share_mode(cup2d_ctx *c, int mode) {
   static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
   return ((mask >> mode) & 1) && edge_share_of(c);
 }
+// N ranks, two-launch organisation: of the three vectors the launch that holds sweep E and the next A+B leaves behind -- r', p'',
+// nu'' -- only nu'' = A P_inv p'' is not a function of the same cells.  A rank holds p', nu', r and t of its ghost blocks (the
+// ring entries of that very launch), so it forms r' = (r - alpha nu') - omega t and p'' = beta' (p' - omega nu') + r' of the
+// ghost blocks ITSELF, with the scalars and the operations the owner used (form_v of krylov_edge.h MODE 2, operation for
+// operation: the same bits), and one vector travels instead of three (a third of the bytes on the link: 262 KB instead of
+// 786 KB per neighbour on a 4096-cell side).  Runs behind the launch and BEFORE its reduction is finished (stage 4 replaces
+// alpha).  CUP2D_GHOST_LOCAL=0: the three vectors travel (the results are the same bit for bit, tests/test_comm.py).
+__global__ __launch_bounds__(WG) void k_ghost_rp(const double *__restrict__ p, const double *__restrict__ nu, const double *__restrict__ r,
+                                                 const double *__restrict__ t, double *__restrict__ rout, double *__restrict__ pout,
+                                                 const KrylovScalars *sc, size_t first, size_t count) {
+  if (sc->status != 0) return;
+  const double malpha = -sc->alpha, c1 = -sc->omega, beta = sc->beta;
+  const bool restart = sc->restart_flag != 0;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < count; i += (size_t)gridDim.x * WG) {
+    const size_t k = first + i;
+    const double sv = r[k] + malpha * nu[k];
+    const double rn = sv + c1 * t[k];
+    rout[k] = rn;
+    if (restart) pout[k] = rn;
+    else {
+      double v = p[k] + c1 * nu[k];
+      v = v * beta;
+      pout[k] = v + rn;
+    }
+  }
+}
+static int ghost_rp(cup2d_ctx *c, const double *p, const double *nu, const double *r, const double *t, double *rout, double *pout) {
+  const size_t first = (size_t)c->nblocks * BC, count = (size_t)c->nghost * BC;
+  if (count == 0) return CUP2D_OK;
+  int grid = (int)((count + WG - 1) / WG);
+  if (grid > c->grid) grid = c->grid;
+  ProfScope prof(c, CUP2D_T_HALO);
+  hipLaunchKernelGGL(k_ghost_rp, dim3(grid), dim3(WG), 0, c->stream, p, nu, r, t, rout, pout, (const KrylovScalars *)c->d_sc, first, count);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // blocks [first, first + count) (a multiple of 16 blocks in front of it: the tiling is the whole range's); merge 0: the launch
 // leaves its partials at [poff, poff + grid) and a later launch of the same sweep finishes over all of them.  *G: its grid.
 template <int MODE>
@@ -1228,6 +1271,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // patch.  Off by default; what it would gain with a slower link than a copy on one GPU is what an N-GPU run has to show.
     static const bool split_on = [] { const char *e = getenv("CUP2D_SWEEP_SPLIT"); return e && atoi(e) != 0; }();
     const bool split = split_on && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
+    const bool ghost_local = ghost_local_enabled() && merge == 2 && gb;  // r' and p'' of the ghost blocks formed here, nu'' travels (k_ghost_rp)
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       c->prof_sample = true;
@@ -1285,7 +1329,14 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         if (split) {
           int gh = 0;
           { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 0, c->n_inner, nb - c->n_inner, 0, &gh)); }
-          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n], true));
+          if (ghost_local) {
+            const GhostRP G = {P[o], N[o], R[o], c->d_t, R[n], P[n], c->d_sc, (size_t)nb * BC, (size_t)c->nghost * BC};
+            if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, N[n], nullptr, nullptr, true, &G));
+            else {
+              CUP2D_TRY(ghost_rp(c, P[o], N[o], R[o], c->d_t, R[n], P[n]));
+              CUP2D_TRY(exchange_begin(c, N[n], 1, BS));
+            }
+          } else if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n], true));
           else CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
           { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 2, 0, c->n_inner, gh, nullptr)); }
         } else {
@@ -1294,13 +1345,23 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         }
       }
       if (merge == 2) {
-        if (!split) {
-          if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n]));
-          else if (gb) CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
+        if (!split && gb) {
+          if (ghost_local) {
+            const GhostRP G = {P[o], N[o], R[o], c->d_t, R[n], P[n], c->d_sc, (size_t)nb * BC, (size_t)c->nghost * BC};
+            if (direct) CUP2D_TRY(comm_exchange_blocks(c, 1, N[n], nullptr, nullptr, false, &G));
+            else {
+              CUP2D_TRY(ghost_rp(c, P[o], N[o], R[o], c->d_t, R[n], P[n]));
+              CUP2D_TRY(exchange_begin(c, N[n], 1, BS));
+            }
+          } else if (direct) CUP2D_TRY(comm_exchange_blocks(c, 3, R[n], P[n], N[n]));
+          else CUP2D_TRY(exchange_begin_blocks3(c, R[n], P[n], N[n]));
         }
         CUP2D_TRY(finish_local(c, 2, 1, 4, report));
         if (split && direct) CUP2D_TRY(comm_blocks_wait(c));
-        else if (gb && !direct) CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
+        else if (gb && !direct) {
+          if (ghost_local) CUP2D_TRY(exchange_end(c, N[n], 1, BS));
+          else CUP2D_TRY(exchange_end_blocks3(c, R[n], P[n], N[n]));
+        }
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }

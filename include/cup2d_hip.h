@@ -400,9 +400,11 @@ typedef int (*cup2d_allreduce_fn)(void *user, double *device_buf, int count, int
 int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wait, cup2d_allreduce_fn allreduce,
                    void *user, double *device_send_buffer, double *device_recv_buffer, double *device_reduce_buffer);
 /* What the caller's buffers really hold, in doubles per strip.  cup2d_set_comm alone promises CUP2D_MIN_STRIP_DOUBLES = 128
- * (the contract of the first two rounds: whole blocks of two Krylov vectors in one message); the two-launch organisation of
- * the solver on N ranks sends whole blocks of THREE vectors in one message (192 doubles per strip) and is chosen only when
- * the capacity says the buffers take it -- otherwise the three-launch form runs (128 doubles per strip at most).  Call it
+ * (the contract of the first two rounds: whole blocks of two Krylov vectors in one message), which is what every
+ * organisation of the solver needs by default (the two-launch organisation sends nu' and p' in one message once per solve and
+ * single vectors afterwards: r' and p'' of the ghost blocks are formed by the receiving rank); with CUP2D_GHOST_LOCAL=0 it sends
+ * whole blocks of THREE vectors in one message (192 doubles per strip) and is then chosen only when the capacity says the
+ * buffers take it -- otherwise the three-launch form runs.  Call it
  * after cup2d_set_comm; values below CUP2D_MIN_STRIP_DOUBLES are an error.  The in-library communicator (cup2d_comm_init)
  * owns its buffers and sets CUP2D_MAX_STRIP_DOUBLES itself. */
 #define CUP2D_MIN_STRIP_DOUBLES 128

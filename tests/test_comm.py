@@ -211,22 +211,28 @@ def test_ghost_blocks_received_in_place_equal_the_generic_exchange(gpu_lib):
     """The Krylov ghost-block exchanges of the in-library communicator run on the compute stream and land in the vectors' ghost
     regions directly (comm.hip comm_exchange_blocks; default) -- against the generic path (pack, second stream, receive buffer,
     unpack; CUP2D_COMM_DIRECT=0) on a patch that is its own W and E neighbour, bytes through ncclSend / ncclRecv both ways: six
-    iterations of the two-launch MERGE 2 solver leave the same last iterate bit for bit, a converged solve the same counts."""
+    iterations of the two-launch MERGE 2 solver leave the same last iterate bit for bit, a converged solve the same counts.
+    Likewise r' and p'' of the ghost blocks formed by the receiving rank (k_ghost_rp; default) against the three vectors
+    travelling (CUP2D_GHOST_LOCAL=0): the same bits."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for direct in ("1", "0"):
-        env = dict(os.environ, CUP2D_COMM_DIRECT=direct, NCCL_SOCKET_IFNAME="lo")
+    # (direct, local): the default; the generic transport path; three vectors travelling instead of r' and p'' of the ghost
+    # blocks being formed by the receiver (k_ghost_rp)
+    for key in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        env = dict(os.environ, CUP2D_COMM_DIRECT=key[0], CUP2D_GHOST_LOCAL=key[1], NCCL_SOCKET_IFNAME="lo")
         r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD % (root, root)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")]
         assert r.returncode == 0 and lines, r.stdout.decode()[-3000:]
-        res[direct] = json.loads(lines[0][7:])
-    for k in res["1"]:
-        a, b = res["1"][k], res["0"][k]
-        assert a["form"] == b["form"] == ["eab", 2, a["form"][2]] and a["iters"] == b["iters"] == 6, (a, b)
-        assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (k, a, b)
-        assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"] <= 1e-8, (a, b)
-        assert a["exchanges"] == b["exchanges"] > 12
+        res[key] = json.loads(lines[0][7:])
+    ref = res[("1", "1")]
+    for key, other in res.items():
+        for k in ref:
+            a, b = ref[k], other[k]
+            assert a["form"] == b["form"] == ["eab", 2, a["form"][2]] and a["iters"] == b["iters"] == 6, (key, a, b)
+            assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (key, k, a, b)
+            assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"] <= 1e-8, (key, a, b)
+            assert a["exchanges"] == b["exchanges"] > 12

@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--profile-tag", default="", help="profiles/<tag>_pmc_traffic.json supplies roofline.traffic (default: the newest "
                                                       "rNN tag without a suffix)")
     ap.add_argument("--cpu-functor-n", type=int, default=4096, help="grid of the reference-functor CPU baseline (the headline size)")
+    ap.add_argument("--no-nrank-proxy", action="store_true", help="skip the N-rank-path leg (a self-periodic patch through RCCL on this GPU)")
     ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
     ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
     return ap.parse_args()
@@ -279,6 +280,43 @@ class Runner:
 
     def close(self):
         self.sim.close()
+
+
+def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
+    import ctypes
+    from cup2d_amd import lib as L
+    from cup2d_amd.distributed import self_periodic_simulation
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    s, g = self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=device)
+    with s:
+        s.set_math(args.math == "strict")
+        s.set_solver(fused=args.solver == "fused", finish_in_kernel=args.finish == "kernel")
+        nxp, nyp = nbx * 8, nby * 8
+        hh = 1.0 / max(nxp, nyp)
+        X, Y = np.meshgrid((np.arange(nxp) + 0.5) * hh, (np.arange(nyp) + 0.5) * hh, indexing="xy")
+        vel0 = np.stack([np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y), -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)], -1)
+        s.vel = vel0 + 1e-3 * np.random.default_rng(20250117).uniform(-1.0, 1.0, vel0.shape)
+        del X, Y, vel0
+        for _ in range(2):
+            s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+        s.synchronize()
+        nst = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(nst):
+            r = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+        s.synchronize()
+        el = (time.perf_counter() - t0) / nst
+        form = s.last_solver_form()
+        n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+        L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "comm_stats")
+        L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
+    plain = plain_elapsed / plain_steps
+    return {"what": "the N-rank code path of the step on one GPU: a %dx%d-block patch that is its own W and E neighbour (ghost blocks on "
+                    "both x sides, bytes through ncclSend / ncclRecv to self, all-gather reductions, MERGE 2 kernels)" % (nbx, nby),
+            "ms_per_step": round(el * 1e3, 3), "value": round(nbx * nby * 64 / el / 1e6, 2), "unit": "Mcell-updates/s",
+            "plain_context_ms_per_step": round(plain * 1e3, 3), "ratio_to_plain": round(el / plain, 4), "iters": r["iters"],
+            "solver_form": list(form), "ghost_blocks": g.nghost, "halo_set_patch": g.halo_tile, "n_inner": g.n_inner,
+            "exchanges": ex.value, "allgathers": ag.value, "timeline": "profiles/r04_nrank_timeline.txt"}
 
 
 def amr_leg(args, device):
@@ -736,6 +774,20 @@ def main():
             amr = {"error": str(e)[:200]}
         beat("amr leg done")
 
+    # The N-rank code path of the same step on THIS one GPU (N = 1 only): a patch that is its own W and E neighbour through the
+    # in-library communicator -- ghost blocks, pack kernels, whole ghost blocks of the Krylov vectors through ncclSend /
+    # ncclRecv, the MERGE 2 kernels, an all-gather + one-wave kernel per reduction, one host look per iteration.  What a rank
+    # of an N-rank run does except waiting for another GPU: its cost next to the plain context above is what the library
+    # adds per rank (the driver's N > 1 runs add the links).
+    nrank_proxy = None
+    if rank == 0 and world == 1 and dist is None and not args.no_nrank_proxy:
+        beat("N-rank path on one GPU")
+        try:
+            nrank_proxy = nrank_proxy_leg(args, local_rank, nx // 8, ny // 8, elapsed_plain or elapsed, args.steps)
+        except Exception as e:  # informative; never fail the bench on it
+            nrank_proxy = {"error": str(e)[:200]}
+        beat("N-rank path done")
+
     if rank == 0:
         out = {
             "metric": "Mcell-updates/sec (advect-diffuse+Poisson sweep) at 4096^2",
@@ -755,7 +807,7 @@ def main():
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "gpu_ms_per_step": gpu_split,
             "kernels": timers, "roofline_extra_sampled_steps_outside_timed_region": extra_sampled_steps,
-            "cpu_baseline": cpu, "amr_configs4": amr,
+            "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy,
         }
     if second is None or world == 1:
         run.close()

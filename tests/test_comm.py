@@ -41,32 +41,9 @@ def _hip():
 
 
 def _self_periodic_sim(nbx, nby):
-    """one rank that is its own W and E neighbour: ghost blocks on both x sides, each filled from the opposite edge"""
-    import cup2d_amd
-    g = BlockGrid(nbx, nby, ghost_sides=(True, True, False, False))
-    s = cup2d_amd.Simulation(nbx, nby, grid=g, h=1.0 / (8 * nbx))
-    sb, sf, rb, rf = [], [], [], []
-    for side in (0, 1):  # W strips then E strips in the send list; W ghosts then E ghosts in the receive list
-        for pos in range(nby):
-            sb.append(int(g.index_of[pos, 0 if side == 0 else nbx - 1]))
-            sf.append(side)
-            rb.append(int(g._ghost_id[(side, pos)]))
-            rf.append(1 - side)
-    arr = [np.asarray(a, dtype=np.int32) for a in (sb, sf, rb, rf)]
-    vp = ctypes.c_void_p
-    L.check(s.L.cup2d_halo_plan(s.ctx, len(sb), arr[0].ctypes.data_as(vp), arr[1].ctypes.data_as(vp), len(rb),
-                                arr[2].ctypes.data_as(vp), arr[3].ctypes.data_as(vp)), "halo_plan")
-    ids = ctypes.create_string_buffer(L.COMM_ID_BYTES)
-    L.check(s.L.cup2d_comm_unique_id(ids), "comm_unique_id")
-    # receive i pairs with send i (RCCL matches the operations of a pair of ranks in issue order): the W ghosts
-    # (receive offset 0) take the E strips (send offset nby), the E ghosts the W strips
-    peer = np.zeros(2, dtype=np.int32)
-    soff = np.asarray([nby, 0], dtype=np.int32)
-    roff = np.asarray([0, nby], dtype=np.int32)
-    cnt = np.asarray([nby, nby], dtype=np.int32)
-    L.check(s.L.cup2d_comm_init(s.ctx, 1, 0, ids, 2, peer.ctypes.data_as(vp), soff.ctypes.data_as(vp), roff.ctypes.data_as(vp),
-                                cnt.ctypes.data_as(vp), None), "comm_init")
-    return s, g
+    """one rank that is its own W and E neighbour (cup2d_amd.distributed.self_periodic_simulation)"""
+    from cup2d_amd.distributed import self_periodic_simulation
+    return self_periodic_simulation(nbx, nby)
 
 
 @pytest.mark.gpu

@@ -19,3 +19,5 @@ try:
 except Exception as e:
     print("bench line unreadable:", e)
 PY
+# what kind of box this was (the two timing modes are per box: DESIGN.md section 6)
+rocm-smi --showclocks --showpower --showmaxpower --showmemorypartition --showcomputepartition 2>&1 | grep -E "fclk|mclk|sclk|Power|Partition" | head -8

@@ -812,7 +812,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
   }();
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
-  for (int k = 0; k <= max_iter + AHEAD; k++) {
+  for (int k = 0; k < max_iter; k++) {  // (exactly max_iter: iterations behind the cap could only return at once)
     const int slot = k % AHEAD;
     if (k >= AHEAD) {
       CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));

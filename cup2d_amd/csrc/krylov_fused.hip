@@ -1285,7 +1285,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       CUP2D_TRY(finish_local(c, 1, 0, 1));
       if (gb && !direct) CUP2D_TRY(exchange_end_blocks2(c, N[0], P[0]));
     }
-    for (int k = 0; k <= max_iter + AHEAD_G * GROUP; k++) {
+    // (exactly max_iter iterations are enqueued: the scalars of the last one set the status to 'cap reached', and what the
+    // host would enqueue behind it could only return at once -- on N ranks with its exchanges and all-gathers still issued)
+    for (int k = 0; k < max_iter; k++) {
       const int grp = k / GROUP, slot = grp % AHEAD_G;
       const bool first_of_group = k % GROUP == 0, last_of_group = k % GROUP == GROUP - 1;
       if (first_of_group && grp >= AHEAD_G) {
@@ -1366,7 +1368,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }
   }
-  for (int k = 0; !eab && k <= max_iter + AHEAD_G * GROUP; k++) {
+  for (int k = 0; !eab && k < max_iter; k++) {
     const int grp = k / GROUP, slot = grp % AHEAD_G;
     const bool first_of_group = k % GROUP == 0, last_of_group = k % GROUP == GROUP - 1;
     if (first_of_group && grp >= AHEAD_G) {

@@ -28,7 +28,7 @@
 // fused_reduce_store)
 
 #ifndef CUP2D_EDGE_NXB
-#define CUP2D_EDGE_NXB 2
+#define CUP2D_EDGE_NXB 3
 #endif
 constexpr int NXB = CUP2D_EDGE_NXB;  // export buffers per wave: a wave may run NXB - 1 rounds ahead of its slowest sibling
 constexpr int EXP_SLOTS = 16;  // perimeter sides a tile may export (host check edge_share_ok: every tile has <= 16)
@@ -200,14 +200,27 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // tiles of 16 blocks; the 8 waves of a workgroup take 8 consecutive tiles per round, contiguous ranges per XCD
   const int ntiles = (count + TB - 1) / TB;
   int t_begin, t_end, t_stride;
+  // (the exports are the hand-over's: the host has checked that the grid allows them, edge_share_ok; MODE 2 / 3 only -- the
+  // A+B of iteration 0 runs once per solve and its registers are full)
+  const bool prev_on = (MODE >= 2) && A.prev == 1;
+  const bool contiguous = (MODE >= 2) && A.prev != 0;  // (A.prev == 2: the contiguous walk alone -- what the order costs by itself)
   {
     const int G = gridDim.x, w = blockIdx.x;
     if (G >= 8 && (G % 8) == 0) {
       const int xcd = w & 7, slot = w >> 3, per = G >> 3;
       const long long lo = (long long)ntiles * xcd / 8, hi = (long long)ntiles * (xcd + 1) / 8;
-      t_begin = (int)lo + slot * FWAVES + wave;
-      t_end = (int)hi;
-      t_stride = per * FWAVES;
+      if (contiguous) {
+        // Previous round: the workgroup owns a CONTIGUOUS piece of its XCD's range and walks it round by round, so that two
+        // consecutive rounds are neighbouring patches of the Hilbert order
+        const long long nr = (hi - lo + FWAVES - 1) / FWAVES, r0 = nr * slot / per, r1 = nr * (slot + 1) / per;
+        t_begin = (int)(lo + r0 * FWAVES) + wave;
+        t_end = (int)(lo + r1 * FWAVES < hi ? lo + r1 * FWAVES : hi);
+        t_stride = FWAVES;
+      } else {
+        t_begin = (int)lo + slot * FWAVES + wave;
+        t_end = (int)hi;
+        t_stride = per * FWAVES;
+      }
     } else {
       t_begin = w * FWAVES + wave;
       t_end = ntiles;
@@ -235,7 +248,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     int is_ring, pad;                       // ... of which the ones to recompute (no tail padding: copies stay in registers)
   };
   // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the previous tile's)
-  const auto classify = [&](int t, int nb) -> Tile {
+  // share: bit 0 = edges of the siblings of the SAME round are taken from their exports (a wait per sibling), bit 1 = ... of the
+  // workgroup's PREVIOUS round (tp0 = its first tile, -1: none; published long ago: no wait to speak of)
+  const bool share_now = (share & 1) != 0;
+  const auto classify = [&](int t, int nb, int tp0) -> Tile {
     Tile T;
     T.b0 = first + t * TB;
     T.nvalid = min(TB, last - T.b0);
@@ -243,11 +259,12 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     const bool outside = si < T.nvalid && nb >= 0 && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     // a sibling: another tile this workgroup holds in the same round (tiles t - wave .. t - wave + 7 below t_end)
     const int nt = (nb - first) / TB, t0 = t - wave;
-    const bool sibling = share != 0 && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
+    const bool sibling = share_now && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
+    const bool prevsib = prev_on && tp0 >= 0 && outside && nb >= first && nb < last && nt >= tp0 && nt < tp0 + FWAVES && nt < t_end;
     T.sib = sibling ? nt - t0 : -1;
     T.pmask = __ballot(outside);
-    T.is_ring = outside && !sibling;
-    T.pad = 0;
+    T.is_ring = outside && !sibling && !prevsib;
+    T.pad = prevsib ? nt - tp0 : -1;  // the wave of the previous round that exported this slot's edge
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (KNOCK & 6) ? 0 : __popcll(rmask);
     T.npass = (T.nring + TB - 1) / TB;
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   Tile T;
   int j = tile_at(0) < t_end ? 0 : 1;
   if (tile_at(j) < t_end) {
-    T = classify(tile_at(j), load_nb(tile_at(j)));
+    T = classify(tile_at(j), load_nb(tile_at(j)), -1);
     issue_ring(Qa, T, 0, 0);  // (always: a batch set that is assigned on SOME paths only is live around the whole loop)
     issue_ring(Qb, T, 0, 1);
   }
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     // this tile's ring list is dead: the NEXT tile is classified into it (past the wave's last tile: this tile once more --
     // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
-    N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb);
+    N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb, more ? t - wave : -1);
     nb_next = load_nb(tile_at(round + 2));
     if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
     // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
@@ -455,10 +472,12 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
       // this buffer held round - NXB: a sibling has read it by the END of that round of its own, i.e. once it has published
-      // the round after it
-      if (round >= NXB) {
+      // the round after it.  Previous round: a sibling in round r also reads the exports of round r - 1, so a buffer may be
+      // overwritten only when every sibling has published the round BEHIND the one that read it last (one round later)
+      const int need = prev_on ? round - NXB + 3 : round - NXB + 2;
+      if (need > 0) {
         for (int u = 0; u < FWAVES; u++)
-          if (u != wave) edge_wait(pub, u, round - NXB + 2, fault);
+          if (u != wave) edge_wait(pub, u, need, fault);
       }
       if (mask_bit(T.pmask, opaque(lane))) {
         const int slot = bits_below_lane(T.pmask);
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + 8 * sside + q];
     }
     // ---- ghost edges a sibling wave exported ----
-    if (share && !(KNOCK & 4)) {
+    if (share_now && !(KNOCK & 4)) {
       for (int u = 0; u < FWAVES; u++) {
         const bool mine = T.sib == u;
         if (__ballot(mine) == 0ull) continue;
@@ -490,6 +509,24 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           const int slot = min((int)__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);  // (int: min(unsigned, int) resolves to the double overload)
 #pragma unroll
           for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[par][slot * BS + q];
+        }
+      }
+    }
+    // ---- ... or exported in the workgroup's previous round (published at least a tile's work ago) ----
+    if (prev_on && !(KNOCK & 4)) {
+      const int ppar = (round + NXB - 1) % NXB;
+      const int pb0 = first + tile_at(round - 1 < 0 ? 0 : round - 1) * TB - wave * TB;  // first block of the previous round's first tile
+      for (int u = 0; u < FWAVES; u++) {
+        const bool mine = T.pad == u;
+        if (__ballot(mine) == 0ull) continue;
+        edge_wait(pub, u, round, fault);
+        if (mine) {
+          const EdgeLds &O = LL[u];
+          const unsigned long long m = O.xmask[ppar];
+          const int bit = (T.nb - (pb0 + u * TB)) * 4 + (ss ^ 1);
+          const int slot = min((int)__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);
+#pragma unroll
+          for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[ppar][slot * BS + q];
         }
       }
     }

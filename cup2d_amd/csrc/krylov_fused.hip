@@ -243,6 +243,8 @@ struct FusedArgs {
   double *y0, *y1, *y2, *rout;
   int *host_status;
   int rev;  // k_edge: the tiles in descending order (krylov_edge.h "Direction")
+  int prev; // k_edge: a workgroup walks CONSECUTIVE rounds and takes the z edges of the side two consecutive 16 x 8 patches share
+            // from the exports of its previous round (krylov_edge.h "Previous round")
 };
 
 // one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)
@@ -953,9 +955,14 @@ static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has 
 }
 // sharing between sibling waves per kind of sweep (it pays where the ring is four vectors wide, MODE 2; it costs the short
 // C+D sweep more in waiting than it saves): CUP2D_EDGE_SHARE = bit mask, bit MODE; default 0b0101 (A+B and MODE 2)
+// ... and the edges of the side two CONSECUTIVE rounds of a workgroup share taken from the previous round's exports (no wait;
+// the workgroup then walks a contiguous piece of the tiles): CUP2D_EDGE_PREV = bit mask by MODE, default 0 (experiment)
+// returns bit 0: same round, bit 1: previous round
 static int edge_share_mode(cup2d_ctx *c, int mode) {
   static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
-  return ((mask >> mode) & 1) && edge_share_of(c);
+  static const int pmask = [] { const char *e = getenv("CUP2D_EDGE_PREV"); return e ? atoi(e) : 0; }();
+  if (!edge_share_of(c)) return 0;
+  return ((mask >> mode) & 1) | (((pmask >> mode) & 1) << 1);
 }
 // N ranks, two-launch organisation: of the three vectors the launch that holds sweep E and the next A+B leaves behind -- r', p'',
 // nu'' -- only nu'' = A P_inv p'' is not a function of the same cells.  A rank holds p', nu', r and t of its ghost blocks (the
@@ -999,9 +1006,13 @@ static int ghost_rp(cup2d_ctx *c, const double *p, const double *nu, const doubl
 template <int MODE>
 static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int count, int poff, int *G) {
   const int g = fused_grid(c, count);
+  const int share = edge_share_mode(c, MODE);
+  FusedArgs a2 = a;
+  static const int wmask = [] { const char *e = getenv("CUP2D_EDGE_WALK"); return e ? atoi(e) : 0; }();  // experiment: the contiguous walk alone
+  a2.prev = ((share >> 1) & 1) ? 1 : (((wmask >> MODE) & 1) ? 2 : 0);
   const auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, first, count,
-                       poff, edge_share_mode(c, MODE), c->d_red, c->d_ticket, c->d_fault);
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, first, count,
+                       poff, share, c->d_red, c->d_ticket, c->d_fault);
   };
   if (merge == 1) go(k_edge<MODE, 1>);
   else if (merge == 2) go(k_edge<MODE, 2>);
@@ -1251,8 +1262,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     c->last_form = eab ? CUP2D_FORM_EAB : edge ? CUP2D_FORM_EDGE : CUP2D_FORM_FULL;
     c->last_merge = merge;
     c->last_handover = 0;
-    if (eab) c->last_handover = (edge_share_mode(c, 0) ? 1 : 0) | (edge_share_mode(c, 2) ? 4 : 0) | (edge_share_mode(c, 3) ? 8 : 0);
-    else if (edge) c->last_handover = (edge_share_mode(c, 0) ? 1 : 0) | (edge_share_mode(c, 1) ? 2 : 0);
+    if (eab) c->last_handover = ((edge_share_mode(c, 0) & 1) ? 1 : 0) | ((edge_share_mode(c, 2) & 1) ? 4 : 0) | ((edge_share_mode(c, 3) & 1) ? 8 : 0);
+    else if (edge) c->last_handover = ((edge_share_mode(c, 0) & 1) ? 1 : 0) | ((edge_share_mode(c, 1) & 1) ? 2 : 0);
   }
   if (eab) {
     // A+B of iteration 0, then per iteration TWO launches: C+D with the sums the next beginning needs (MODE 3), and sweep E

@@ -179,21 +179,23 @@ print("RESULT " + json.dumps(out))
 '''
 
 
-@pytest.mark.parametrize("form,share", [("eab", "5"), ("eab", "15"), ("eab", "0"), ("edge", "15"), ("edge", "0"), ("full", "0")])
-def test_forms_of_the_fused_sweeps(gpu_lib, form, share):
+@pytest.mark.parametrize("form,share,prev", [("eab", "5", "0"), ("eab", "15", "0"), ("eab", "0", "0"), ("edge", "15", "0"), ("edge", "0", "0"),
+                                             ("full", "0", "0"), ("eab", "5", "12"), ("eab", "15", "8")])
+def test_forms_of_the_fused_sweeps(gpu_lib, form, share, prev):
     """The organisations of the tile-fused solver on one GPU (CUP2D_FUSED_FORM; read once per process, hence the child):
     eab (the default: csrc/krylov_edge.h MODE 2 / 3 -- sweep E and the next A+B in one launch, rho' and the restart decision
     from the sums of C+D), edge (A P_inv v = v + ghost edges of z in three launches), full (k_fused).  share: per kind of
     sweep, the z edges of sibling tiles handed over through LDS or every perimeter edge recomputed.  Four iterations at zero
     tolerance equal the five sweeps to round-off on every block order (grids whose tiles have more than 16 perimeter sides
     fall back to recomputation by themselves), and a converged solve satisfies the reference's criterion against the oracle's
-    operator."""
+    operator.  prev: CUP2D_EDGE_PREV (opt-in, measured slower): the workgroups walk consecutive rounds and take the edges of the
+    side two consecutive patches share from the previous round's exports (bit mask by MODE: 8 = C+D', 4 = E+A+B)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CUP2D_FUSED_FORM=form, CUP2D_EDGE_SHARE=share)
+    env = dict(os.environ, CUP2D_FUSED_FORM=form, CUP2D_EDGE_SHARE=share, CUP2D_EDGE_PREV=prev)
     r = subprocess.run([sys.executable, "-c", _EDGE_CHILD % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     txt = r.stdout.decode()
     lines = [l for l in txt.splitlines() if l.startswith("RESULT ")]

@@ -154,7 +154,11 @@ from cup2d_amd.grid import BlockGrid
 from oracle import oracle as O
 out = {}
 rng = np.random.default_rng(5)
-for order, nbx, nby in (("hilbert", 8, 8), ("hilbert", 32, 32), ("rowmajor", 5, 3), ("hilbert", 6, 5), ("hilbert", 64, 32), ("rowmajor", 16, 16)):
+import os
+grids = [("hilbert", 8, 8), ("hilbert", 32, 32), ("rowmajor", 5, 3), ("hilbert", 6, 5), ("hilbert", 64, 32), ("rowmajor", 16, 16)]
+if os.environ.get("CUP2D_EDGE_PREV", "0") != "0":   # a workgroup needs at least two rounds for a previous one: 4 096 tiles and more
+    grids = [("hilbert", 32, 32), ("hilbert", 256, 256), ("hilbert", 384, 256)]
+for order, nbx, nby in grids:
     g = BlockGrid(nbx, nby, order=order)
     b = rng.uniform(-1, 1, (g.ny, g.nx)); b -= b.mean()
     last = {}

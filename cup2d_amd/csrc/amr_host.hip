@@ -1048,6 +1048,32 @@ static long long regrid_jobs(const Leaves &L, const RegridPlan &RP, std::vector<
   return njobs;
 }
 
+// The job and corner tables cup2d_amr_regrid_device hands to k_amr_regrid, for a host that wants to look at them (no GPU, no
+// context: tests/test_amr.py replays the kernel on them in numpy).  jobs[njobs][8], corners[nprolong][4][12]; with jobs ==
+// NULL only the counts are returned (*nprolong may be NULL).  Returns njobs or a negative error.
+extern "C" long long cup2d_amr_regrid_jobs(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *st,
+                                           long long cap_jobs, int32_t *jobs, long long cap_prolong, int32_t *corners,
+                                           long long *nprolong) {
+  if (bad_grid_args(nblocks, blocks, bpdx, bpdy, "amr_regrid_jobs")) return CUP2D_ERR_ARG;
+  if (!st) { cup2d::set_error("amr_regrid_jobs: bad argument"); return CUP2D_ERR_ARG; }
+  const Leaves L(nblocks, blocks, bpdx, bpdy);
+  RegridPlan RP;
+  const long long n_new = make_plan(L, nblocks, bpdx, bpdy, level_max, st, true, RP);
+  if (n_new < 0) return n_new;
+  std::vector<int32_t> J, C;
+  const long long njobs = regrid_jobs(L, RP, J, C);
+  const long long np = (long long)(C.size() / (4 * cup2d::CORNER_INTS));
+  if (nprolong) *nprolong = np;
+  if (!jobs) return njobs;
+  if (cap_jobs < njobs || cap_prolong < np || (np && !corners)) {
+    cup2d::set_error("amr_regrid_jobs: capacity %lld / %lld < %lld jobs / %lld refined blocks", cap_jobs, cap_prolong, njobs, np);
+    return CUP2D_ERR_ARG;
+  }
+  std::copy(J.begin(), J.end(), jobs);
+  std::copy(C.begin(), C.end(), corners);
+  return njobs;
+}
+
 extern "C" int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nblocks, const int32_t *blocks, int bpdx, int bpdy,
                                        int level_max, const int32_t *st, int nfields, const int32_t *fields) {
   using namespace cup2d;

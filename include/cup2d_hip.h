@@ -352,6 +352,14 @@ long long cup2d_amr_regrid_local(int nblocks, const int32_t *blocks, int bpdx, i
  * blocks); the N-rank regrid is cup2d_amr_regrid_local.  The caller destroys src afterwards. */
 int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nblocks, const int32_t *blocks, int bpdx, int bpdy,
                             int level_max, const int32_t *states, int nfields, const int32_t *fields);
+/* The tables cup2d_amr_regrid_device gives its kernel, without a GPU (for inspection and for the CPU replay of the kernel in
+ * tests/test_amr.py): jobs[njobs][8] = {type, a0..a4, i0, j0} -- type 0 COPY {dst, src}, 1 RESTRICT {dst, s00, s10, s01, s11},
+ * 2 PROLONG {src, d0, d1, d2, d3, -, i0, j0} (the prolong jobs come first; job k's corner record is number k) --,
+ * corners[nprolong][4][12] = {kind, flags, nine coarse cells (block << 1 | averaged, -1: none), pad}, kind 0 wall (flags bit 1:
+ * y wall) / 1 same-level cell of block c[2] / 2 TestInterp on the nine coarse cells / 3 2 x 2 mean in finer block c[2] / 4 none.
+ * jobs == NULL: counts only.  Returns njobs. */
+long long cup2d_amr_regrid_jobs(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
+                                long long cap_jobs, int32_t *jobs, long long cap_prolong, int32_t *corners, long long *nprolong);
 int cup2d_download_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, double *host);
 int cup2d_upload_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, const double *host);
 int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks);

@@ -142,6 +142,117 @@ def test_amr_host_regrid_library_vs_python_statement():
     assert all(v > 10 for v in seen.values()), seen
 
 
+def test_amr_regrid_kernel_tables_replayed_on_the_cpu():
+    """cup2d_amr_regrid_device's HOST half without a GPU: the job and corner tables it hands to k_amr_regrid
+    (cup2d_amr_regrid_jobs) replayed in numpy exactly as the kernel reads them -- COPY / RESTRICT / PROLONG from the parent's
+    tensorial halo-1 tile, side cells by the closed forms of the block operators (oracle.amr.lab1 = amr_ghost), corner cells from
+    the 12-int descriptors (wall / same-level cell / 2 x 2 mean of a finer block / TestInterp on nine coarse cells, leaf or
+    averaged) -- against the library's host regrid, bit for bit, on random balanced grids: a wrong index in a table cannot
+    hide behind the GPU."""
+    import ctypes
+    from cup2d_amd import amr as A, lib as L
+    from oracle import amr as OA
+    lib = L.load_library()
+    vp = ctypes.c_void_p
+    kinds = {0: 0, 1: 0, 2: 0, 3: 0}
+    for seed in range(4):
+        rng = np.random.default_rng(500 + seed)
+        level_max, l0 = 4 + seed % 2, 1 + seed % 2
+        blocks = np.array([(l0, i, j) for j in range(1 << l0) for i in range(1 << l0)], dtype=np.int64)
+        vel, pres = rng.uniform(-1, 1, (len(blocks), 128)), rng.uniform(-1, 1, (len(blocks), 64))
+        for it in range(5):
+            nb = len(blocks)
+            if nb > 250:
+                break
+            st = A.validate_states(blocks, rng.choice([0, 1, 2], size=nb, p=[0.55, 0.2, 0.25]).astype(np.int32), level_max)
+            if not (st != A.LEAVE).any():
+                continue
+            b_host, d_host = A.regrid(blocks, st, {"vel": (vel, 2, True), "pres": (pres, 1, False)}, level_max)
+            b32, st32 = np.ascontiguousarray(blocks, dtype=np.int32), np.ascontiguousarray(st, dtype=np.int32)
+            npro = ctypes.c_longlong()
+            nj = lib.cup2d_amr_regrid_jobs(nb, b32.ctypes.data_as(vp), 1, 1, level_max, st32.ctypes.data_as(vp), 0, None, 0, None, ctypes.byref(npro))
+            assert nj > 0
+            jobs, corners = np.zeros((nj, 8), np.int32), np.zeros((max(1, npro.value), 4, 12), np.int32)
+            assert lib.cup2d_amr_regrid_jobs(nb, b32.ctypes.data_as(vp), 1, 1, level_max, st32.ctypes.data_as(vp), nj, jobs.ctypes.data_as(vp),
+                                             npro.value, corners.ctypes.data_as(vp), None) == nj
+            assert (jobs[:npro.value, 0] == 2).all() and (jobs[npro.value:, 0] != 2).all()   # prolong jobs first
+            grid = OA.AmrGrid(blocks)
+            for name, fld, dim in (("vel", vel, 2), ("pres", pres, 1)):
+                f = fld.reshape(nb, 64, dim)
+                out = np.full((len(b_host), 64, dim), np.nan)
+                for k, J in enumerate(jobs):
+                    if J[0] == 0:
+                        out[J[1]] = f[J[2]]
+                    elif J[0] == 1:
+                        for lane in range(64):
+                            X, Y = lane & 7, lane >> 3
+                            kid = f[J[2 + 2 * (Y >> 2) + (X >> 2)]].reshape(8, 8, dim)
+                            x, y = X & 3, Y & 3
+                            out[J[1], lane] = (kid[2 * y, 2 * x] + kid[2 * y + 1, 2 * x] + kid[2 * y, 2 * x + 1] + kid[2 * y + 1, 2 * x + 1]) / 4
+                    else:
+                        b, i0, j0 = int(J[1]), int(J[6]), int(J[7])
+                        T = np.empty((10, 10, dim))
+                        for d in range(dim):
+                            sign = None if dim == 1 else ((-1.0, 1.0) if d == 0 else (1.0, -1.0))
+                            T[:, :, d] = OA.lab1(grid, f[:, :, d], b, sign)
+                        for cn in range(4):
+                            cx, cy = (1 if cn & 1 else -1), (1 if cn >> 1 else -1)
+                            gx, gy = (0 if cx < 0 else 9), (0 if cy < 0 else 9)       # tile indices [row][col]
+                            ex, ey = (1 if cx < 0 else 8), (1 if cy < 0 else 8)
+                            C = corners[k, cn]
+                            kinds[min(int(C[0]), 3)] += 1
+                            if C[0] == 0:
+                                ywall = bool(C[1] & 2)
+                                for d in range(dim):
+                                    v = T[ey, gx, d] if ywall else T[gy, ex, d]
+                                    if dim == 2 and ((ywall and d == 1) or (not ywall and d == 0)):
+                                        v = -v
+                                    T[gy, gx, d] = v
+                            elif C[0] == 1:
+                                cell = (7 if cy < 0 else 0) * 8 + (7 if cx < 0 else 0)
+                                T[gy, gx] = f[C[2], cell]
+                            elif C[0] == 2:
+                                XX, YY = 4 * i0 + (-1 if cx < 0 else 4), 4 * j0 + (-1 if cy < 0 else 4)
+                                Cc = [[np.nan] * 3 for _ in range(3)]
+                                for a in range(3):
+                                    for c in range(3):
+                                        e, GX, GY = int(C[2 + 3 * a + c]), XX - 1 + a, YY - 1 + c
+                                        if e < 0:
+                                            continue
+                                        blk = f[e >> 1].reshape(8, 8, dim)
+                                        if e & 1:
+                                            x, y = 2 * (GX & 3), 2 * (GY & 3)
+                                            Cc[a][c] = (blk[y, x, 0] + blk[y + 1, x, 0] + blk[y, x + 1, 0] + blk[y + 1, x + 1, 0]) / 4
+                                        else:
+                                            Cc[a][c] = blk[GY & 7, GX & 7, 0]
+                                T[gy, gx, :] = OA._test_interp(Cc, 0.25 if cx < 0 else -0.25, 0.25 if cy < 0 else -0.25)
+                            elif C[0] == 3:
+                                blk = f[C[2]].reshape(8, 8, dim)
+                                x, y = (6 if cx < 0 else 0), (6 if cy < 0 else 0)
+                                T[gy, gx] = (blk[y, x] + blk[y + 1, x] + blk[y, x + 1] + blk[y + 1, x + 1]) / 4
+                            else:
+                                T[gy, gx] = np.nan
+                        for lane in range(64):
+                            pi, pj = lane & 7, lane >> 3
+                            I, Jc, i, j = pi >> 2, pj >> 2, 2 * (pi & 3), 2 * (pj & 3)
+                            u = lambda dj, di: T[pj + 1 + dj, pi + 1 + di]  # noqa: E731
+                            l00, l0p, l0m, lm0, lmm, lmp = u(0, 0), u(1, 0), u(-1, 0), u(0, -1), u(-1, -1), u(1, -1)
+                            lp0, lpm, lpp = u(0, 1), u(-1, 1), u(1, 1)
+                            x, y = 0.5 * (lp0 - lm0), 0.5 * (l0p - l0m)
+                            x2, y2 = (lp0 + lm0) - 2.0 * l00, (l0p + l0m) - 2.0 * l00
+                            xy = 0.25 * ((lpp + lmm) - (lpm + lmp))
+                            c2 = 0.03125 * x2 + 0.03125 * y2
+                            kid = out[J[2 + 2 * Jc + I]].reshape(8, 8, dim)
+                            kid[j, i] = (l00 + (-0.25 * x - 0.25 * y)) + (c2 + 0.0625 * xy)
+                            kid[j, i + 1] = (l00 + (+0.25 * x - 0.25 * y)) + (c2 - 0.0625 * xy)
+                            kid[j + 1, i] = (l00 + (-0.25 * x + 0.25 * y)) + (c2 - 0.0625 * xy)
+                            kid[j + 1, i + 1] = (l00 + (+0.25 * x + 0.25 * y)) + (c2 + 0.0625 * xy)
+                assert not np.isnan(out).any(), (seed, it, name)
+                assert np.array_equal(out.reshape(len(b_host), -1), d_host[name]), (seed, it, name)
+            blocks, vel, pres = b_host, d_host["vel"], d_host["pres"]
+    assert all(v > 0 for v in kinds.values()), kinds   # every kind of corner was replayed
+
+
 def test_amr_host_routines_reject_bad_input():
     """the regrid-time host routines (no GPU): argument checks and the error text, through the C ABI"""
     import ctypes

@@ -692,6 +692,15 @@ def main():
                  "families": {f: round(v, 4) for f, v in step_ms.items() if v},
                  "note": "final_x = the solve's last pass x = P_inv y (under a timer since round 4)"}
 
+    # where the solver's vectors lie (csrc/krylov_fused.hip tune_placement): the search the first solve of the context ran
+    placement = None
+    try:
+        pl = sim.placement()
+        placement = dict(pl, what="the two launches of an iteration run in one of two modes that follow where the eleven vectors they "
+                                  "stream lie in device memory; the first solve of a context times several complete sets (us per "
+                                  "iteration on zero-filled vectors, reduction finish excluded) and keeps the fastest")
+    except Exception as e:
+        placement = {"error": str(e)[:200]}
     cpu = None
     beat("gpu part")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -807,7 +816,7 @@ def main():
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "gpu_ms_per_step": gpu_split,
             "kernels": timers, "roofline_extra_sampled_steps_outside_timed_region": extra_sampled_steps,
-            "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy,
+            "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy, "placement": placement,
         }
     if second is None or world == 1:
         run.close()

@@ -900,6 +900,14 @@ int cup2d_get_last_solver_form(cup2d_ctx *c, int *form, int *merge, int *handove
   if (handover) *handover = fused ? c->last_handover : 0;
   return CUP2D_OK;
 }
+int cup2d_get_placement(cup2d_ctx *c, int *candidates, double *kept_us, double *slowest_us, double *first_us) {
+  CUP2D_CHECK_CTX(c);
+  if (candidates) *candidates = c->placement_candidates;
+  if (kept_us) *kept_us = c->placement_best_us;
+  if (slowest_us) *slowest_us = c->placement_worst_us;
+  if (first_us) *first_us = c->placement_first_us;
+  return CUP2D_OK;
+}
 int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   CUP2D_CHECK_CTX(c);
   if (kind != CUP2D_SOLVER_SWEEPS && kind != CUP2D_SOLVER_FUSED) { set_error("set_solver: kind %d", kind); return CUP2D_ERR_ARG; }

@@ -153,6 +153,10 @@ struct cup2d_ctx {
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
   int last_solver = 0;       // what the last solve ran
   int last_form = 0, last_merge = 0, last_handover = 0;  // cup2d_get_last_solver_form
+  // placement search of the solver's vectors (krylov_fused.hip tune_placement): done once per context
+  bool placement_tuned = false;
+  int placement_candidates = 0;
+  double placement_best_us = 0, placement_worst_us = 0, placement_first_us = 0;
   int finish_in_kernel = 1;  // the last workgroup of a reducing sweep finishes the reduction (krylov_common.h)
   unsigned *d_ticket = nullptr;  // arrival counter of arrive_last, zero between launches
   double *d_partials = nullptr;  // [NSLOT][grid]

@@ -216,6 +216,12 @@ class Simulation(BodyOps):
         _l.check(self.L.cup2d_get_last_solver_form(self._ctx, ctypes.byref(f), ctypes.byref(m), ctypes.byref(h)), "get_last_solver_form")
         return ("none", "full", "edge", "eab")[f.value], m.value, h.value
 
+    def placement(self):
+        """the placement search of the solver's vectors (cup2d_get_placement): sets timed, us per iteration kept / slowest / first"""
+        n, a, b, f = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _l.check(self.L.cup2d_get_placement(self._ctx, ctypes.byref(n), ctypes.byref(a), ctypes.byref(b), ctypes.byref(f)), "get_placement")
+        return dict(candidates=n.value, kept_us=a.value, slowest_us=b.value, first_us=f.value)
+
     def set_matrix_coo(self, row, col, val, halo=0):
         """Assembled Poisson operator (what main.cpp:7034-7112 pushes into LocalSpMatDnVec), local
         int32 indices in device block order; poisson_solve / apply_A use it instead of the stencil."""

@@ -196,6 +196,12 @@ int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
  * 2 finish in the kernel + reductions over the ranks; handover = bit mask by kind of sweep (bit 0 A+B, 1 C+D, 2 E+A+B,
  * 3 C+D') of the sweeps whose sibling waves handed z edges through LDS.  All zero after a five-sweep solve. */
 int cup2d_get_last_solver_form(cup2d_ctx *ctx, int *form, int *merge, int *handover);
+/* The placement search of the solver's vectors (krylov_fused.hip tune_placement: the durations of the two launches of an
+ * iteration come in two modes that follow where the eleven vectors they stream lie in device memory; the first two-launch solve
+ * of a context on a grid of 2048^2 cells and more tries CUP2D_PLACEMENT_TRIES = 8 complete sets and keeps the fastest).
+ * candidates = sets timed (0: no search ran), the microseconds per iteration of the kept set, of the slowest set seen and of
+ * the set the context was created with.  Diagnostic (bench.py "placement"). */
+int cup2d_get_placement(cup2d_ctx *ctx, int *candidates, double *kept_us, double *slowest_us, double *first_us);
 /* Diagnostic: the reference returns the BEST iterate in the max norm (cuda.cu:535-547), which within a capped number of
  * iterations may still be the initial guess -- nothing of the iterations is then visible in PRES.  With keep_last on, a
  * solve also keeps its LAST iterate (x0 + P_inv y for the fused organisation) in a solver scratch vector;

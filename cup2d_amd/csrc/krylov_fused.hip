@@ -1147,12 +1147,14 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 // same again on every later solve; another process on the same box: 126, 117, 118, 127, ... (tools/gpu_placement_modes.py,
 // tools/gpu_calls/gpu_r04_call18.sh).  Start offsets inside the allocations move nothing, one large
 // allocation carved up is reproducibly the slow mode (round 3).  So the first fused solve of a context on a large grid
-// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 8) complete sets of the eleven vectors -- all held while it
+// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 16) complete sets of the eleven vectors -- all held while it
 // looks, so that every set is other memory --, times three iterations' worth of the two launches on each (the MERGE 0
 // instances on zero-filled vectors with a scratch scalar record: no reduction finish, nothing of the context's state
-// touched), keeps the fastest set and gives the others back.  ~60 ms once per context at 4096^2.
+// touched), keeps the fastest set and gives the others back: 2 ms per set at 4096^2, once per context.  A set in the fast
+// mode turned up among 8 in four of five processes, among 12 in one of two (gpu_r04_call19.sh): the sets of a process are
+// not independent draws, and a process can be out of luck.
 static int tune_placement(cup2d_ctx *c) {
-  static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 8; }();
+  static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 16; }();
   if (c->placement_tuned) return CUP2D_OK;
   c->placement_tuned = true;
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
@@ -1161,7 +1163,7 @@ static int tune_placement(cup2d_ctx *c) {
   double **slot[NV] = {&c->d_r, &c->d_s, &c->d_p, &c->d_p2, &c->d_nu, &c->d_nu2, &c->d_t, &c->d_y, &c->d_yopt, &c->d_xopt, &c->d_rhat};
   size_t free_b = 0, total_b = 0;
   CUP2D_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-  int tries = tries_env > 16 ? 16 : tries_env;
+  int tries = tries_env > 48 ? 48 : tries_env;
   while (tries > 1 && (size_t)(tries - 1) * NV * bytes > free_b / 2) tries--;  // never more than half of what is free
   if (tries <= 1) return CUP2D_OK;
   StageClock clk("tune_placement");

@@ -11,8 +11,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; p=d.get
 print('$shift_args  %.1f Mcell-updates/s  %.3f ms/step  C+D %.1f us  E+A+B %.1f us  verified %s  placement: %s sets, kept %.1f / slowest %.1f / first %.1f us' % (d['value'], d['ms_per_step'], 1e3*k['sweep_C']['ms_avg'], 1e3*k['sweep_EA']['ms_avg'], d['verified']['ok'], p.get('candidates'), p.get('kept_us',0), p.get('slowest_us',0), p.get('first_us',0)))"
   done
 }
-run 5 CUP2D_PLACEMENT_TRIES=8
-run 3 CUP2D_PLACEMENT_TRIES=0
-run 2 CUP2D_PLACEMENT_TRIES=12
+run 6 CUP2D_PLACEMENT_TRIES=16
+run 2 CUP2D_PLACEMENT_TRIES=0
+run 4 CUP2D_PLACEMENT_TRIES=32
 CUP2D_HOST_TIMING=1 python3 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-amr --no-nrank-proxy --no-verify 2>&1 >/dev/null | grep "tune_placement" | tail -12
-timeout 1500 python3 -m pytest tests/test_solver_variants_gpu.py tests/test_baseline_sizes_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -5
+echo

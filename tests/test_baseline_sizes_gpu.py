@@ -193,12 +193,17 @@ def test_solver_at_the_bench_configuration(gpu_lib, oracle):
             assert r["err"] < 0.2 * r["err_init"], r  # 50 iterations did reduce the residual
             assert abs(true - r["err"]) <= 1e-6 * r["err"] + 1e-9, (kind, true, r)
         placement = s.placement()
+        s.set_solver(fused=True, finish_in_kernel=True)
+        s.fill(L.PRES, 0.0)
+        s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=1)
+        form = s.last_solver_form()
     xf, rf, _ = out["fused"]
     xs, rs, _ = out["sweeps"]
     # the first two-launch solve of this context searched for a fast placement of its vectors (krylov_fused.hip tune_placement):
     # several complete sets were timed, the kept one is the fastest seen -- and the iterates above are what the solver computes on it
-    print("placement search:", placement)
-    assert placement["candidates"] >= 2 and placement["kept_us"] <= placement["first_us"] <= placement["slowest_us"], placement
+    print("placement search:", placement, "form", form)
+    if form[0] == "eab":   # (the search probes the two-launch organisation's kernels: CUP2D_FUSED_FORM=full / edge run without it)
+        assert placement["candidates"] >= 2 and placement["kept_us"] <= placement["first_us"] <= placement["slowest_us"], placement
     assert rf["err_init"] == rs["err_init"]
     scale = np.abs(xs).max()
     print("bench-config solver: err_init %.3e  fused err %.6e  sweeps err %.6e  max|x_f - x_s| / max|x| = %.2e"

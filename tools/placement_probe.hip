@@ -30,6 +30,14 @@ __global__ void k_11(P11 q) {  // 8 read, 3 written: contiguous chunk per workgr
     q.p[8][i] = s; q.p[9][i] = s; q.p[10][i] = s;
   }
 }
+__global__ void k_2(P11 q) {  // read a, read + write b, contiguous chunk per workgroup
+  const size_t per = (N / 2 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < N / 2 ? lo + per : N / 2;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const double2 a = q.p[0][i]; double2 v = q.p[1][i];
+    v.x += a.x; v.y += a.y;
+    q.p[1][i] = v;
+  }
+}
 int main(int argc, char **argv) {
   const int NB = argc > 1 ? atoi(argv[1]) : 44;
   std::vector<double *> b(NB);
@@ -51,6 +59,50 @@ int main(int argc, char **argv) {
   std::sort(order.begin(), order.end(), [&](int a, int c) { return rw[a] > rw[c]; });
   std::vector<int> fast(order.begin(), order.begin() + 11), slow(order.end() - 11, order.end());
   printf("the 11 buffers fastest alone: %7.1f GB/s    the 11 slowest alone: %7.1f GB/s\n", set11(fast), set11(slow));
+  // 3b. pairs: a lockstep pass over TWO buffers (one read, one read + written) for every pair of the first NP buffers: is the
+  //     interference pairwise?  Then: the 11 buffers picked greedily for the best worst-pair, against the consecutive sets
+  {
+    const int NP = NB < 33 ? NB : 33;
+    std::vector<std::vector<double>> M(NP, std::vector<double>(NP, 0.0));
+    double lo = 1e30, hi = 0;
+    for (int i = 0; i < NP; i++)
+      for (int j = i + 1; j < NP; j++) {
+        P11 q; for (int k = 0; k < 11; k++) q.p[k] = nullptr;
+        q.p[0] = (double2 *)b[i]; q.p[1] = (double2 *)b[j];
+        const double gb = 3.0 * N * 8 / 1e6 / timeit([&] { hipLaunchKernelGGL(k_2, dim3(2048), dim3(256), 0, 0, q); });
+        M[i][j] = M[j][i] = gb; lo = gb < lo ? gb : lo; hi = gb > hi ? gb : hi;
+      }
+    printf("pairs of the first %d buffers (read a, read + write b in lockstep): %.0f .. %.0f GB/s; rows = buffer, entries = GB/s / 100\n", NP, lo, hi);
+    for (int i = 0; i < NP; i++) { printf("  %2d:", i); for (int j = 0; j < NP; j++) printf(" %2.0f", i == j ? 0.0 : M[i][j] / 100); printf("\n"); }
+    // greedy: start from the best pair, add the buffer whose worst pair with the chosen ones is best
+    std::vector<int> pick; int bi = 0, bj = 1;
+    for (int i = 0; i < NP; i++) for (int j = i + 1; j < NP; j++) if (M[i][j] > M[bi][bj]) { bi = i; bj = j; }
+    pick = {bi, bj};
+    while ((int)pick.size() < 11) {
+      int best = -1; double bestw = -1;
+      for (int c = 0; c < NP; c++) {
+        if (std::find(pick.begin(), pick.end(), c) != pick.end()) continue;
+        double w = 1e30; for (int p : pick) w = M[c][p] < w ? M[c][p] : w;
+        if (w > bestw) { bestw = w; best = c; }
+      }
+      pick.push_back(best);
+    }
+    std::vector<int> worstpick; { // and the opposite: greedily the worst pairs
+      int wi = 0, wj = 1; for (int i = 0; i < NP; i++) for (int j = i + 1; j < NP; j++) if (M[i][j] < M[wi][wj]) { wi = i; wj = j; }
+      worstpick = {wi, wj};
+      while ((int)worstpick.size() < 11) {
+        int best = -1; double bestw = 1e30;
+        for (int c = 0; c < NP; c++) {
+          if (std::find(worstpick.begin(), worstpick.end(), c) != worstpick.end()) continue;
+          double w = 0; for (int p : worstpick) w += M[c][p];
+          if (w < bestw) { bestw = w; best = c; }
+        }
+        worstpick.push_back(best);
+      }
+    }
+    printf("11 streams: greedy best-pairs set %7.1f GB/s   greedy worst-pairs set %7.1f GB/s   (picked:", set11(pick), set11(worstpick));
+    for (int p : pick) printf(" %d", p); printf(")\n");
+  }
   // 4. ONE allocation, the 11 streams at base + k * (128 MiB + delta): does a spacing exist that is reliably fast?
   for (auto &p : b) CK(hipFree(p));
   char *big = nullptr;

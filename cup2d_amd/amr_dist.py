@@ -18,8 +18,11 @@ coarse-fine labs 2582-2684, flux faces 1819-1825).  Here the same partition is p
                  whose range changes has migrated) and every rank fetches what its new range is made of from the old
                  owners and computes its own prolonged / restricted blocks (fetch_new_range, cup2d_amr_regrid_local).
 
-The device side needs nothing AMR-specific for the exchange: ghost blocks travel whole through the face-strip kernels
-(a strip of width 8 is the block), the kernels of csrc/amr.hip read them through the same tables as owned blocks.
+The device side needs nothing AMR-specific for the exchange: a ghost block is a copy of the remote block, the kernels of
+csrc/amr.hip read it through the same tables as owned blocks.  What TRAVELS is not the whole block but the cells of it the
+receiving rank's kernels read (AmrPartition.cells: one cell plan per operator family, cup2d_halo_plan_cells) -- the strips of the
+reference's synchroniser, found by running the kernels' own ghost expressions with a recording accessor
+(cup2d_amr_trace_reads); CUP2D_AMR_STRIPS=0 sends whole blocks (the block plan alone).
 """
 import ctypes
 
@@ -29,19 +32,41 @@ from . import lib as _l
 from .amr import AmrBlockGrid, AmrSimulation, BS, regrid, tag_states, validate_states, LEAVE
 
 
+class CellTopo:
+    """per-peer offsets and counts of one cell plan, in the shape TorchComm reads (peer, send offset, receive offset, cells out,
+    cells in) -- the message unit is one cell"""
+
+    def __init__(self, peers, nsend, nrecv):
+        self.peers, self.nsend, self.nrecv = peers, int(nsend), int(nrecv)
+
+
+def strips_enabled():
+    import os
+    return os.environ.get("CUP2D_AMR_STRIPS", "1") != "0"
+
+
+def _mask_cells(mask_rows):
+    """uint64 masks [n] -> (row index, cell) of every set bit, rows ascending, cells ascending"""
+    if len(mask_rows) == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    bits = np.unpackbits(np.ascontiguousarray(mask_rows, dtype="<u8").view(np.uint8).reshape(-1, 8), axis=1, bitorder="little")
+    return np.nonzero(bits)
+
+
 def partition_bounds(nblocks, nranks):
     """contiguous, equally filled ranges of the Hilbert-ordered leaf list (the reference's balance criterion: blocks per rank)"""
     return np.array([(nblocks * r) // nranks for r in range(nranks + 1)], dtype=np.int64)
 
 
 class AmrPartition:
-    def __init__(self, G, nranks, rank, coo=None):
+    def __init__(self, G, nranks, rank, coo=None, strips=None):
         """G: the GLOBAL AmrBlockGrid (every rank holds the leaf list, 12 bytes per block).  coo: the global Poisson triplets
         (G.poisson_coo()) when the caller wants this rank's rows as triplets (row, col, val: the route through
         cup2d_set_matrix_coo, and the tests); without them the library assembles the rows from the local tables
         (cup2d_amr_install_poisson) -- a row's columns lie in the block itself and its face neighbours, all in the first
         ghost ring."""
         self.G, self.nranks, self.rank = G, int(nranks), int(rank)
+        strips = strips_enabled() if strips is None else bool(strips)
         nb = G.nblocks
         self.bounds = partition_bounds(nb, nranks)
         self.owner = np.searchsorted(self.bounds, np.arange(nb), side="right") - 1
@@ -100,6 +125,54 @@ class AmrPartition:
             self.col = (cb * 64 + c[m] % 64).astype(np.int32)
             self.val = np.ascontiguousarray(v[m])
         self.gather = (self.send_block.astype(np.int64)[:, None] * 64 + np.arange(64)[None, :]).ravel().astype(np.int32)
+        # ---- cell plans: of the blocks above, the cells the peer's kernels read (one list per operator family) ----
+        self.cells = self._cell_plans() if (strips and self.peers) else None
+        if self.cells is not None:
+            self.gather = self.cells[_l.CELLS_MATRIX][0]
+
+    def _cell_plans(self):
+        """[set] -> (send_cell int32 [ns], recv_cell int32 [nr], CellTopo).  Link (reader rank a, owner rank b): the cells of b's
+        blocks that a's blocks read, in (global block, cell) order on both ends.  The receiver traces its own blocks that some
+        peer holds as ghosts (every block that reads a remote one is in that remote's two rings); the sender traces its ghost
+        copies of the receiver's blocks -- the same readers as far as this link goes, so the same list, with no message."""
+        G, L = self.G, _l.load_library()
+        vp = ctypes.c_void_p
+        kind = np.ascontiguousarray(G.kind, dtype=np.int32)
+        nbr2 = np.ascontiguousarray(G.nbr2, dtype=np.int32)
+        half = np.ascontiguousarray(G.half, dtype=np.int32)
+        nb = G.nblocks
+
+        def trace(readers, which):
+            mask = np.zeros(nb, dtype=np.uint64)
+            r = np.ascontiguousarray(readers, dtype=np.int32)
+            _l.check(L.cup2d_amr_trace_reads(nb, kind.ctypes.data_as(vp), nbr2.ctypes.data_as(vp), half.ctypes.data_as(vp), len(r),
+                                             r.ctypes.data_as(vp), which, mask.ctypes.data_as(vp)), "amr_trace_reads")
+            return mask
+        mine = [g[self.owner[g] == self.rank] for q, g in enumerate(self._ghosts) if q != self.rank and len(g)]
+        readers_me = np.unique(np.concatenate(mine)) if mine else np.zeros(0, dtype=np.int64)
+        plans = []
+        for which in range(3):
+            mask_me = trace(readers_me, which)
+            mask_me[self.lo:self.hi] = 0  # (reads inside the own range)
+            held = np.zeros(nb, dtype=bool)
+            held[self.ghost_ids] = True
+            assert held[mask_me != 0].all(), "a kernel reads a remote block outside the ghost list"
+            send, recv, peers = [], [], []
+            for (q, _so, _ro, _ns, _nr) in self.peers:
+                g_in = self.ghost_ids[self.owner[self.ghost_ids] == q]          # my ghosts that q owns, ascending
+                rows, cells = _mask_cells(mask_me[g_in])
+                cin = self.local_of[g_in[rows]] * 64 + cells
+                mask_q = trace(g_in, which)[self.lo:self.hi]                       # what q's blocks next to me read of mine
+                rows, cells = _mask_cells(mask_q)
+                cout = rows * 64 + cells
+                listed = np.zeros(self.nowned, dtype=bool)
+                listed[self.send_block[_so:_so + _ns]] = True
+                assert listed[rows].all(), "a cell of a block the peer does not hold as a ghost"
+                peers.append((q, len(send), len(recv), len(cout), len(cin)))
+                send.extend(cout.tolist())
+                recv.extend(cin.tolist())
+            plans.append((np.asarray(send, dtype=np.int32), np.asarray(recv, dtype=np.int32), CellTopo(peers, len(send), len(recv))))
+        return plans
 
     def _neighbours(self, ids):
         G = self.G
@@ -162,6 +235,9 @@ class DistributedAmrSimulation(AmrSimulation):
         zs, zr = np.zeros(max(1, P.nsend), dtype=np.int32), np.zeros(max(1, P.nrecv), dtype=np.int32)
         _l.check(self.L.cup2d_halo_plan(self._ctx, P.nsend, P.send_block.ctypes.data_as(vp), zs.ctypes.data_as(vp), P.nrecv,
                                         P.recv_block.ctypes.data_as(vp), zr.ctypes.data_as(vp)), "halo_plan")
+        for which, (sc, rc, _t) in enumerate(P.cells or ()):
+            _l.check(self.L.cup2d_halo_plan_cells(self._ctx, which, len(sc), sc.ctypes.data_as(vp), len(rc), rc.ctypes.data_as(vp)),
+                     "halo_plan_cells")
         self.comm_errors = []
         if comm == "rccl":
             token = ctypes.create_string_buffer(_l.COMM_ID_BYTES)
@@ -172,6 +248,10 @@ class DistributedAmrSimulation(AmrSimulation):
             cols = [np.ascontiguousarray([p[k] for p in P.peers], dtype=np.int32) for k in range(5)]
             _l.check(self.L.cup2d_comm_init(self._ctx, self.world, self.rank, box[0], len(P.peers), *[c.ctypes.data_as(vp) for c in cols]),
                      "comm_init")
+            for which, (_sc, _rc, t) in enumerate(P.cells or ()):
+                cc = [np.ascontiguousarray([x[k] for x in t.peers], dtype=np.int32) for k in (1, 3, 2, 4)]
+                _l.check(self.L.cup2d_comm_set_cell_counts(self._ctx, which, len(t.peers), *[c.ctypes.data_as(vp) for c in cc]),
+                         "comm_set_cell_counts")
             self.comm = None
         else:
             if mode is None:
@@ -195,7 +275,19 @@ class DistributedAmrSimulation(AmrSimulation):
             hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
             pending = []
 
+            self.cell_exchanges = [0, 0, 0]  # per cell plan: exchanges issued (diagnostics, tests)
+            self.block_exchanges = 0
+            self.sent_doubles = [0, 0]         # through the cell plans: what went out, what the same exchanges move as whole blocks
+
             def exchange(user, snd, rcv, sd, st):
+                cs = _l.cell_strip(sd)
+                if cs is not None:  # a cell plan: the unit is one cell of cs[1] doubles, offsets and counts of that plan
+                    self.cell_exchanges[cs[0]] += 1
+                    self.sent_doubles[0] += P.cells[cs[0]][2].nsend * cs[1]
+                    self.sent_doubles[1] += P.nsend * 64 * cs[1]
+                    cm.exchange(cs[1], topo=P.cells[cs[0]][2])
+                    return
+                self.block_exchanges += 1
                 cm.exchange(sd)
                 if rcv and rcv != cm.recv.data_ptr():
                     pending.append((rcv, P.nrecv * sd * 8))

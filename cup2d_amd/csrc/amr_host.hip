@@ -10,6 +10,8 @@
 #include <thread>
 #include <vector>
 
+#include "amr_ghost.h"
+#include "block.h"
 #include "ctx.h"
 
 namespace {
@@ -158,6 +160,61 @@ extern "C" long long cup2d_amr_poisson_coo(int nblocks, const int32_t *kind, con
         }
       }
   return nnz;
+}
+
+// Which cells of OTHER blocks the operators of the listed blocks read: the very expressions the kernels evaluate (amr_ghost
+// / amr_ghost3 of amr_ghost.h, build_row above), run with an accessor that records instead of reading.  An N-rank exchange
+// that delivers exactly these cells of a ghost block (instead of the whole block) leaves every kernel's input unchanged --
+// what the reference's synchroniser arrives at with its per-stencil strips (main.cpp:2053-2125, 2582-2684).
+extern "C" int cup2d_amr_trace_reads(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half, int nreaders,
+                                     const int32_t *readers, int set, uint64_t *mask) {
+  if (nblocks <= 0 || !kind || !nbr2 || !half || nreaders < 0 || (nreaders && !readers) || !mask || set < 0 || set > 2) {
+    cup2d::set_error("amr_trace_reads: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  for (int i = 0; i < nreaders; i++)
+    if (readers[i] < 0 || readers[i] >= nblocks) {
+      cup2d::set_error("amr_trace_reads: readers[%d] = %d", i, readers[i]);
+      return CUP2D_ERR_ARG;
+    }
+  cup2d::AmrDev T;
+  T.kind = kind; T.nbr2 = nbr2; T.half = half; T.level = nullptr; T.faces = nullptr; T.h0 = 0.0;
+  int bad = 0;
+  const auto mark = [&](int self, int blk, int cell) {
+    if (blk < 0 || blk >= nblocks || cell < 0 || cell >= 64) { bad++; return; }
+    if (blk != self) mask[blk] |= 1ull << cell;
+  };
+  for (int i = 0; i < nreaders; i++) {
+    const int b = readers[i];
+    if (set == 0) {  // the halo-1 operators: k_amr_scalar / k_amr_vector (32 cross ghosts)
+      for (int s = 0; s < 4; s++)
+        for (int q = 0; q < BS; q++) {
+          const auto get = [&](int blk, int cell) { mark(b, blk, cell); return 0.0; };
+          (void)cup2d::amr_ghost(get, kind[4 * b + s], nbr2[(4 * b + s) * 2], nbr2[(4 * b + s) * 2 + 1], half[4 * b + s], s, q, 0.0,
+                                 0.0, 1.0);
+        }
+    } else if (set == 1) {  // the halo-3 tile of k_amr_advect (96 cross ghosts)
+      for (int s = 0; s < 4; s++)
+        for (int k = 0; k < 3; k++)
+          for (int q = 0; q < BS; q++) {
+            const auto get = [&](int blk, int cell) { mark(b, blk, cell); return double2{0.0, 0.0}; };
+            (void)cup2d::amr_ghost3(get, T, b, s, k, q, double2{0.0, 0.0}, double2{0.0, 0.0});
+          }
+    } else {  // the columns of the block's rows of the Poisson matrix (interior rows stay in the block)
+      for (int iy = 0; iy < BS; iy++)
+        for (int ix = 0; ix < BS; ix++) {
+          if (ix > 0 && ix < BS - 1 && iy > 0 && iy < BS - 1) continue;
+          Row r;
+          build_row(r, b, ix, iy, kind, nbr2, half);
+          for (int k = 0; k < r.n; k++) mark(b, (int)(r.col[k] / 64), (int)(r.col[k] % 64));
+        }
+    }
+  }
+  if (bad) {
+    cup2d::set_error("amr_trace_reads: %d reads outside the tables (a neighbour entry of a reader is missing)", bad);
+    return CUP2D_ERR_ARG;
+  }
+  return CUP2D_OK;
 }
 
 namespace cup2d {

@@ -376,6 +376,16 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
     CUP2D_HIP_CHECK(dev_malloc(p, slab_doubles(c, 1) * sizeof(double)));
     CUP2D_HIP_CHECK(hipMemset(*p, 0, slab_doubles(c, 1) * sizeof(double)));
   }
+  // CUP2D_POISON_GHOSTS=1 (tests): the ghost blocks of every field and Krylov vector start as NaN instead of zero, so that a
+  // kernel reading a ghost cell no exchange delivered (cup2d_halo_plan_cells lists too little) cannot pass a parity test
+  static const bool poison = [] { const char *e = getenv("CUP2D_POISON_GHOSTS"); return e && atoi(e) != 0; }();
+  if (poison && nghost > 0) {
+    const auto ghosts_nan = [&](double *q, int dim) {
+      return hipMemset(q + (size_t)nblocks * BC * dim, 0xFF, (size_t)nghost * BC * dim * sizeof(double));
+    };
+    for (int f = 0; f < CUP2D_NFIELDS; f++) CUP2D_HIP_CHECK(ghosts_nan(c->d_field[f], dim_of(f)));
+    for (double **q : kv) CUP2D_HIP_CHECK(ghosts_nan(*q, 1));
+  }
   build_P_inv(c->h_Pinv);
   CUP2D_HIP_CHECK(dev_malloc(&c->d_Pinv, BC * BC * sizeof(double)));
   // the dense kernels read d_Pinv[k][n] as the coefficient of input k in output n, i.e. the transpose of
@@ -460,6 +470,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->mat.d_reg);
   dev_free(c->amr.d_level); dev_free(c->amr.d_kind); dev_free(c->amr.d_nbr2); dev_free(c->amr.d_half);
   dev_free(c->amr.d_faces); dev_free(c->amr.d_faces2);
+  for (auto &cp : c->cells) { dev_free(cp.d_send); dev_free(cp.d_recv); cp = cup2d::CellPlan(); }
   dev_free(c->plan.d_send_block); dev_free(c->plan.d_send_face);
   dev_free(c->plan.d_recv_block); dev_free(c->plan.d_recv_face);
   clk.lap("frees");
@@ -1301,6 +1312,7 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
   // back to c->stream through an event before unpack: waiting for c->stream covers it.)
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   dev_free(p.d_send_block); dev_free(p.d_send_face); dev_free(p.d_recv_block); dev_free(p.d_recv_face);
+  for (auto &cp : c->cells) { dev_free(cp.d_send); dev_free(cp.d_recv); cp = cup2d::CellPlan(); }  // (subsets of the old plan)
   p = HaloPlan();
   p.nsend = nsend; p.nrecv = nrecv;
   if (nsend) {
@@ -1316,6 +1328,35 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
     CUP2D_HIP_CHECK(hipMemcpy(p.d_recv_face, rf, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
     p.h_recv_block.assign(rb, rb + nrecv);
   }
+  return CUP2D_OK;
+}
+int cup2d_halo_plan_cells(cup2d_ctx *c, int set, int nsend, const int32_t *sc, int nrecv, const int32_t *rc) {
+  CUP2D_CHECK_CTX(c);
+  if (set < 0 || set >= cup2d::CELL_SETS || nsend < 0 || nrecv < 0 || (nsend && !sc) || (nrecv && !rc)) return CUP2D_ERR_ARG;
+  // a cell list is a subset of the block plan's blocks: the communicator's buffers are sized by that plan
+  if ((long long)nsend > (long long)c->plan.nsend * BC || (long long)nrecv > (long long)c->plan.nrecv * BC) {
+    set_error("halo_plan_cells: %d / %d cells exceed the block plan (%d / %d blocks)", nsend, nrecv, c->plan.nsend, c->plan.nrecv);
+    return CUP2D_ERR_ARG;
+  }
+  for (int i = 0; i < nsend; i++)
+    if (sc[i] < 0 || sc[i] >= c->nblocks * BC) { set_error("halo_plan_cells: send cell %d = %d", i, sc[i]); return CUP2D_ERR_ARG; }
+  for (int i = 0; i < nrecv; i++)
+    if (rc[i] < c->nblocks * BC || rc[i] >= c->ntotal * BC) { set_error("halo_plan_cells: receive cell %d = %d", i, rc[i]); return CUP2D_ERR_ARG; }
+  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));  // kernels of the old plan may still read its lists (cup2d_halo_plan)
+  cup2d::CellPlan &P = c->cells[set];
+  dev_free(P.d_send); dev_free(P.d_recv);
+  P = cup2d::CellPlan();
+  if (nsend == 0 && nrecv == 0) return CUP2D_OK;
+  P.nsend = nsend; P.nrecv = nrecv;
+  if (nsend) {
+    CUP2D_HIP_CHECK(dev_malloc(&P.d_send, nsend * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(P.d_send, sc, nsend * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (nrecv) {
+    CUP2D_HIP_CHECK(dev_malloc(&P.d_recv, nrecv * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(P.d_recv, rc, nrecv * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  P.active = true;
   return CUP2D_OK;
 }
 static bool width_ok(int w) { return w >= 1 && w <= 4; }

@@ -122,6 +122,7 @@ struct RcclComm {
   int nranks = 1, rank = 0;
   std::vector<int> peer, soff, roff, cnt, rcnt;   // per peer: rank, first strip in the send / receive list, strips sent / received
   std::vector<int> rblock0;  // per peer: the first of its ghost blocks
+  std::vector<int> csoff[CELL_SETS], croff[CELL_SETS], ccnt[CELL_SETS], crcnt[CELL_SETS];  // the same for the cell plans (cup2d_comm_set_cell_counts)
   bool direct = false;       // every peer's ghost blocks are consecutive: whole blocks can be received in place
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
   long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
@@ -151,14 +152,25 @@ static int rccl_exchange(void *user, double *send, double *recv, int strip_doubl
   if (rc->peer.empty()) return 0;
   CUP2D_HIP_CB(hipEventRecord(rc->ev_packed, (hipStream_t)stream));
   CUP2D_HIP_CB(hipStreamWaitEvent(rc->comm_stream, rc->ev_packed, 0));
-  const size_t sd = (size_t)strip_doubles;
+  // strips of the block plan, or (strip_doubles < 0: CUP2D_CELL_STRIP) cells of a cell plan with its own offsets and counts
+  const std::vector<int> *soff = &rc->soff, *roff = &rc->roff, *cnt = &rc->cnt, *rcnt = &rc->rcnt;
+  size_t sd = (size_t)(strip_doubles > 0 ? strip_doubles : 0);
+  if (strip_doubles < 0) {
+    const int set = CUP2D_CELL_STRIP_SET(strip_doubles);
+    sd = (size_t)CUP2D_CELL_STRIP_DIM(strip_doubles);
+    if (set < 0 || set >= CELL_SETS || rc->ccnt[set].size() != rc->peer.size()) {
+      set_error("rccl exchange: no cell counts for set %d (cup2d_comm_set_cell_counts)", set);
+      return -1;
+    }
+    soff = &rc->csoff[set]; roff = &rc->croff[set]; cnt = &rc->ccnt[set]; rcnt = &rc->crcnt[set];
+  }
   CUP2D_NCCL(rc, rc->api->GroupStart());
   for (size_t i = 0; i < rc->peer.size(); i++)  // receives first, as main.cpp:2040-2047 posts them
-    if (rc->rcnt[i] > 0)
-      CUP2D_NCCL(rc, rc->api->Recv(recv + rc->roff[i] * sd, rc->rcnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+    if ((*rcnt)[i] > 0)
+      CUP2D_NCCL(rc, rc->api->Recv(recv + (*roff)[i] * sd, (*rcnt)[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
   for (size_t i = 0; i < rc->peer.size(); i++)
-    if (rc->cnt[i] > 0)
-      CUP2D_NCCL(rc, rc->api->Send(send + rc->soff[i] * sd, rc->cnt[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
+    if ((*cnt)[i] > 0)
+      CUP2D_NCCL(rc, rc->api->Send(send + (*soff)[i] * sd, (*cnt)[i] * sd, ncclDouble, rc->peer[i], rc->p2p, rc->comm_stream));
   CUP2D_NCCL(rc, rc->api->GroupEnd());
   CUP2D_HIP_CB(hipEventRecord(rc->ev_arrived, rc->comm_stream));
   return 0;
@@ -498,6 +510,26 @@ int cup2d_comm_finalize(cup2d_ctx *c) {
   return comm_finalize_impl(c);
 }
 
+int cup2d_comm_set_cell_counts(cup2d_ctx *c, int set, int npeers, const int32_t *so, const int32_t *sn, const int32_t *ro,
+                               const int32_t *rn) {
+  CUP2D_CHECK_CTX(c);
+  if (!c->rccl) { set_error("comm_set_cell_counts: no in-library communicator (cup2d_comm_init)"); return CUP2D_ERR_COMM; }
+  RcclComm *rc = c->rccl;
+  if (set < 0 || set >= CELL_SETS || npeers != (int)rc->peer.size() || (npeers && (!so || !sn || !ro || !rn))) {
+    set_error("comm_set_cell_counts: set %d, %d peers (the communicator has %d)", set, npeers, (int)rc->peer.size());
+    return CUP2D_ERR_ARG;
+  }
+  const CellPlan &P = c->cells[set];
+  for (int i = 0; i < npeers; i++)
+    if (so[i] < 0 || sn[i] < 0 || ro[i] < 0 || rn[i] < 0 || so[i] + sn[i] > P.nsend || ro[i] + rn[i] > P.nrecv) {
+      set_error("comm_set_cell_counts: peer %d (%d at %d out, %d at %d in) does not fit cell plan %d (%d sent, %d received): call "
+                "cup2d_halo_plan_cells first", i, sn[i], so[i], rn[i], ro[i], set, P.nsend, P.nrecv);
+      return CUP2D_ERR_ARG;
+    }
+  rc->csoff[set].assign(so, so + npeers); rc->ccnt[set].assign(sn, sn + npeers);
+  rc->croff[set].assign(ro, ro + npeers); rc->crcnt[set].assign(rn, rn + npeers);
+  return CUP2D_OK;
+}
 int cup2d_comm_stats(cup2d_ctx *c, int *nranks, int *npeers, long long *exchanges, long long *allreduces, long long *allgathers) {
   CUP2D_CHECK_CTX(c);
   if (!c->rccl) { set_error("comm_stats: no communicator"); return CUP2D_ERR_ARG; }

@@ -58,6 +58,16 @@ struct HaloPlan {
   std::vector<int32_t> h_recv_block;  // host copy: the communicator checks whether a peer's ghost blocks are consecutive
 };
 
+// cup2d_halo_plan_cells: the ghost cells one family of operators reads, cell by cell (adapted grids on N ranks).  A cell is
+// 64 * block + cell of the context's numbering: owned blocks on the send side, ghost blocks on the receive side; entry i of a
+// peer's send list lands in entry i of what the receiver lists for that peer.
+constexpr int CELL_SETS = 3;  // CUP2D_CELLS_HALO1, _HALO3, _MATRIX
+struct CellPlan {
+  bool active = false;
+  int nsend = 0, nrecv = 0;
+  int32_t *d_send = nullptr, *d_recv = nullptr;
+};
+
 // General sparse Poisson operator (the matrix of main.cpp:7034-7112 as LocalSpMatDnVec hands it over,
 // cuda.cu:206-296) in sliced-ELL form with slices of 64 rows: one slice = the 64 rows of one 8x8 block
 // = one wavefront.  Entry k of row (slice s, lane l) sits at ptr[s] + 64*k + l, so a wave reads
@@ -177,6 +187,7 @@ struct cup2d_ctx {
   hipEvent_t solve_ev[SOLVE_AHEAD] = {nullptr};
   double *h_red = nullptr;               // pinned [8]
   cup2d::HaloPlan plan;
+  cup2d::CellPlan cells[cup2d::CELL_SETS];
   cup2d::SellMatrix mat;
   cup2d::AmrTopo amr;
   int precond = cup2d::PRECOND_FD;  // block-Jacobi implementation (krylov.hip); FD needs the built-in P_inv
@@ -365,6 +376,9 @@ int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double
 int exchange_begin(cup2d_ctx *c, const double *vec, int dim, int width);
 int exchange_end(cup2d_ctx *c, double *vec, int dim, int width);
 int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
+// the same through a cell plan (cup2d_halo_plan_cells), blocking like exchange_halo: gather the listed cells, transport with
+// strip_doubles = CUP2D_CELL_STRIP(set, dim), scatter into the ghost blocks.  dst == nullptr: into vec's own ghost blocks
+int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim);
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);

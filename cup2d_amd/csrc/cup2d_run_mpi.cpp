@@ -177,6 +177,7 @@ static Links links_of(const Patch &p) {
 // -comm mpi: the three callbacks of cup2d_set_comm, host-staged
 struct MpiTransport {
   const Links *P = nullptr;
+  const Links *cells = nullptr;  // [3]: the cell plans of an adapted grid (strip_doubles < 0: CUP2D_CELL_STRIP), or none
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr;  // device buffers the library packs into / unpacks from
   double *h_send = nullptr, *h_recv = nullptr, *h_red = nullptr;  // pinned
   std::vector<MPI_Request> req;
@@ -205,7 +206,9 @@ struct MpiTransport {
   }
   static int exchange(void *user, double *dsend, double *drecv, int sd, void *stream) {
     MpiTransport &T = *static_cast<MpiTransport *>(user);
-    const Links &p = *T.P;
+    if (sd < 0 && !T.cells) return -1;
+    const Links &p = sd < 0 ? T.cells[CUP2D_CELL_STRIP_SET(sd)] : *T.P;  // a cell plan: its own offsets and counts, unit = one cell
+    if (sd < 0) sd = CUP2D_CELL_STRIP_DIM(sd);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.nsend && hipMemcpyAsync(T.h_send, dsend, p.nsend * sd * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
@@ -260,6 +263,11 @@ struct AmrPart {
   std::vector<int32_t> level, kind, nbr2, half, nbr;    // local tables: [nowned + nghost] (nbr: owned blocks only)
   std::vector<int32_t> send_block, recv_block, zeros_s, zeros_r, gather;
   Links links;
+  // cell plans (include/cup2d_hip.h cup2d_halo_plan_cells): of the blocks above, the cells the peer's kernels read -- per
+  // operator family the send / receive cell lists and their per-peer offsets and counts (the unit of a message is one cell)
+  bool strips = true;
+  std::vector<int32_t> send_cell[3], recv_cell[3];
+  Links cell_links[3];
   int owner_of(int g) const { return (int)(std::upper_bound(bounds.begin(), bounds.end(), (long long)g) - bounds.begin()) - 1; }
   static std::vector<long long> ranges(long long n, int nranks) {  // equally filled contiguous ranges (blocks per rank)
     std::vector<long long> b(nranks + 1);
@@ -268,6 +276,7 @@ struct AmrPart {
   }
   void build(int nb_, const int32_t *blocks, const int32_t *gkind, const int32_t *gnbr2, const int32_t *ghalf, int nranks_, int rank_) {
     nb = nb_; nranks = nranks_; rank = rank_;
+    if (const char *e = std::getenv("CUP2D_AMR_STRIPS")) strips = std::atoi(e) != 0;  // 0: whole ghost blocks (the block plan alone)
     bounds = ranges(nb, nranks);
     lo = (int)bounds[rank]; hi = (int)bounds[rank + 1]; nowned = hi - lo;
     std::vector<int> stamp(nb, -1);
@@ -340,6 +349,41 @@ struct AmrPart {
     gather.resize(send_block.size() * BC);
     for (size_t k = 0; k < send_block.size(); k++)
       for (int c = 0; c < BC; c++) gather[k * BC + c] = send_block[k] * BC + c;
+    for (int set = 0; set < 3; set++) { send_cell[set].clear(); recv_cell[set].clear(); cell_links[set] = Links(); }
+    if (!strips || links.peer.empty()) return;
+    // Link (reader rank a, owner rank b): the cells of b's blocks that a's blocks read, in (global block, cell) order on both
+    // ends -- the receiver traces its own blocks that some peer holds as ghosts, the sender its ghost copies of the receiver's
+    // blocks (the same readers as far as the link goes): cup2d_amr_trace_reads runs the kernels' own ghost expressions
+    std::vector<int32_t> readers_me;
+    for (int p = 0; p < nranks; p++)
+      if (p != rank)
+        for (int32_t g : ghosts[p]) if (g >= lo && g < hi) readers_me.push_back(g);
+    std::sort(readers_me.begin(), readers_me.end());
+    readers_me.erase(std::unique(readers_me.begin(), readers_me.end()), readers_me.end());
+    std::vector<uint64_t> mask_me(nb), mask_q(nb);
+    for (int set = 0; set < 3; set++) {
+      std::fill(mask_me.begin(), mask_me.end(), 0);
+      RUN(cup2d_amr_trace_reads(nb, gkind, gnbr2, ghalf, (int)readers_me.size(), readers_me.data(), set, mask_me.data()));
+      Links &cl = cell_links[set];
+      for (size_t k = 0; k < links.peer.size(); k++) {
+        const int q = links.peer[k];
+        std::vector<int32_t> g_in;
+        for (int32_t g : ghost_ids) if (g >= bounds[q] && g < bounds[q + 1]) g_in.push_back(g);
+        cl.peer.push_back(q); cl.soff.push_back((int32_t)send_cell[set].size()); cl.roff.push_back((int32_t)recv_cell[set].size());
+        for (int32_t g : g_in)
+          for (int c = 0; c < BC; c++)
+            if (mask_me[g] >> c & 1) recv_cell[set].push_back(local_of[g] * BC + c);
+        std::fill(mask_q.begin(), mask_q.end(), 0);
+        RUN(cup2d_amr_trace_reads(nb, gkind, gnbr2, ghalf, (int)g_in.size(), g_in.data(), set, mask_q.data()));
+        for (int b = lo; b < hi; b++)
+          for (int c = 0; c < BC; c++)
+            if (mask_q[b] >> c & 1) send_cell[set].push_back((b - lo) * BC + c);
+        cl.scnt.push_back((int32_t)send_cell[set].size() - cl.soff.back());
+        cl.rcnt.push_back((int32_t)recv_cell[set].size() - cl.roff.back());
+      }
+      cl.nsend = send_cell[set].size(); cl.nrecv = recv_cell[set].size();
+    }
+    gather = send_cell[CUP2D_CELLS_MATRIX];
   }
 };
 
@@ -368,15 +412,26 @@ struct AmrRunMpi {
     RUN(cup2d_create(&ctx, P.nowned, P.nghost, P.nowned, P.nbr.data(), H0, device));
     RUN(cup2d_halo_plan(ctx, (int)P.send_block.size(), P.send_block.data(), P.zeros_s.data(), (int)P.recv_block.size(), P.recv_block.data(),
                         P.zeros_r.data()));
+    const bool cells = P.strips && !P.links.peer.empty();
+    if (cells)
+      for (int set = 0; set < 3; set++)
+        RUN(cup2d_halo_plan_cells(ctx, set, (int)P.send_cell[set].size(), P.send_cell[set].data(), (int)P.recv_cell[set].size(),
+                                  P.recv_cell[set].data()));
     if (rccl) {
       char token[CUP2D_COMM_ID_BYTES];
       if (g_rank == 0) RUN(cup2d_comm_unique_id(token));
       MPI_Bcast(token, sizeof token, MPI_BYTE, 0, MPI_COMM_WORLD);
       RUN(cup2d_comm_init(ctx, world, g_rank, token, (int)P.links.peer.size(), P.links.peer.data(), P.links.soff.data(), P.links.roff.data(),
                           P.links.scnt.data(), P.links.rcnt.data()));
+      if (cells)
+        for (int set = 0; set < 3; set++) {
+          const Links &cl = P.cell_links[set];
+          RUN(cup2d_comm_set_cell_counts(ctx, set, (int)cl.peer.size(), cl.soff.data(), cl.scnt.data(), cl.roff.data(), cl.rcnt.data()));
+        }
       RUN(cup2d_comm_selftest(ctx, 20.0, nullptr, 0));
     } else {
       T.init(P.links);
+      T.cells = cells ? P.cell_links : nullptr;
       RUN(cup2d_set_comm(ctx, &MpiTransport::exchange, &MpiTransport::wait, &MpiTransport::allreduce, &T, T.d_send, T.d_recv, T.d_red));
       RUN(cup2d_set_comm_strip_capacity(ctx, MpiTransport::MAX_STRIP));
     }
@@ -712,6 +767,15 @@ int main(int argc, char **argv) {
     for (size_t k = 0; k < P.links.peer.size(); k++)
       for (int32_t x : {P.links.peer[k], P.links.soff[k], P.links.roff[k], P.links.scnt[k], P.links.rcnt[k]}) lk.push_back(x);
     put("links", lk);
+    for (int set = 0; set < 3; set++) {  // the cell plans (empty lists with CUP2D_AMR_STRIPS=0)
+      const std::string k = std::to_string(set);
+      put(("send_cell" + k).c_str(), P.send_cell[set]); put(("recv_cell" + k).c_str(), P.recv_cell[set]);
+      const Links &cl = P.cell_links[set];
+      std::vector<int32_t> ck;
+      for (size_t i = 0; i < cl.peer.size(); i++)
+        for (int32_t x : {cl.peer[i], cl.soff[i], cl.roff[i], cl.scnt[i], cl.rcnt[i]}) ck.push_back(x);
+      put(("cell_links" + k).c_str(), ck);
+    }
     MPI_Finalize();
     return 0;
   }

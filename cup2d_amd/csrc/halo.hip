@@ -175,6 +175,49 @@ int exchange_end(cup2d_ctx *c, double *vec, int dim, int width) {
   }
   return halo_unpack_impl(c, vec, dim, width, c->d_recv);
 }
+// ---- cell plans (adapted grids on N ranks): what travels is the list of cells the receiver's kernels read -------------
+template <bool PACK>
+__global__ __launch_bounds__(WG) void k_cells(double *__restrict__ field, double *__restrict__ buf, const int32_t *__restrict__ cells,
+                                              int n, int dim) {
+  const size_t total = (size_t)n * dim;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+    const size_t e = i / dim;
+    const int comp = (int)(i - e * dim);
+    const size_t at = (size_t)cells[e] * dim + comp;
+    if (PACK) buf[i] = field[at];
+    else field[at] = buf[i];
+  }
+}
+int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  const CellPlan &P = c->cells[set];
+  if (!P.active) { set_error("exchange_cells: no cell plan %d", set); return CUP2D_ERR_ARG; }
+  const auto grid_for_n = [&](size_t total) {
+    int g = (int)((total + WG - 1) / WG);
+    return g > c->grid ? c->grid : (g < 1 ? 1 : g);
+  };
+  {
+    ProfScope prof(c, CUP2D_T_HALO);
+    if (P.nsend > 0) {
+      hipLaunchKernelGGL(k_cells<true>, dim3(grid_for_n((size_t)P.nsend * dim)), dim3(WG), 0, c->stream, vec, c->d_send, P.d_send, P.nsend, dim);
+      CUP2D_HIP_CHECK(hipGetLastError());
+    }
+  }
+  if (c->exchange(c->comm_user, c->d_send, c->d_recv, CUP2D_CELL_STRIP(set, dim), c->stream) != 0) {
+    set_error("exchange callback failed (cell plan %d)", set);
+    return CUP2D_ERR_COMM;
+  }
+  if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+    set_error("wait callback failed");
+    return CUP2D_ERR_COMM;
+  }
+  if (P.nrecv > 0) {
+    ProfScope prof(c, CUP2D_T_HALO);
+    hipLaunchKernelGGL(k_cells<false>, dim3(grid_for_n((size_t)P.nrecv * dim)), dim3(WG), 0, c->stream, vec, c->d_recv, P.d_recv, P.nrecv, dim);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  return CUP2D_OK;
+}
 int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width) {
   CUP2D_TRY(exchange_begin(c, vec, dim, width));
   return exchange_end(c, vec, dim, width);

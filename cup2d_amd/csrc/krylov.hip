@@ -604,6 +604,11 @@ __global__ __launch_bounds__(WG) void k_gather(const double *__restrict__ vec, c
   for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) buf[i] = vec[idx[i]];
 }
 
+__global__ __launch_bounds__(WG) void k_scatter(double *__restrict__ vec, const int32_t *__restrict__ idx,
+                                                const double *__restrict__ buf, int n) {
+  for (int i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) vec[idx[i]] = buf[i];
+}
+
 // Halo of a Krylov vector in matrix mode (cuda.cu:356-380): gather the entries the neighbour ranks
 // need, hand them to the exchange callback, which delivers the entries this rank needs straight into
 // vec[m .. m+halo) (the "device_recv" argument of the callback), and wait for them.
@@ -616,6 +621,27 @@ int matrix_exchange(cup2d_ctx *c, double *vec) {
     if (grid > c->grid) grid = c->grid;
     hipLaunchKernelGGL(k_gather, dim3(grid), dim3(WG), 0, c->stream, vec, M.d_gather, c->d_send, M.ngather);
     CUP2D_HIP_CHECK(hipGetLastError());
+  }
+  // cell plan of the matrix columns (cup2d_halo_plan_cells, adapted grids on N ranks): the gathered cells travel as cells and
+  // are scattered into the vector's ghost blocks -- the columns of the rows keep their meaning
+  const CellPlan &CP = c->cells[CUP2D_CELLS_MATRIX];
+  if (CP.active) {
+    if (M.ngather != CP.nsend) { set_error("matrix_exchange: the gather list (%d) is not the cell plan's send list (%d)", M.ngather, CP.nsend); return CUP2D_ERR_ARG; }
+    if (c->exchange(c->comm_user, c->d_send, c->d_recv, CUP2D_CELL_STRIP(CUP2D_CELLS_MATRIX, 1), c->stream) != 0) {
+      set_error("exchange callback failed (matrix cells)");
+      return CUP2D_ERR_COMM;
+    }
+    if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
+      set_error("wait callback failed");
+      return CUP2D_ERR_COMM;
+    }
+    if (CP.nrecv > 0) {
+      int g2 = (CP.nrecv + WG - 1) / WG;
+      if (g2 > c->grid) g2 = c->grid;
+      hipLaunchKernelGGL(k_scatter, dim3(g2), dim3(WG), 0, c->stream, vec, CP.d_recv, (const double *)c->d_recv, CP.nrecv);
+      CUP2D_HIP_CHECK(hipGetLastError());
+    }
+    return CUP2D_OK;
   }
   // the gather list is the halo plan's send blocks, whole (adapted grids on N ranks): the message unit is a block, the
   // transports count strips of the plan; otherwise single entries (cuda.h's send_pack_idx_ protocol)

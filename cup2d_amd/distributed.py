@@ -119,47 +119,50 @@ class TorchComm:
             self.compute_stream = None
 
     # ---- point-to-point -----------------------------------------------------------------------
-    def _p2p(self, send, recv, strip_doubles):
+    def _p2p(self, send, recv, strip_doubles, topo=None):
         """post all receives, then all sends, as one batch (one ncclGroup on RCCL).  The P2POp lists are built once
         per strip width: an exchange happens twice per BiCGSTAB iteration, its host cost is on the critical path of
         keeping the GPU fed."""
         dist = self.dist
-        key = (send.data_ptr(), recv.data_ptr(), strip_doubles)
+        topo = topo or self.topo  # (a cell plan of an adapted grid brings its own offsets and counts: amr_dist.CellTopo)
+        key = (send.data_ptr(), recv.data_ptr(), strip_doubles, id(topo))
         ops = self._ops.get(key)
         if ops is None:
             ops = []
-            for pr in self.topo.peers:  # (peer, send offset, receive offset, strips out[, strips in])
+            for pr in topo.peers:  # (peer, send offset, receive offset, strips out[, strips in])
                 peer, roff, n = pr[0], pr[2], pr[4] if len(pr) > 4 else pr[3]
                 if n:
                     ops.append(dist.P2POp(dist.irecv, recv[roff * strip_doubles:(roff + n) * strip_doubles], peer, self.group))
-            for pr in self.topo.peers:
+            for pr in topo.peers:
                 peer, soff, n = pr[0], pr[1], pr[3]
                 if n:
                     ops.append(dist.P2POp(dist.isend, send[soff * strip_doubles:(soff + n) * strip_doubles], peer, self.group))
             self._ops[key] = ops
         return dist.batch_isend_irecv(ops) if ops else []
 
-    def exchange(self, strip_doubles):
-        """start moving the packed strips (called after the pack kernel was enqueued)"""
+    def exchange(self, strip_doubles, topo=None):
+        """start moving the packed strips (called after the pack kernel was enqueued); topo: another unit and other per-peer
+        counts than the block plan's (the cell plans of an adapted grid)"""
         torch = self.torch
+        topo = topo or self.topo
         if self.mode == "device":
             self.ev_packed.record(self.compute_stream)
             self.comm_stream.wait_event(self.ev_packed)
             with torch.cuda.stream(self.comm_stream):
-                for r in self._p2p(self.send, self.recv, strip_doubles):
+                for r in self._p2p(self.send, self.recv, strip_doubles, topo):
                     r.wait()
                 self.ev_arrived.record(self.comm_stream)
         elif self.mode == "staged":
-            ns, nr = self.topo.nsend * strip_doubles, self.topo.nrecv * strip_doubles
+            ns, nr = topo.nsend * strip_doubles, topo.nrecv * strip_doubles
             with torch.cuda.stream(self.compute_stream):
                 self.h_send[:ns].copy_(self.send[:ns], non_blocking=True)
             self.compute_stream.synchronize()
-            for r in self._p2p(self.h_send, self.h_recv, strip_doubles):
+            for r in self._p2p(self.h_send, self.h_recv, strip_doubles, topo):
                 r.wait()
             with torch.cuda.stream(self.compute_stream):
                 self.recv[:nr].copy_(self.h_recv[:nr], non_blocking=True)
         else:
-            for r in self._p2p(self.send, self.recv, strip_doubles):
+            for r in self._p2p(self.send, self.recv, strip_doubles, topo):
                 r.wait()
 
     def wait(self):

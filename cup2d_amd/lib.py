@@ -22,6 +22,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 
 # every symbol include/cup2d_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
+    "cup2d_amr_trace_reads", "cup2d_halo_plan_cells", "cup2d_comm_set_cell_counts",
     "cup2d_create", "cup2d_destroy", "cup2d_last_error", "cup2d_version", "cup2d_set_stream", "cup2d_get_stream",
     "cup2d_synchronize", "cup2d_set_math", "cup2d_upload", "cup2d_download", "cup2d_upload_slab",
     "cup2d_download_slab", "cup2d_field_ptr", "cup2d_fill", "cup2d_copy_field", "cup2d_advect_diffuse_rhs",
@@ -144,6 +145,9 @@ def load_library():
     L.cup2d_halo_unpack_vec.argtypes = [vp, vp, i, i, vp]
     L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, WAIT_FN, ALLREDUCE_FN, vp, vp, vp, vp]
     L.cup2d_set_comm_strip_capacity.argtypes = [vp, ctypes.c_int]
+    L.cup2d_amr_trace_reads.argtypes = [i, vp, vp, vp, i, vp, i, vp]
+    L.cup2d_halo_plan_cells.argtypes = [vp, i, i, vp, i, vp]
+    L.cup2d_comm_set_cell_counts.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.cup2d_amr_set_finest_level.argtypes = [vp, i]
     L.cup2d_body_set.argtypes = [vp, i, i, vp, vp, vp, vp, d, d]
     L.cup2d_body_clear.argtypes = [vp]
@@ -160,6 +164,17 @@ def load_library():
     L.cup2d_get_timing.argtypes = [vp, i, ctypes.POINTER(d), ctypes.POINTER(i)]
     _LIB = L
     return L
+
+
+CELLS_HALO1, CELLS_HALO3, CELLS_MATRIX = 0, 1, 2  # cup2d_halo_plan_cells sets
+CELL_SET_NAMES = ("halo1", "halo3", "matrix")
+
+
+def cell_strip(strip_doubles):
+    """(set, doubles per cell) of a negative strip_doubles the exchange callback receives (CUP2D_CELL_STRIP), else None"""
+    if strip_doubles >= 0:
+        return None
+    return (-strip_doubles) >> 4, (-strip_doubles) & 15
 
 
 def check(status, what=""):

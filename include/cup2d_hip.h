@@ -424,6 +424,44 @@ int cup2d_set_comm(cup2d_ctx *ctx, cup2d_exchange_fn exchange, cup2d_wait_fn wai
 #define CUP2D_MIN_STRIP_DOUBLES 128
 int cup2d_set_comm_strip_capacity(cup2d_ctx *ctx, int doubles_per_strip);
 
+/* ---- strips on adapted grids: cell plans (main.cpp:2053-2125 pack with fine->coarse extent, 2582-2684 remote unpack) ----
+ * The ghost blocks of an adapted grid on N ranks travel whole through the plan of cup2d_halo_plan unless the caller also
+ * installs CELL PLANS: for one family of operators, the cells of the sent blocks the receiving rank's kernels actually read.
+ *   CUP2D_CELLS_HALO1   cup2d_laplacian_sub / apply_A / pressure_rhs / pressure_correction / vorticity (one ghost layer: the
+ *                       edge row of a same-level block, two rows of a finer one, four cells of a coarser one)
+ *   CUP2D_CELLS_HALO3   the WENO tile of cup2d_advect_diffuse_rhs / _rk2 (three layers; 3 x 3 coarse cells around the third
+ *                       layer across a coarser side, which reach into that block's tangential neighbour)
+ *   CUP2D_CELLS_MATRIX  the columns of the rank's rows of the Poisson matrix (main.cpp:7034-7112) in ghost blocks: the
+ *                       Krylov vector's exchange, twice per BiCGSTAB iteration
+ * cup2d_amr_trace_reads (host only, no context): which cells those are.  kind / nbr2 / half = tables of cup2d_set_amr over
+ *   `nblocks` blocks in ANY consistent numbering (every rank holds the global leaf list, so: the global one); readers = the
+ *   blocks whose operators are meant; mask[nblocks] receives, OR-ed in, bit (8 iy + ix) of every cell of every OTHER block
+ *   that the readers' kernels (set 0, 1) or matrix rows (set 2) touch.  It runs the kernels' own ghost expressions
+ *   (csrc/amr_ghost.h) and the library's own row assembly with a recording accessor: nothing to keep in step by hand.
+ *   Both ends of a link derive the same list from it -- the receiver with its blocks as readers, the sender with its ghost
+ *   copies of the receiver's blocks as readers -- in (global block, cell) order; no negotiation round.
+ * cup2d_halo_plan_cells: send_cell[nsend] = 64 * owned block + cell, receive_cell[nrecv] = 64 * ghost block + cell (local
+ *   numbering of the context), peers in the order of the block plan.  nsend = nrecv = 0 removes the plan of that set.
+ *   With a plan for a set the exchange callback is called with strip_doubles = CUP2D_CELL_STRIP(set, dim) < 0: the message
+ *   unit is one cell of dim doubles, and the per-peer offsets and counts are those of the set's cell lists
+ *   (cup2d_comm_set_cell_counts tells them to the in-library communicator); device_send / device_recv are the buffers of
+ *   cup2d_set_comm (a cell list never outgrows them: it is a subset of the plan's blocks).  For CUP2D_CELLS_MATRIX the
+ *   gather list of cup2d_set_gather must be the same send list; the received cells are scattered into the vector's ghost
+ *   blocks (columns keep their meaning: 64 * ghost block + cell).
+ * Every operator's result is unchanged to the bit: the cells not delivered are cells no kernel reads. */
+#define CUP2D_CELLS_HALO1 0
+#define CUP2D_CELLS_HALO3 1
+#define CUP2D_CELLS_MATRIX 2
+#define CUP2D_CELL_STRIP(set, dim) (-(16 * (set) + (dim)))
+#define CUP2D_CELL_STRIP_SET(strip_doubles) ((-(strip_doubles)) >> 4)
+#define CUP2D_CELL_STRIP_DIM(strip_doubles) ((-(strip_doubles)) & 15)
+int cup2d_amr_trace_reads(int nblocks, const int32_t *kind, const int32_t *nbr2, const int32_t *half, int nreaders,
+                          const int32_t *readers, int set, uint64_t *mask);
+int cup2d_halo_plan_cells(cup2d_ctx *ctx, int set, int nsend, const int32_t *send_cell, int nrecv, const int32_t *receive_cell);
+/* per peer of cup2d_comm_init (same order): first cell and number of cells in the set's send and receive lists */
+int cup2d_comm_set_cell_counts(cup2d_ctx *ctx, int set, int npeers, const int32_t *send_offset, const int32_t *send_count,
+                               const int32_t *recv_offset, const int32_t *recv_count);
+
 /* ---- penalisation with host-supplied bodies (main.cpp:6643-7006) ----
  * A body is what the reference keeps per shape: for every block the shape touches an Obstacle with the shape's own
  * indicator chi[8][8] and deformation velocity udef[8][8][2] (main.cpp:3283-3286; produced on the host by the shape

@@ -361,6 +361,9 @@ def run_amr_gpu(rank, world):
             assert r["dt"] == rr["dt"], (r, rr)
             dv, dp = np.abs(s.get_field(L.VEL) - vref[own]).max(), np.abs(s.get_field(L.PRES) - pref[own]).max()
             assert dv < 1e-8 and dp < 1e-7, (rank, dv, dp, r, rr)
+            from cup2d_amd.amr_dist import strips_enabled
+            assert (min(s.cell_exchanges) > 0 and s.sent_doubles[0] * 4 <= s.sent_doubles[1]) if strips_enabled() else sum(s.cell_exchanges) == 0, \
+                (s.cell_exchanges, s.sent_doubles)
             # ---- regrid across the ranks = the single-context regrid (same leaves, bit-identical fields) ----
             ref.set_field(L.VEL, F["vel"])
             s.set_field(L.VEL, F["vel"][own])
@@ -384,7 +387,8 @@ def run_amr_cpu(rank, world):
     """the AMR plan in a real exchange (gloo, host tensors): every rank packs the blocks its peers list as ghosts, one
     batched send/receive per peer with the plan's offsets and counts (different in the two directions), and every ghost
     block that arrives is the owner's block of that global id; then the face arrays (4 faces x 8 x dim per sent block) and
-    the two reductions of the AMR step (max, and the {sum, sum} pair of the volume-weighted mean)."""
+    the two reductions of the AMR step (max, and the {sum, sum} pair of the volume-weighted mean); then the three cell plans
+    (what actually travels when a field is refreshed) through the same transport."""
     import torch
     import torch.distributed as dist
     from cup2d_amd.amr import AmrBlockGrid, circle_band_grid
@@ -404,6 +408,22 @@ def run_amr_cpu(rank, world):
             got = cm.recv[:P.nrecv * unit].numpy().reshape(P.nrecv, unit)
             slab[P.recv_block] = got
             assert np.array_equal(slab, field[P.local_ids]), (rank, unit)
+        # the cell plans through the same transport: what arrives in a ghost block are the owner's values of exactly the cells
+        # the plan lists, in the places the kernels read them; every other cell of the ghost blocks is left alone
+        for which, (sc, rc, T) in enumerate(P.cells):
+            for dim, seed in ((1, 11), (2, 12)):
+                field = np.random.default_rng(seed + which).uniform(-1, 1, (nb * 64, dim))
+                slab = np.full(((P.nowned + P.nghost) * 64, dim), np.nan)
+                slab[:P.nowned * 64] = field[P.lo * 64:P.hi * 64]
+                cm.send[:T.nsend * dim] = torch.from_numpy(slab[sc].ravel())
+                cm.exchange(dim, topo=T)
+                cm.wait()
+                slab[rc] = cm.recv[:T.nrecv * dim].numpy().reshape(T.nrecv, dim)
+                want = field.reshape(nb, 64, dim)[P.local_ids].reshape(-1, dim)
+                got_cells = np.zeros(len(slab), dtype=bool)
+                got_cells[rc] = True
+                assert np.array_equal(slab[rc], want[rc]) and np.isnan(slab[P.nowned * 64:][~got_cells[P.nowned * 64:]]).all(), (rank, which, dim)
+            assert T.nsend * 4 <= 64 * P.nsend or which == 1, (which, T.nsend, P.nsend)
         # reductions as the AMR step issues them
         cm.red[0] = float(rank + 1)
         cm.allreduce(0, 1, 1)  # max
@@ -520,6 +540,19 @@ def run_amr_big_gpu(rank, world):
         dv = np.abs(s.get_field(L.VEL) - ref.get_field(L.VEL)[own]).max()
         dp = np.abs(s.get_field(L.PRES) - ref.get_field(L.PRES)[own]).max()
         assert dv < 1e-8 and dp < 1e-6, (rank, dv, dp, r, rr)
+        # ---- what travelled: the cells the kernels read (cell plans), not the blocks ----
+        from cup2d_amd.amr_dist import strips_enabled
+        if strips_enabled():
+            sent, whole = s.sent_doubles
+            assert min(s.cell_exchanges) > 0 and sent * 4 <= whole, (s.cell_exchanges, s.sent_doubles)
+            if rank == 0:
+                P = s.part
+                print("amr_big strips (rank 0): exchanges through the cell plans halo1 / halo3 / matrix = %s, block-plan exchanges (face "
+                      "arrays) = %d; doubles sent %d where whole ghost blocks are %d (1/%.1f); cells per plan %s of %d in the %d sent blocks"
+                      % (s.cell_exchanges, s.block_exchanges, sent, whole, whole / sent, [c[2].nsend for c in P.cells], 64 * P.nsend, P.nsend),
+                      flush=True)
+        else:
+            assert s.part.cells is None and sum(s.cell_exchanges) == 0
         # ---- regrid across the ranks = the single-context regrid ----
         ref.set_field(L.VEL, vel); s.set_field(L.VEL, vel[own])
         ref.vorticity()

@@ -87,18 +87,83 @@ def test_amr_partition_plans_are_consistent(nranks):
         assert P.col.max() < 64 * (P.nowned + P.nghost) and P.row.max() < 64 * P.nowned
         nnz += len(P.val)
     assert nnz == len(coo[2])
+    # ---- the cell plans: both ends of a link list the same cells of the same blocks, inside the block plan ----
+    for which in range(3):
+        for P in parts:
+            sc, rc, T = P.cells[which]
+            assert (sc < 64 * P.nowned).all() and (rc >= 64 * P.nowned).all() and (rc < 64 * (P.nowned + P.nghost)).all()
+            assert [t[0] for t in T.peers] == [t[0] for t in P.peers]
+            for (q, so, ro, ns, nr), (_q, bso, bro, bns, bnr) in zip(T.peers, P.peers):
+                Q = parts[q]
+                qs, qr, QT = Q.cells[which]
+                e = [x for x in QT.peers if x[0] == P.rank][0]
+                assert (ns, nr) == (e[4], e[3])
+                mine = P.local_ids[sc[so:so + ns] // 64] * 64 + sc[so:so + ns] % 64          # global cells I send to q
+                theirs = Q.local_ids[qr[e[2]:e[2] + e[4]] // 64] * 64 + qr[e[2]:e[2] + e[4]] % 64
+                assert np.array_equal(mine, theirs) and (np.diff(mine) > 0).all()
+                assert np.isin(sc[so:so + ns] // 64, P.send_block[bso:bso + bns]).all()
+            if which == L.CELLS_MATRIX:  # exactly the ghost columns of this rank's rows
+                assert np.array_equal(np.unique(P.col[P.col >= 64 * P.nowned]), np.sort(rc))
+                assert np.array_equal(P.gather, sc)
+        cells, blocks = sum(P.cells[which][2].nsend for P in parts), 64 * sum(P.nsend for P in parts)
+        assert cells * (2 if which == L.CELLS_HALO3 else 4) <= blocks, (which, cells, blocks)
+
+
+def test_amr_trace_reads_on_small_grids():
+    """cup2d_amr_trace_reads (the kernels' own ghost expressions with a recording accessor) on grids small enough to count by
+    hand: two same-level blocks; one coarse block next to four fine ones"""
+    import ctypes
+    import numpy as np
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid
+    lib = L.load_library()
+    vp = ctypes.c_void_p
+
+    def trace(G, readers, which):
+        mask = np.zeros(G.nblocks, dtype=np.uint64)
+        k, n, h = (np.ascontiguousarray(a, dtype=np.int32) for a in (G.kind, G.nbr2, G.half))
+        r = np.ascontiguousarray(readers, dtype=np.int32)
+        L.check(lib.cup2d_amr_trace_reads(G.nblocks, k.ctypes.data_as(vp), n.ctypes.data_as(vp), h.ctypes.data_as(vp), len(r), r.ctypes.data_as(vp),
+                                          which, mask.ctypes.data_as(vp)), "trace")
+        return [sorted(c for c in range(64) if int(m) >> c & 1) for m in mask]
+    # two level-0 blocks side by side: (level, i, j)
+    G = AmrBlockGrid(np.array([[0, 0, 0], [0, 1, 0]], dtype=np.int32), bpdx=2, bpdy=1)
+    west_col = lambda depth: sorted(8 * y + x for y in range(8) for x in range(depth))
+    assert trace(G, [0], L.CELLS_HALO1) == [[], west_col(1)]
+    assert trace(G, [0], L.CELLS_HALO3) == [[], west_col(3)]
+    assert trace(G, [0], L.CELLS_MATRIX) == [[], west_col(1)]
+    # the left root block refined once, the right one not
+    G = AmrBlockGrid(np.array([[1, 0, 0], [1, 1, 0], [1, 0, 1], [1, 1, 1], [0, 1, 0]], dtype=np.int32), bpdx=2, bpdy=1)
+    lv = G.blocks[:, 0]
+    coarse = int(np.nonzero(lv == 0)[0][0])
+    fine_e = [b for b in range(G.nblocks) if lv[b] == 1 and G.blocks[b, 1] == 1]  # the two fine blocks that touch the coarse one
+    for which, deep_f, n_c in ((L.CELLS_HALO1, 2, 4), (L.CELLS_HALO3, 6, None), (L.CELLS_MATRIX, 2, None)):
+        m = trace(G, [coarse], which)  # the coarse block reads 2 x 2 means (rows) / the two fine cells (matrix): `deep_f` columns deep
+        # (the kernels never read fine row 1 across a W/E face: the reference's unrolled branch pairs rows 0 and 2 there,
+        # main.cpp:2528-2531 -- the trace knows, because it IS the kernel's expression)
+        rows = range(8) if which == L.CELLS_MATRIX else (0, 2, 3, 4, 5, 6, 7)
+        for b in fine_e:
+            assert m[b] == sorted(8 * y + x for y in rows for x in range(8 - deep_f, 8)), (which, b, m[b])
+        m = trace(G, fine_e[:1], which)  # a fine block reads the coarse block's west column along its half of the face (+ more)
+        col0 = [c for c in m[coarse] if c % 8 == 0]
+        assert len(col0) >= 4 and (n_c is None or len(m[coarse]) == n_c), (which, m[coarse])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world):
-    launch("amr", world, 0, 0, 0, 0, 29811 + world, timeout=900)
+@pytest.mark.parametrize("world,strips", [(2, "1"), (3, "1"), (2, "0")])
+def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world, strips):
+    """strips = "1" (default): the ghost blocks are refreshed through the cell plans -- only the cells the kernels read travel --
+    and start as NaN (CUP2D_POISON_GHOSTS), so a kernel that read a cell no plan delivered could not equal the reference's
+    functors bit for bit; "0": whole blocks through the block plan"""
+    launch("amr", world, 0, 0, 0, 0, 29811 + world + 4 * int(strips), timeout=900, CUP2D_AMR_STRIPS=strips, CUP2D_POISON_GHOSTS="1")
 
 
 @pytest.mark.gpu
-def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu():
-    """the circle-band grid (three levels, Hilbert order) on three ranks: block operators bit for bit, step, regrid"""
-    launch("amr_big", 3, 0, 0, 0, 0, 29831, timeout=900)
+@pytest.mark.parametrize("strips", ["1", "0"])
+def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu(strips):
+    """the circle-band grid (three levels, Hilbert order) on three ranks: block operators bit for bit, step, regrid; with the
+    cell plans (strips) what is sent is at most a quarter of the whole ghost blocks"""
+    launch("amr_big", 3, 0, 0, 0, 0, 29831 + int(strips), timeout=900, CUP2D_AMR_STRIPS=strips, CUP2D_POISON_GHOSTS="1")
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -217,8 +282,9 @@ def test_cpp_mpi_driver_amr_matches_the_single_rank_driver_gpu(tmp_path, world, 
     env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r1 = subprocess.run([one] + common + ["-state", str(tmp_path / "one")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
     assert r1.returncode == 0, r1.stdout.decode()[-3000:]
+    # (the ranks' ghost blocks start as NaN: what the cell plans do not deliver must be what no kernel reads)
     rn = subprocess.run([mpiexec, "-n", str(world), exe] + common + ["-comm", comm, "-state", str(tmp_path / "n")], stdout=subprocess.PIPE,
-                        stderr=subprocess.STDOUT, timeout=900, cwd=ROOT, env=env)
+                        stderr=subprocess.STDOUT, timeout=900, cwd=ROOT, env=dict(env, CUP2D_POISON_GHOSTS="1"))
     out = rn.stdout.decode()
     assert rn.returncode == 0 and "done: 5 steps" in out, out[-3000:]
     s1 = [l.split() for l in r1.stdout.decode().splitlines() if l.startswith("step ")]
@@ -247,7 +313,8 @@ def test_cpp_mpi_driver_amr_matches_the_single_rank_driver_gpu(tmp_path, world, 
 def test_cpp_amr_partition_equals_the_python_plan(tmp_path, world):
     """csrc/cup2d_run_mpi.cpp AmrPart (-planOnly: no GPU) against cup2d_amd/amr_dist.py AmrPartition on the 4 084-block
     three-level grid: ranges, ghost closure (two rings), local topology tables, whole-block links with their offsets and
-    counts per direction, the gather list -- table by table, rank by rank"""
+    counts per direction, the gather list, the three cell plans (which cells of those blocks travel) -- table by table, rank by
+    rank"""
     import shutil
     import numpy as np
     from cup2d_amd import amr as A
@@ -269,3 +336,7 @@ def test_cpp_amr_partition_equals_the_python_plan(tmp_path, world):
         for name in ("level", "kind", "nbr2", "half", "nbr", "send_block", "recv_block", "gather"):
             assert np.array_equal(got(name), np.asarray(getattr(P, name)).ravel()), (rank, name)
         assert got("links").reshape(-1, 5).tolist() == [list(p) for p in P.peers], rank
+        for which in range(3):  # the cell plans: what of those blocks travels, per operator family
+            sc, rc, T = P.cells[which]
+            assert np.array_equal(got("send_cell%d" % which), sc) and np.array_equal(got("recv_cell%d" % which), rc), (rank, which)
+            assert got("cell_links%d" % which).reshape(-1, 5).tolist() == [list(p) for p in T.peers], (rank, which)

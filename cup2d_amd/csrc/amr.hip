@@ -440,18 +440,24 @@ __global__ __launch_bounds__(WG) void k_amr_shift(double *__restrict__ p, const 
 
 // main.cpp:6607-6642 on an adapted grid: vold = vel; two stages of [KernelAdvectDiffuse + flux correction; V = Vold +
 // c tmpV / h^2] (the reference's own un-fused sequence: the face arrays need tmpV)
-int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
+// One stage (cup2d_advect_diffuse_stage on an adapted grid).  Stage 1 saves vel in VOLD and leaves the mid-point velocity in
+// VEL (the reference's own data flow, main.cpp:6607-6626); stage 2 reads both.
+int amr_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage) {
   const AmrDev T = amr_dev(c);
-  const size_t bytes = (size_t)c->nblocks * BC * 2 * sizeof(double);
-  CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_VOLD], c->d_field[CUP2D_VEL], bytes, hipMemcpyDeviceToDevice, c->stream));
-  for (int stage = 0; stage < 2; stage++) {
-    CUP2D_TRY(amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt));
-    hipLaunchKernelGGL(k_amr_axpy<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)c->d_field[CUP2D_VEL],
-                       (const double2 *)c->d_field[CUP2D_VOLD], (const double2 *)c->d_field[CUP2D_TMPV], T, c->nblocks,
-                       stage == 0 ? 0.5 : 1.0);
+  if (stage == 1) {
+    const size_t bytes = (size_t)c->nblocks * BC * 2 * sizeof(double);
+    CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_field[CUP2D_VOLD], c->d_field[CUP2D_VEL], bytes, hipMemcpyDeviceToDevice, c->stream));
   }
+  CUP2D_TRY(amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt));
+  hipLaunchKernelGGL(k_amr_axpy<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)c->d_field[CUP2D_VEL],
+                     (const double2 *)c->d_field[CUP2D_VOLD], (const double2 *)c->d_field[CUP2D_TMPV], T, c->nblocks,
+                     stage == 1 ? 0.5 : 1.0);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
+}
+int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt) {
+  CUP2D_TRY(amr_advect_diffuse_stage(c, nu, dt, 1));
+  return amr_advect_diffuse_stage(c, nu, dt, 2);
 }
 // main.cpp:7007-7027: tmp = pressure_rhs (+ flux correction); pold = pres; pres = 0; tmp -= Lap(pold) (+ flux correction)
 int amr_poisson_rhs(cup2d_ctx *c, double dt) {

@@ -718,11 +718,6 @@ int cup2d_amr_set_finest_level(cup2d_ctx *c, int level_finest) {
   c->amr.h_min = c->amr.h0 / (double)(1 << level_finest);
   return CUP2D_OK;
 }
-#define AMR_UNSUPPORTED(c)                                                                      \
-  if ((c)->amr.active) {                                                                        \
-    set_error("%s: not built for adapted grids yet (cup2d_set_amr is active)", __func__);       \
-    return CUP2D_ERR_UNSUPPORTED;                                                               \
-  }
 #define AMR_ALL_BLOCKS(c, phase)                                                                \
   if ((c)->amr.active && (phase) != CUP2D_BLOCKS_ALL) {                                         \
     set_error("%s: adapted grids take CUP2D_BLOCKS_ALL", __func__);                             \
@@ -740,9 +735,13 @@ int cup2d_advect_diffuse_rhs(cup2d_ctx *c, double nu, double dt, int phase) {
 }
 int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, int phase) {
   CUP2D_CHECK_CTX(c);
-  AMR_UNSUPPORTED(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
+  if (c->amr.active) {  // the reference's un-fused stage (flux correction between the functor and the update)
+    AMR_ALL_BLOCKS(c, phase);
+    if (stage != 1 && stage != 2) { set_error("advect_diffuse_stage: stage %d", stage); return CUP2D_ERR_ARG; }
+    return amr_advect_diffuse_stage(c, nu, dt, stage);
+  }
   const double ih2 = 1.0 / (c->h * c->h);
   if (stage == 1)  // main.cpp:6616-6626: mid = vel + (0.5/h^2) rhs(vel)
     return launch_advect(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_VEL], c->d_vscratch, 1, nu, dt, 0.5 / (c->h * c->h),
@@ -884,14 +883,22 @@ int cup2d_compute_dt(cup2d_ctx *c, double nu, double cfl, double *dt) {
 }
 
 // ---- Poisson ----------------------------------------------------------------------------------
+// An adapted grid solves with the operator of main.cpp:7034-7112.  A caller that has not installed one gets the library's own
+// assembly from the topology tables (cup2d_amr_install_poisson: stored rows only where the grid is irregular) -- on one rank;
+// on N ranks the gather list of the exchange is the caller's to give (cup2d_set_gather), so nothing can be installed for it.
+static int amr_operator_ready(cup2d_ctx *c, const char *who) {
+  if (!c->amr.active || c->mat.active) return CUP2D_OK;
+  if (c->nghost > 0) {
+    set_error("%s: adapted grid on N ranks without an operator: cup2d_amr_install_poisson (or cup2d_set_matrix_coo) and cup2d_set_gather first", who);
+    return CUP2D_ERR_UNSUPPORTED;
+  }
+  return cup2d_amr_install_poisson(c);
+}
 int cup2d_poisson_solve(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                         int *restarts, double *linf, double *linf_init) {
   CUP2D_CHECK_CTX(c);
   if (max_iter < 0) { set_error("poisson_solve: max_iter"); return CUP2D_ERR_ARG; }
-  if (c->amr.active && !c->mat.active) {
-    set_error("poisson_solve: on an adapted grid install the assembled operator (cup2d_set_matrix_coo)");
-    return CUP2D_ERR_UNSUPPORTED;
-  }
+  CUP2D_TRY(amr_operator_ready(c, "poisson_solve"));
   c->last_solver = (c->solver == CUP2D_SOLVER_FUSED && fused_supported(c)) ? CUP2D_SOLVER_FUSED : CUP2D_SOLVER_SWEEPS;
   if (c->last_solver == CUP2D_SOLVER_FUSED)
     return solve_fused_impl(c, max_error, max_rel_error, max_restarts, max_iter, iters, restarts, linf, linf_init);
@@ -1261,10 +1268,7 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
 int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
                int max_iter, double *dt_out, int *iters, double *linf) {
   CUP2D_CHECK_CTX(c);
-  if (c->amr.active && !c->mat.active) {
-    set_error("step: on an adapted grid install the assembled Poisson operator first (cup2d_set_matrix_coo)");
-    return CUP2D_ERR_UNSUPPORTED;
-  }
+  CUP2D_TRY(amr_operator_ready(c, "step"));
   // the previous call on this context was a cup2d_step that left max|u| of its result behind (ctx.h)
   c->use_cached_umax = !c->amr.active && !c->vel_ptr_exposed && c->umax_partials > 0 && c->api_calls == c->umax_valid_at + 1;
   double dt = 0;

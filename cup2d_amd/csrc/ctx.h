@@ -366,6 +366,7 @@ int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, doub
 int amr_vorticity(cup2d_ctx *c, const double *vel, double *out);
 int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt);
 int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt);
+int amr_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage);
 int amr_poisson_rhs(cup2d_ctx *c, double dt);
 int amr_project(cup2d_ctx *c, double dt);
 int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt);

@@ -192,6 +192,7 @@ int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim) {
   if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
   const CellPlan &P = c->cells[set];
   if (!P.active) { set_error("exchange_cells: no cell plan %d", set); return CUP2D_ERR_ARG; }
+  if (!c->d_send || !c->d_recv) { set_error("exchange_cells: a cell plan needs both buffers of cup2d_set_comm"); return CUP2D_ERR_ARG; }
   const auto grid_for_n = [&](size_t total) {
     int g = (int)((total + WG - 1) / WG);
     return g > c->grid ? c->grid : (g < 1 ? 1 : g);

@@ -626,6 +626,7 @@ int matrix_exchange(cup2d_ctx *c, double *vec) {
   // are scattered into the vector's ghost blocks -- the columns of the rows keep their meaning
   const CellPlan &CP = c->cells[CUP2D_CELLS_MATRIX];
   if (CP.active) {
+    if (!c->d_recv) { set_error("matrix_exchange: a cell plan needs the receive buffer of cup2d_set_comm"); return CUP2D_ERR_ARG; }
     if (M.ngather != CP.nsend) { set_error("matrix_exchange: the gather list (%d) is not the cell plan's send list (%d)", M.ngather, CP.nsend); return CUP2D_ERR_ARG; }
     if (c->exchange(c->comm_user, c->d_send, c->d_recv, CUP2D_CELL_STRIP(CUP2D_CELLS_MATRIX, 1), c->stream) != 0) {
       set_error("exchange callback failed (matrix cells)");

@@ -249,8 +249,12 @@ int cup2d_matrix_stats(cup2d_ctx *ctx, int *plain_blocks, int *general_tile_bloc
  * cup2d_laplacian_sub, cup2d_apply_A, cup2d_pressure_rhs, cup2d_poisson_rhs, cup2d_pressure_correction,
  * cup2d_project (volume-weighted means), cup2d_vorticity, cup2d_compute_dt (finest h), and cup2d_poisson_solve /
  * cup2d_step once the caller's coarse-fine matrix rows are installed with cup2d_set_matrix_coo (main.cpp:7034-7113).
- * phase must be CUP2D_BLOCKS_ALL; the nbr table of cup2d_create is ignored.  Not built for adapted grids yet (they
- * return CUP2D_ERR_UNSUPPORTED): the fused RK-stage kernels (cup2d_advect_diffuse_stage), the matrix-free solve. */
+ * phase must be CUP2D_BLOCKS_ALL; the nbr table of cup2d_create is ignored.  cup2d_advect_diffuse_stage runs one stage of
+ * that un-fused sequence (stage 1: VOLD = vel, then the mid-point velocity is left in VEL -- not in a scratch slab as on a
+ * uniform grid; stage 2: vel = VOLD + rhs(vel) / h^2; TMPV holds the stage's rhs; stages 1 + 2 = cup2d_advect_diffuse_rk2 to
+ * the bit).  cup2d_poisson_solve / cup2d_step without an installed operator: on one rank the library assembles the rows from
+ * these tables itself (cup2d_amr_install_poisson: plain same-level blocks stay matrix-free, stored rows only where the grid is
+ * irregular); on N ranks they return CUP2D_ERR_UNSUPPORTED until the operator and the gather list are installed. */
 typedef enum { CUP2D_AMR_WALL = 0, CUP2D_AMR_SAME = 1, CUP2D_AMR_COARSER = 2, CUP2D_AMR_FINER = 3 } cup2d_amr_kind;
 int cup2d_set_amr(cup2d_ctx *ctx, double h0, const int32_t *level, const int32_t *kind, const int32_t *nbr2,
                   const int32_t *half);
@@ -441,7 +445,8 @@ int cup2d_set_comm_strip_capacity(cup2d_ctx *ctx, int doubles_per_strip);
  *   Both ends of a link derive the same list from it -- the receiver with its blocks as readers, the sender with its ghost
  *   copies of the receiver's blocks as readers -- in (global block, cell) order; no negotiation round.
  * cup2d_halo_plan_cells: send_cell[nsend] = 64 * owned block + cell, receive_cell[nrecv] = 64 * ghost block + cell (local
- *   numbering of the context), peers in the order of the block plan.  nsend = nrecv = 0 removes the plan of that set.
+ *   numbering of the context), peers in the order of the block plan.  nsend = nrecv = 0 removes the plan of that set; so
+ *   does a new cup2d_halo_plan (the cell lists are subsets of its blocks: install them after it).
  *   With a plan for a set the exchange callback is called with strip_doubles = CUP2D_CELL_STRIP(set, dim) < 0: the message
  *   unit is one cell of dim doubles, and the per-peer offsets and counts are those of the set's cell lists
  *   (cup2d_comm_set_cell_counts tells them to the in-library communicator); device_send / device_recv are the buffers of

@@ -687,18 +687,63 @@ def test_cpp_host_driver_amr_run_matches_python_gpu(gpu_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_amr_rk_stages_one_by_one_equal_the_rk2_entry_gpu(gpu_lib):
+    """cup2d_advect_diffuse_stage on an adapted grid (the reference's un-fused stage, main.cpp:6607-6642): stage 1 leaves vel in
+    VOLD and the mid-point velocity in VEL, stages 1 + 2 = cup2d_advect_diffuse_rk2 bit for bit"""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    dt = float(F["dt"])
+    for strict in (True, False):
+        with AmrSimulation(AmrBlockGrid(F["blocks"]), nu=float(F["nu"])) as s:
+            s.set_math(strict)
+            s.set_field(L.VEL, F["vel"])
+            L.check(s.L.cup2d_advect_diffuse_rk2(s._ctx, s.nu, dt), "rk2")
+            want = s.get_field(L.VEL)
+            s.set_field(L.VEL, F["vel"])
+            L.check(s.L.cup2d_advect_diffuse_stage(s._ctx, s.nu, dt, 1, L.BLOCKS_ALL), "stage 1")
+            assert np.array_equal(s.get_field(L.VOLD), F["vel"])
+            mid = s.get_field(L.VEL)
+            assert not np.array_equal(mid, F["vel"]) and not np.array_equal(mid, want)
+            L.check(s.L.cup2d_advect_diffuse_stage(s._ctx, s.nu, dt, 2, L.BLOCKS_ALL), "stage 2")
+            assert np.array_equal(s.get_field(L.VEL), want)
+
+
+@pytest.mark.gpu
 def test_amr_unsupported_entry_points_say_so(gpu_lib):
     import ctypes
     from cup2d_amd import lib as L
     from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
     F = golden("amr_functors.npz")
     with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
-        assert s.L.cup2d_step(s._ctx, 1e-3, 0.5, 0.0, 0.0, 10, 10, None, None, None) == -4  # no assembled operator yet
-        assert b"adapted" in s.L.cup2d_last_error()
-        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 1, L.BLOCKS_ALL) == -4  # the fused RK stage kernels
-        it = ctypes.c_int()
-        assert s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 10, 10, ctypes.byref(it), None, None, None) == -4
+        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 3, L.BLOCKS_ALL) == -1  # a stage that does not exist
+        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 1, L.BLOCKS_INNER) == -1
         assert s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER) == -1  # CUP2D_ERR_ARG: adapted grids take all blocks
+
+
+@pytest.mark.gpu
+def test_amr_solve_without_an_installed_operator_assembles_its_own_gpu(gpu_lib):
+    """cup2d_poisson_solve on an adapted grid whose caller installed no matrix: the library assembles the operator of
+    main.cpp:7034-7112 from the topology tables -- the same solve, bit for bit, as after an explicit install of the triplets"""
+    import ctypes
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    G = AmrBlockGrid(F["blocks"])
+    b = np.random.default_rng(3).uniform(-1, 1, (G.nblocks, 64))
+    b -= b.mean()
+    out = []
+    for explicit in (False, True):
+        with AmrSimulation(G) as s:
+            if explicit:
+                s.install_poisson_matrix(via_triplets=True)
+            s.set_field(L.TMP, b)
+            s.set_field(L.PRES, np.zeros((G.nblocks, 64)))
+            it, err = ctypes.c_int(), ctypes.c_double()
+            L.check(s.L.cup2d_poisson_solve(s._ctx, 0.0, 0.0, 100, 40, ctypes.byref(it), None, ctypes.byref(err), None), "poisson_solve")
+            assert it.value == 40 and np.isfinite(err.value)
+            out.append((s.get_field(L.PRES), err.value))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
 
 
 def _penalize_numpy(vel, CHI, blocks_idx, origin, h, chi, udef, centre, lam, dt):

@@ -83,6 +83,66 @@ def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_cell_plan_through_rccl_to_self(gpu_lib):
+    """cup2d_halo_plan_cells + cup2d_comm_set_cell_counts with real ncclSend / ncclRecv (the rank is its own W and E neighbour):
+    the patch is given topology tables (cup2d_set_amr: every block on level 0, the x sides of the edge blocks same-level
+    neighbours of the ghost blocks), so its operators run the adapted-grid kernels and refresh their ghost blocks through the
+    cell plan of the halo-1 family -- the 8 edge cells of a ghost block travel, the other 56 stay NaN -- and Lap(p) of the
+    x-periodic field comes out bit for bit"""
+    import os
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    nbx, nby = 6, 5
+    s, g = _self_periodic_sim(nbx, nby)
+    hip = _hip()
+    vp = ctypes.c_void_p
+    nb, ng = g.nblocks, g.nghost
+    with s:
+        kind = np.zeros((nb + ng, 4), dtype=np.int32)                      # ghost blocks: sides nobody reads (walls)
+        nbr2 = -np.ones((nb + ng, 4, 2), dtype=np.int32)
+        kind[:nb] = np.where(g.nbr >= 0, L.AMR_SAME, L.AMR_WALL)
+        nbr2[:nb, :, 0] = g.nbr
+        level, half = np.zeros(nb + ng, dtype=np.int32), np.zeros((nb + ng, 4), dtype=np.int32)
+        L.check(s.L.cup2d_set_amr(s.ctx, s.h, level.ctypes.data_as(vp), kind.ctypes.data_as(vp), nbr2.ctypes.data_as(vp),
+                                  half.ctypes.data_as(vp)), "set_amr")
+        # what the kernels read of the ghost blocks, from the library's own trace: the column that touches the patch
+        mask = np.zeros(nb + ng, dtype=np.uint64)
+        readers = np.arange(nb, dtype=np.int32)
+        L.check(s.L.cup2d_amr_trace_reads(nb + ng, kind.ctypes.data_as(vp), nbr2.ctypes.data_as(vp), half.ctypes.data_as(vp), nb,
+                                          readers.ctypes.data_as(vp), L.CELLS_HALO1, mask.ctypes.data_as(vp)), "trace")
+        col = lambda x: sum(1 << (8 * y + x) for y in range(8))
+        for gi, (side, pos) in enumerate(g.ghost_coords):  # the W ghost is read at its east column, the E ghost at its west one
+            assert int(mask[nb + gi]) == col(7 if side == 0 else 0)
+        # send list in the order of the block plan (W edge blocks, then E edge blocks); receive list: W ghosts, then E ghosts
+        send = [64 * int(g.index_of[pos, 0 if side == 0 else nbx - 1]) + 8 * y + (0 if side == 0 else 7)
+                for side in (0, 1) for pos in range(nby) for y in range(8)]
+        recv = [64 * int(g._ghost_id[(side, pos)]) + 8 * y + (7 if side == 0 else 0) for side in (0, 1) for pos in range(nby) for y in range(8)]
+        sc, rc = np.asarray(send, dtype=np.int32), np.asarray(recv, dtype=np.int32)
+        L.check(s.L.cup2d_halo_plan_cells(s.ctx, L.CELLS_HALO1, len(sc), sc.ctypes.data_as(vp), len(rc), rc.ctypes.data_as(vp)), "halo_plan_cells")
+        n8 = 8 * nby
+        soff, roff, cnt = (np.asarray(a, dtype=np.int32) for a in ([n8, 0], [0, n8], [n8, n8]))  # as the block plan pairs them
+        assert s.L.cup2d_comm_set_cell_counts(s.ctx, L.CELLS_HALO1, 1, soff.ctypes.data_as(vp), cnt.ctypes.data_as(vp), roff.ctypes.data_as(vp),
+                                              cnt.ctypes.data_as(vp)) == -1  # one entry per peer of cup2d_comm_init: two here
+        L.check(s.L.cup2d_comm_set_cell_counts(s.ctx, L.CELLS_HALO1, 2, soff.ctypes.data_as(vp), cnt.ctypes.data_as(vp), roff.ctypes.data_as(vp),
+                                               cnt.ctypes.data_as(vp)), "comm_set_cell_counts")
+        rng = np.random.default_rng(5)
+        p, t = rng.uniform(-1, 1, (g.ny, g.nx)), rng.uniform(-1, 1, (g.ny, g.nx))
+        s.set_field(L.POLD, p)
+        s.set_field(L.TMP, t)
+        nan = np.full((ng, 64), np.nan)  # ghost copies of POLD start as NaN: only what the plan delivers can be a number
+        base = ctypes.c_void_p(s.field_ptr(L.POLD) + nb * 64 * 8)
+        assert hip.hipMemcpy(base, nan.ctypes.data, nan.nbytes, 1) == 0
+        s.laplacian_sub()
+        W, E = np.roll(p, 1, axis=1), np.roll(p, -1, axis=1)                 # periodic in x
+        S, N = np.vstack([p[:1], p[:-1]]), np.vstack([p[1:], p[-1:]])          # walls in y: ghost = edge cell
+        assert np.array_equal(s.get_field(L.TMP), t - ((((W + E) + S) + N) - 4 * p))
+        slab = np.zeros((nb + ng, 64))
+        assert hip.hipMemcpy(slab.ctypes.data, s.field_ptr(L.POLD), slab.nbytes, 2) == 0
+        got = np.isfinite(slab[nb:])
+        assert got.sum() == 8 * ng and all(got[gi].reshape(8, 8)[:, 7 if side == 0 else 0].all() for gi, (side, pos) in enumerate(g.ghost_coords))
+        L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fused", [True, False])
 def test_one_rank_through_the_communicator_equals_the_plain_context(gpu_lib, oracle, fused, tmp_path):
     """world = 1 under torch.distributed (gloo carries the token): every reduction goes through ncclAllReduce /

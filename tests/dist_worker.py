@@ -535,7 +535,11 @@ def run_amr_big_gpu(rank, world):
             sim.set_field(L.TMPV, np.zeros((n, 64, 2)))
             sim.install_poisson_matrix()
         rr = ref.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=1000)
+        import time
+        dist.barrier()
+        t_step = time.perf_counter()
         r = s.step(tol=1e-10, rel_tol=0.0, max_restarts=100, max_iter=1000)
+        t_step = time.perf_counter() - t_step
         assert r["dt"] == rr["dt"] and s.last_solver() == ref.last_solver() == "fused", (r, rr)
         dv = np.abs(s.get_field(L.VEL) - ref.get_field(L.VEL)[own]).max()
         dp = np.abs(s.get_field(L.PRES) - ref.get_field(L.PRES)[own]).max()
@@ -575,7 +579,9 @@ def run_amr_big_gpu(rank, world):
         assert np.isfinite(r2["err"]) and r2["err"] <= 1e-9
         assert not s.comm_errors, s.comm_errors
         if rank == 0:
-            print("amr_big: %d blocks on %d ranks; step dv %.1e dp %.1e; regrid -> %d blocks" % (nb, world, dv, dp, len(blocks_ref)), flush=True)
+            print("amr_big: %d blocks on %d ranks; step dv %.1e dp %.1e (%d iterations, %.0f ms on rank 0: ranks share the GPU, host-staged "
+                  "gloo, strips %s); regrid -> %d blocks" % (nb, world, dv, dp, r["iters"], 1e3 * t_step, os.environ.get("CUP2D_AMR_STRIPS", "1"),
+                                                            len(blocks_ref)), flush=True)
     dist.barrier()
 
 

@@ -363,12 +363,21 @@ def amr_leg(args, device):
             beat("amr regrid %d" % k)
         warm = sorted(regrids[1:], key=lambda r: r["ms"])[1]
         t_adapt, changed, nb_after, stages = warm["ms"] * 1e-3, warm["changed"], warm["blocks_after"], warm["stages_ms"]
+    # what a rank of configs[4]'s 8-rank run exchanges on this grid (the plan alone: host code, no second GPU here)
+    from cup2d_amd.amr_dist import AmrPartition
+    P = AmrPartition(g, 8, 0)
+    plan8 = {"rank": 0, "owned_blocks": P.nowned, "ghost_blocks": P.nghost, "sent_blocks": P.nsend, "peers": len(P.peers),
+             "cells_sent_per_refresh": {n: int(c[2].nsend) for n, c in zip(L.CELL_SET_NAMES, P.cells)},
+             "cells_of_the_sent_blocks": 64 * P.nsend,
+             "what": "contiguous Hilbert ranges on 8 ranks (main.cpp:6494-6504); a refresh of ghost blocks sends the cells the receiver's "
+                     "kernels read (cup2d_halo_plan_cells; found by tracing the kernels' own ghost expressions), not whole blocks: "
+                     "matrix = the Krylov vector, twice per BiCGSTAB iteration.  Plan only -- one GPU per box"}
     return {"workload": "three-level block-AMR grid, finest level %d^2-equivalent in a band around a circle; same step, %d BiCGSTAB "
                         "iters on the assembled coarse-fine operator" % (8 << args.amr_lfine, args.iters),
             "blocks": g.nblocks, "cells": g.nblocks * 64, "blocks_per_level": np.bincount(g.blocks[:, 0]).tolist(),
             "value": round(g.nblocks * 64 / el / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_step": round(el * 1e3, 3),
             "iters": r["iters"], "solver": solver, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
-            "grid_build_ms": round(t_grid * 1e3, 1),
+            "grid_build_ms": round(t_grid * 1e3, 1), "plan_on_8_ranks": plan8,
             "regrid": {"changed": bool(changed), "blocks_before": warm["blocks_before"], "blocks_after": nb_after,
                        "ms": round(t_adapt * 1e3, 1), "first_ms": regrids[0]["ms"], "all": regrids,
                        "stages_ms": stages,

@@ -285,6 +285,7 @@ int launch_max_abs(cup2d_ctx *c, const double *v, size_t n, double *d_out);
 int launch_block_linf(cup2d_ctx *c, const double *f, double *d_out);
 int launch_precond(cup2d_ctx *c, const double *in, double *out, int first, int count);
 int launch_precond_add(cup2d_ctx *c, const double *y, double *x, double *tmp);
+bool launch_final_x_on_device(cup2d_ctx *c, const double *y0, const double *y1, const double *y2, double *x, bool x0_zero);
 int launch_matvec(cup2d_ctx *c, double *x, double *y);  // y = A x through the installed SellMatrix
 // Device memory of a context comes from a per-process pool (api.hip): cup2d_destroy / cup2d_clear_matrix / a new
 // cup2d_set_amr hand their buffers back, the next context -- after every regrid a host builds one -- takes them again

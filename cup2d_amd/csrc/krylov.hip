@@ -139,6 +139,44 @@ __global__ __launch_bounds__(WG) void k_precond_fd(const double *__restrict__ in
   }
 }
 
+// The fused solver's last step x = x0 + P_inv y_opt (cuda.cu:546-547) with the choice of y_opt -- which of the three y buffers
+// holds the best iterate, or none of them when no iterate beat x0 -- read from the scalars ON THE DEVICE: the host does not
+// have to wait for the solve to end before it can enqueue this launch (and whatever follows the solve in a step).
+template <bool ADD>
+__global__ __launch_bounds__(WG) void k_final_x_fd(const double *__restrict__ y0, const double *__restrict__ y1,
+                                                   const double *__restrict__ y2, double *__restrict__ out,
+                                                   const double *__restrict__ fd, const KrylovScalars *__restrict__ sc, int count) {
+  __shared__ double buf[WPG][2][BC];
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ix = lane & 7, iy = lane >> 3;
+  const int best = sc->ybest;
+  const bool keep_x0 = sc->best_is_x0 != 0;  // x = x0: nothing to add (ADD), zero (x0 = 0 and known to be)
+  if (keep_x0 && ADD) return;
+  const double *__restrict__ in = best == 0 ? y0 : (best == 1 ? y1 : y2);
+  FdBasis B;
+  B.load(fd, ix, iy);
+  const GroupRange gr = group_range(count);
+  for (int g = gr.begin; g < gr.end; g += gr.stride) {
+    const int rel = g * WPG + wave;
+    if (rel < count) {
+      const size_t o = (size_t)rel * BC + lane;
+      if (keep_x0) { out[o] = 0.0; continue; }  // (wave-uniform)
+      const double z = precond_fd(in[o], B, buf[wave][0], buf[wave][1], ix, iy, lane);
+      out[o] = ADD ? out[o] + z : z;
+    }
+  }
+}
+// true if it was launched: the built-in preconditioner in its fast-diagonalisation form (the default)
+bool launch_final_x_on_device(cup2d_ctx *c, const double *y0, const double *y1, const double *y2, double *x, bool x0_zero) {
+  if (c->precond != PRECOND_FD) return false;
+  const int nb = c->nblocks;
+  if (x0_zero)
+    hipLaunchKernelGGL(k_final_x_fd<false>, dim3(grid_for(c, nb)), dim3(WG), 0, c->stream, y0, y1, y2, x, c->d_fd, c->d_sc, nb);
+  else
+    hipLaunchKernelGGL(k_final_x_fd<true>, dim3(grid_for(c, nb)), dim3(WG), 0, c->stream, y0, y1, y2, x, c->d_fd, c->d_sc, nb);
+  return true;
+}
+
 // sweep A, fast-diagonalisation preconditioner; the next block's p, nu, r are in flight while the
 // current block is transformed
 __global__ __launch_bounds__(WG) void k_sweepA_fd(double *__restrict__ p, const double *__restrict__ nu,

@@ -1547,6 +1547,17 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = true;
+  // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt.  Which buffer holds y_opt is in the scalars: the launch reads it there,
+  // so it is enqueued behind the last iteration without the host having seen the solve end (one wait per solve instead of two;
+  // a caller that asked for the last iterate takes the host's route below).  Enqueued BEFORE the copies of the scalars: a
+  // copy into pageable memory (edge_fault) may hold the host until it has happened
+  const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
+  bool x_done = false;
+  if (!c->keep_last) {
+    ProfScope prof(c, CUP2D_T_FINAL_X);
+    x_done = launch_final_x_on_device(c, ybuf[0], ybuf[1], ybuf[2], x, x0_zero);
+    CUP2D_HIP_CHECK(hipGetLastError());
+  }
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
   int edge_fault = 0;
   CUP2D_HIP_CHECK(hipMemcpyAsync(&edge_fault, c->d_fault, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1556,8 +1567,6 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     set_error("poisson_solve: the edge-form sweep lost a hand-over between sibling waves (CUP2D_EDGE_SHARE=0 avoids the path)");
     return CUP2D_ERR_HIP;
   }
-  // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt
-  const double *ybuf[3] = {c->d_y, c->d_yopt, c->d_xopt};  // k_sweepE_y's three buffers
   const double *ybest = ybuf[c->h_sc->ybest];
   c->have_last = false;
   if (c->keep_last) {  // the last iterate x0 + P_inv y, for cup2d_solver_last_iterate (before x0 in PRES is overwritten)
@@ -1573,7 +1582,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     }
     c->have_last = true;
   }
-  {
+  if (!x_done) {
     ProfScope prof(c, CUP2D_T_FINAL_X);
     if (c->h_sc->best_is_x0) {  // the initial guess is the answer: x = x0
       if (x0_zero) CUP2D_TRY(launch_zero(c, x, n));
@@ -1582,8 +1591,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     } else {
       CUP2D_TRY(launch_precond_add(c, ybest, x, c->d_s));
     }
+    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   }
-  CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   if (iters) *iters = c->h_sc->iter;
   if (restarts) *restarts = c->h_sc->restarts;
   if (linf) *linf = c->h_sc->err_opt;

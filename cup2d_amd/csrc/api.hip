@@ -1292,10 +1292,14 @@ int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max
   } else {
     CUP2D_TRY(cup2d_poisson_rhs(c, dt, 0));
   }
+  c->solve_tail = [](cup2d_ctx *cc, double dt_) { return cup2d_project(cc, dt_); };
+  c->solve_tail_arg = dt;
+  c->solve_tail_ran = false;
   const int rc_solve = cup2d_poisson_solve(c, max_error, max_rel_error, max_restarts, max_iter, iters, nullptr, linf, nullptr);
   c->x0_is_zero = false;
+  c->solve_tail = nullptr;
   CUP2D_TRY(rc_solve);
-  CUP2D_TRY(cup2d_project(c, dt));
+  if (!c->solve_tail_ran) CUP2D_TRY(cup2d_project(c, dt));  // (solvers that wait for their end before the last pass)
   c->umax_valid_at = c->api_calls;  // (umax_partials > 0 only if the same-level projection kernel wrote them)
   if (dt_out) *dt_out = dt;
   return CUP2D_OK;

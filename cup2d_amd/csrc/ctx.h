@@ -176,6 +176,12 @@ struct cup2d_ctx {
   static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)
   bool keep_last = false, have_last = false;  // cup2d_solver_keep_last: the solve leaves its LAST iterate in d_z
   bool x0_is_zero = false;               // set by cup2d_step around its solve: the initial guess is zero, PRES is not read
+  // set by cup2d_step around its solve: what follows the solve in the step (the projection).  The fused solver enqueues it
+  // right behind its last pass, BEFORE it waits for the solve to end and reads the iteration count -- the stream has the
+  // projection's launches by the time the solve's last kernel retires (solve_tail_ran tells the step that it happened)
+  int (*solve_tail)(cup2d_ctx *, double) = nullptr;
+  double solve_tail_arg = 0.0;
+  bool solve_tail_ran = false;
   // max|u| of the velocity a cup2d_step leaves behind: its projection kernel writes per-workgroup maxima (slot 3 of
   // d_partials) and the NEXT cup2d_step takes its dt from them instead of reading the field again -- valid only if that
   // step is the very next call on the context (every entry point counts itself in api_calls) and nobody holds a raw

@@ -1558,6 +1558,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     x_done = launch_final_x_on_device(c, ybuf[0], ybuf[1], ybuf[2], x, x0_zero);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
+  if (x_done && c->solve_tail) {  // cup2d_step: the projection, enqueued while the solve's last launches still run
+    c->solve_tail_ran = true;
+    CUP2D_TRY(c->solve_tail(c, c->solve_tail_arg));
+  }
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
   int edge_fault = 0;
   CUP2D_HIP_CHECK(hipMemcpyAsync(&edge_fault, c->d_fault, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -1340,7 +1340,9 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
 }
 int cup2d_halo_plan_cells(cup2d_ctx *c, int set, int nsend, const int32_t *sc, int nrecv, const int32_t *rc) {
   CUP2D_CHECK_CTX(c);
-  if (set < 0 || set >= cup2d::CELL_SETS || nsend < 0 || nrecv < 0 || (nsend && !sc) || (nrecv && !rc)) return CUP2D_ERR_ARG;
+  const bool remove = nsend == -1 && nrecv == -1;
+  if (set < 0 || set >= cup2d::CELL_SETS || (!remove && (nsend < 0 || nrecv < 0 || (nsend && !sc) || (nrecv && !rc)))) return CUP2D_ERR_ARG;
+  if (remove) nsend = nrecv = 0;
   // a cell list is a subset of the block plan's blocks: the communicator's buffers are sized by that plan
   if ((long long)nsend > (long long)c->plan.nsend * BC || (long long)nrecv > (long long)c->plan.nrecv * BC) {
     set_error("halo_plan_cells: %d / %d cells exceed the block plan (%d / %d blocks)", nsend, nrecv, c->plan.nsend, c->plan.nrecv);
@@ -1354,7 +1356,9 @@ int cup2d_halo_plan_cells(cup2d_ctx *c, int set, int nsend, const int32_t *sc, i
   cup2d::CellPlan &P = c->cells[set];
   dev_free(P.d_send); dev_free(P.d_recv);
   P = cup2d::CellPlan();
-  if (nsend == 0 && nrecv == 0) return CUP2D_OK;
+  if (remove) return CUP2D_OK;
+  // (an EMPTY plan is a plan: this rank then sends and receives nothing for the set, while its peers exchange cells among
+  // themselves -- falling back to whole blocks here would post messages nobody waits for)
   P.nsend = nsend; P.nrecv = nrecv;
   if (nsend) {
     CUP2D_HIP_CHECK(dev_malloc(&P.d_send, nsend * sizeof(int32_t)));

@@ -445,8 +445,9 @@ int cup2d_set_comm_strip_capacity(cup2d_ctx *ctx, int doubles_per_strip);
  *   Both ends of a link derive the same list from it -- the receiver with its blocks as readers, the sender with its ghost
  *   copies of the receiver's blocks as readers -- in (global block, cell) order; no negotiation round.
  * cup2d_halo_plan_cells: send_cell[nsend] = 64 * owned block + cell, receive_cell[nrecv] = 64 * ghost block + cell (local
- *   numbering of the context), peers in the order of the block plan.  nsend = nrecv = 0 removes the plan of that set; so
- *   does a new cup2d_halo_plan (the cell lists are subsets of its blocks: install them after it).
+ *   numbering of the context), peers in the order of the block plan.  nsend = nrecv = -1 removes the plan of that set; so
+ *   does a new cup2d_halo_plan (the cell lists are subsets of its blocks: install them after it).  Empty lists (0, 0) are a
+ *   plan like any other: every rank of a run installs the set or none does.
  *   With a plan for a set the exchange callback is called with strip_doubles = CUP2D_CELL_STRIP(set, dim) < 0: the message
  *   unit is one cell of dim doubles, and the per-peer offsets and counts are those of the set's cell lists
  *   (cup2d_comm_set_cell_counts tells them to the in-library communicator); device_send / device_recv are the buffers of

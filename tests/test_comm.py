@@ -31,6 +31,17 @@ def test_comm_argument_checks_without_a_gpu():
     assert lib.cup2d_comm_selftest(None, 1.0, None, 0) == -1
     assert lib.cup2d_halo_exchange(None, L.VEL, 3) == -1
     assert lib.cup2d_comm_stats(None, None, None, None, None, None) == -1
+    assert lib.cup2d_halo_plan_cells(None, 0, 0, None, 0, None) == -1 and lib.cup2d_comm_set_cell_counts(None, 0, 0, None, None, None, None) == -1
+    # the trace of the kernels' ghost reads is host code: bad tables, sets and readers are refused
+    import numpy as np
+    k, n2, h = np.zeros((2, 4), dtype=np.int32), -np.ones((2, 4, 2), dtype=np.int32), np.zeros((2, 4), dtype=np.int32)
+    mask, rd = np.zeros(2, dtype=np.uint64), np.asarray([0, 5], dtype=np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.cup2d_amr_trace_reads(2, P(k), P(n2), P(h), 1, P(rd), 3, P(mask)) == -1   # no such set
+    assert lib.cup2d_amr_trace_reads(2, P(k), P(n2), P(h), 2, P(rd), 0, P(mask)) == -1 and b"readers[1]" in lib.cup2d_last_error()
+    assert lib.cup2d_amr_trace_reads(2, P(k), P(n2), P(h), 1, P(rd), 0, P(mask)) == 0 and not mask.any()  # walls all round: nothing read
+    k[0, 1] = L.AMR_SAME  # a neighbour entry that is missing from the tables: reported, not dereferenced
+    assert lib.cup2d_amr_trace_reads(2, P(k), P(n2), P(h), 1, P(rd), 0, P(mask)) == -1 and b"outside the tables" in lib.cup2d_last_error()
     del vp, one
 
 

@@ -23,8 +23,10 @@ def launch(mode, world, px, py, nbx, nby, port, timeout=600, **extra_env):
             print(line)
 
 
-@pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 4, 6), (2, 1, 2, 5, 3), (4, 2, 2, 4, 4)])
+@pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 4, 6), (2, 1, 2, 5, 3), (4, 2, 2, 4, 4), (8, 2, 4, 4, 4), (8, 4, 2, 3, 5)])
 def test_plan_and_exchange_cpu_gloo(world, px, py, nbx, nby):
+    """(8, 2, 4): BASELINE.json configs[3]'s layout (main.cpp:6494-6504 for the ranges) -- four of its eight ranks have THREE
+    ghost sides (S and N at once + one x side), the other four two; (8, 4, 2): the transposed layout (W and E at once)."""
     launch("cpu", world, px, py, nbx, nby, 29611 + world + px)
 
 
@@ -56,7 +58,7 @@ def test_decomposed_path_at_configs3_rank_size_gpu(px, py, share, split):
            CUP2D_SWEEP_SPLIT=split)
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 5])
+@pytest.mark.parametrize("nranks", [2, 3, 5, 8])
 def test_amr_partition_plans_are_consistent(nranks):
     """host planning of an adapted grid on N ranks (cup2d_amd/amr_dist.py): contiguous balanced Hilbert ranges, ghost sets
     that cover every table entry the kernels read and every matrix column, send lists that are the peers' receive lists"""
@@ -166,7 +168,7 @@ def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu(strips):
     launch("amr_big", 3, 0, 0, 0, 0, 29831 + int(strips), timeout=900, CUP2D_AMR_STRIPS=strips, CUP2D_POISON_GHOSTS="1")
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_amr_whole_block_exchange_cpu_gloo(world):
     """the adapted-grid plan driven through a real multi-process exchange on the CPU (gloo): ghost blocks, face arrays,
     reductions"""

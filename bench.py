@@ -42,6 +42,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: the measured copy ceiling (what a streaming kernel's ACTUAL bytes can move at)
 FP64_PEAK_TFLOPS = 78.6      # 256 CU x 64 FMA/clk x 2 x 2.4 GHz
 CONFIGS3_N = 8192            # BASELINE.json configs[3]: 8192^2 cells, global
+# Test-only: CUP2D_BENCH_SHARE_GPU=1 lets the N ranks of `--gpus N` share GPU 0 of a one-GPU box (RCCL cannot connect two
+# ranks on one device, so the transport is torch.distributed's gloo, host-staged, behind cup2d_set_comm): every line of this
+# file that an 8-rank run executes -- both layouts, the JSON merge, the comm block, the watchdog -- runs before the driver's
+# one 8-GPU run does (tests/test_bench_world8.py).  The line it prints says "shared_gpu": true and is not a measurement.
+SHARE_GPU = os.environ.get("CUP2D_BENCH_SHARE_GPU", "0") == "1"
 MIN_ROOFLINE_LAUNCHES = 100  # a per-kernel roofline is reported from at least this many event-timed launches
 
 
@@ -65,6 +70,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=4096, help="cells per side of one rank's patch (layout weak)")
+    ap.add_argument("--configs3-n", type=int, default=CONFIGS3_N, help="global cells per side of layout configs3 (tests shrink it)")
     ap.add_argument("--layout", default="weak", choices=["weak", "configs3"],
                     help="weak: --n^2 cells per rank; configs3: 8192^2 cells global over px x py ranks (BASELINE.json configs[3])")
     ap.add_argument("--no-second-layout", action="store_true", help="N > 1: do not also measure the other layout")
@@ -99,7 +105,7 @@ def spawn_ranks(args):
     output through.  Exits non-zero with a clear message when the node has fewer GPUs than asked."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (SHARE_GPU and have >= 1):
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible on this node\n" % (args.gpus, have))
         sys.exit(2)
     with socket.socket() as s:
@@ -158,7 +164,7 @@ class Runner:
             kind = args.comm
             try:
                 self.sim = DistributedSimulation(nx // 8, ny // 8, px, py, nu=1e-3, cfl=0.5, device=local_rank,
-                                                 comm=kind, mode="device", group=ctl.get("nccl"))
+                                                 comm=kind, mode="staged" if SHARE_GPU else "device", group=ctl.get("nccl"))
             except Exception as e:
                 # the in-library communicator is the product path: its failure (init or self-test) is an error, not a reason
                 # to measure something else under the same name.  `--comm torch` asks for the other transport explicitly.
@@ -282,41 +288,77 @@ class Runner:
         self.sim.close()
 
 
-def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
+def _proxy_velocity(nbx, nby):
+    nxp, nyp = nbx * 8, nby * 8
+    hh = 1.0 / max(nxp, nyp)
+    X, Y = np.meshgrid((np.arange(nxp) + 0.5) * hh, (np.arange(nyp) + 0.5) * hh, indexing="xy")
+    vel0 = np.stack([np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y), -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)], -1)
+    return vel0 + 1e-3 * np.random.default_rng(20250117).uniform(-1.0, 1.0, vel0.shape)
+
+
+def _proxy_time(args, s, nst):
+    for _ in range(2):
+        s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+    s.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nst):
+        r = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+    s.synchronize()
+    return (time.perf_counter() - t0) / nst, r
+
+
+def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step):
+    """one self-periodic patch (axes "x": ghost blocks W and E; "xy": on all four sides, the shape of an interior rank) timed
+    next to the plain context of the same size (plain_s_per_step None: timed here)"""
     import ctypes
+    import cup2d_amd
     from cup2d_amd import lib as L
     from cup2d_amd.distributed import self_periodic_simulation
-    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    s, g = self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=device)
+    nst = max(3, min(args.steps, 10))
+    vel = _proxy_velocity(nbx, nby)
+    if plain_s_per_step is None:
+        with cup2d_amd.Simulation(nbx, nby, nu=1e-3, cfl=0.5, device=device) as p:
+            p.set_math(args.math == "strict")
+            p.set_solver(fused=args.solver == "fused", finish_in_kernel=args.finish == "kernel")
+            p.vel = vel
+            plain_s_per_step, _ = _proxy_time(args, p, nst)
+    s, g = self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=device, axes=axes)
     with s:
         s.set_math(args.math == "strict")
         s.set_solver(fused=args.solver == "fused", finish_in_kernel=args.finish == "kernel")
-        nxp, nyp = nbx * 8, nby * 8
-        hh = 1.0 / max(nxp, nyp)
-        X, Y = np.meshgrid((np.arange(nxp) + 0.5) * hh, (np.arange(nyp) + 0.5) * hh, indexing="xy")
-        vel0 = np.stack([np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y), -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y)], -1)
-        s.vel = vel0 + 1e-3 * np.random.default_rng(20250117).uniform(-1.0, 1.0, vel0.shape)
-        del X, Y, vel0
-        for _ in range(2):
-            s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
-        s.synchronize()
-        nst = max(3, min(args.steps, 10))
-        t0 = time.perf_counter()
-        for _ in range(nst):
-            r = s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
-        s.synchronize()
-        el = (time.perf_counter() - t0) / nst
+        s.vel = vel
+        del vel
+        el, r = _proxy_time(args, s, nst)
         form = s.last_solver_form()
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "comm_stats")
         L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
-    plain = plain_elapsed / plain_steps
-    return {"what": "the N-rank code path of the step on one GPU: a %dx%d-block patch that is its own W and E neighbour (ghost blocks on "
-                    "both x sides, bytes through ncclSend / ncclRecv to self, all-gather reductions, MERGE 2 kernels)" % (nbx, nby),
+    return {"blocks": "%dx%d" % (nbx, nby), "ghost_sides": "WE" if axes == "x" else "WESN", "peers": p.value,
             "ms_per_step": round(el * 1e3, 3), "value": round(nbx * nby * 64 / el / 1e6, 2), "unit": "Mcell-updates/s",
-            "plain_context_ms_per_step": round(plain * 1e3, 3), "ratio_to_plain": round(el / plain, 4), "iters": r["iters"],
-            "solver_form": list(form), "ghost_blocks": g.nghost, "halo_set_patch": g.halo_tile, "n_inner": g.n_inner,
-            "exchanges": ex.value, "allgathers": ag.value, "timeline": "profiles/r04_nrank_timeline.txt"}
+            "plain_context_ms_per_step": round(plain_s_per_step * 1e3, 3), "ratio_to_plain": round(el / plain_s_per_step, 4),
+            "fixed_us_per_iteration_over_plain": round((el - plain_s_per_step) / max(1, r["iters"]) * 1e6, 1),
+            "iters": r["iters"], "solver_form": list(form), "ghost_blocks": g.nghost, "halo_set_patch": g.halo_tile,
+            "n_inner": g.n_inner, "exchanges": ex.value, "allgathers": ag.value}
+
+
+def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    plain = plain_elapsed / plain_steps
+    # the headline patch with ghost blocks on all four sides (an interior rank; the 2 x 4 layout's ranks have two or three), the
+    # same with the two x sides only (round 4's figure), and BASELINE.json configs[3]'s per-rank patch (4096 x 2048 cells) on
+    # four sides next to a plain context of that size
+    out = nrank_proxy_patch(args, device, nbx, nby, "xy", plain)
+    out["what"] = ("the N-rank code path of the step on one GPU: a patch that is its own W, E, S and N neighbour (ghost blocks on "
+                   "all four sides, four send/recv pairs per ncclGroup to self, all-gather reductions, MERGE 2 kernels)")
+    out["timeline"] = "profiles/r05_nrank_timeline.txt"
+    others = []
+    for (bx, by, axes, pl) in ((nbx, nby, "x", plain), (nbx, max(1, nby // 2), "xy", None)):
+        try:
+            others.append(nrank_proxy_patch(args, device, bx, by, axes, pl))
+        except Exception as e:  # informative
+            others.append({"blocks": "%dx%d" % (bx, by), "error": str(e)[:200]})
+    out["other_patches"] = others
+    return out
 
 
 def amr_leg(args, device):
@@ -413,6 +455,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if SHARE_GPU:
+        local_rank = 0          # every rank on GPU 0
+        if world > 1 or args.force_dist:
+            args.comm = "torch"  # gloo, host-staged (see SHARE_GPU above)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU %d (%d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -428,13 +474,13 @@ def main():
         # control plane only: token, barriers, max of the wall time; a rank that dies must not leave the others waiting
         dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=4))
         ctl["gloo"] = dist.group.WORLD
-        if args.comm == "torch":
+        if args.comm == "torch" and not SHARE_GPU:
             ctl["nccl"] = dist.new_group(backend="nccl")
         px, py = cartesian_dims(world)
 
     def geometry(layout):
         if layout == "configs3":
-            return CONFIGS3_N // px, CONFIGS3_N // py
+            return args.configs3_n // px, args.configs3_n // py
         return args.n, args.n
 
     nx, ny = geometry(args.layout)
@@ -512,8 +558,11 @@ def main():
 
     comm_info = None
     if dist is not None:
-        comm_info = {"transport": {"rccl": "in-library RCCL communicator (csrc/comm.hip)", "torch": "torch.distributed nccl behind cup2d_set_comm",
-                                   "none": "none"}[run.comm_kind], "peers_of_rank0": len(sim.topo.peers)}
+        comm_info = {"transport": {"rccl": "in-library RCCL communicator (csrc/comm.hip)",
+                                   "torch": "torch.distributed gloo, host-staged, behind cup2d_set_comm (ranks share GPU 0: test only)"
+                                   if SHARE_GPU else "torch.distributed nccl behind cup2d_set_comm",
+                                   "none": "none"}[run.comm_kind], "peers_of_rank0": len(sim.topo.peers), "shared_gpu": SHARE_GPU,
+                     "cartesian": "%dx%d" % (px, py)}
         if run.comm_kind == "rccl":
             st = sim.comm_stats()
             rep = getattr(sim, "comm_report", {}) or {}
@@ -806,10 +855,20 @@ def main():
             nrank_proxy = {"error": str(e)[:200]}
         beat("N-rank path done")
 
+    # the one field that says the timed work was real, within the first bytes of the line (the full block is "verified")
+    verified_summary = None
+    if verified is not None:
+        li = verified.get("last_iterate") or {}
+        e8 = li.get("eight_iterations") or {}
+        verified_summary = {"ok": verified.get("ok"), "reported_vs_recomputed_residual": [verified.get("residual_reported"),
+                                                                                            verified.get("residual_recomputed")],
+                            "last_iterate_relative_gap": li.get("relative_gap"), "eight_iterations_vs_five_sweeps": e8.get("relative"),
+                            "error": verified.get("error")}
     if rank == 0:
         out = {
             "metric": "Mcell-updates/sec (advect-diffuse+Poisson sweep) at 4096^2",
             "value": round(value, 3), "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
+            "verified_summary": verified_summary,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "ms_per_step_no_kernel_timers": round(elapsed_plain / args.steps * 1e3, 3) if elapsed_plain else None,
             "higher_is_better": True,

@@ -294,22 +294,30 @@ class DistributedSimulation(Simulation):
         _l.check(self.L.cup2d_halo_exchange(self._ctx, int(field), int(width)), "halo_exchange")
 
 
-def self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=0):
-    """One rank that is its own W and E neighbour through the in-library communicator: ghost blocks on both x sides, each
-    filled from the opposite edge by ncclSend / ncclRecv to self (a domain periodic in x).  Everything a rank of an N-rank run
-    does -- the halo set ordered last, pack kernels, whole ghost blocks of the Krylov vectors through RCCL, the MERGE 2
-    kernels, an all-gather and a one-wave kernel per reduction -- on ONE GPU: the tests of the communicator's data path
-    (tests/test_comm.py) and the N-rank-path leg of bench.py use it.  Returns (Simulation, BlockGrid); the caller finalises
-    the communicator (cup2d_comm_finalize) before closing."""
-    g = BlockGrid(nbx, nby, ghost_sides=(True, True, False, False))
+def self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=0, axes="x"):
+    """One rank that is its own neighbour through the in-library communicator: ghost blocks on both x sides (axes "x": a domain
+    periodic in x, walls in y) or on all four sides (axes "xy": doubly periodic -- what an INTERIOR rank of a decomposition has,
+    and every rank of BASELINE.json configs[3]'s 2 x 4 layout has two or three of: halo-set patches that meet in corners, four
+    peers in one ncclGroup, four consecutive ghost ranges received in place), each filled from the opposite edge by ncclSend /
+    ncclRecv to self.  Everything a rank of an N-rank run does -- the halo set ordered last, pack kernels, whole ghost blocks of
+    the Krylov vectors through RCCL, the MERGE 2 kernels, an all-gather and a one-wave kernel per reduction -- on ONE GPU: the
+    tests of the communicator's data path (tests/test_comm.py) and the N-rank-path leg of bench.py use it.  Returns (Simulation,
+    BlockGrid); the caller finalises the communicator (cup2d_comm_finalize) before closing."""
+    if axes not in ("x", "xy"):
+        raise ValueError("axes must be 'x' or 'xy'")
+    sides = (0, 1) if axes == "x" else (0, 1, 2, 3)
+    g = BlockGrid(nbx, nby, ghost_sides=tuple(k in sides for k in range(4)))
     s = Simulation(nbx, nby, nu=nu, cfl=cfl, device=device, grid=g, h=1.0 / (8 * max(nbx, nby)))
     sb, sf, rb, rf = [], [], [], []
-    for side in (0, 1):  # W strips then E strips in the send list; W ghosts then E ghosts in the receive list
-        for pos in range(nby):
-            sb.append(int(g.index_of[pos, 0 if side == 0 else nbx - 1]))
+    for side in sides:  # W, E, S, N strips in the send list; W, E, S, N ghosts in the receive list
+        for pos in range(nby if side < 2 else nbx):
+            if side < 2:
+                sb.append(int(g.index_of[pos, 0 if side == 0 else nbx - 1]))
+            else:
+                sb.append(int(g.index_of[0 if side == 2 else nby - 1, pos]))
             sf.append(side)
             rb.append(int(g._ghost_id[(side, pos)]))
-            rf.append(1 - side)
+            rf.append(OPPOSITE[side])
     arr = [np.asarray(a, dtype=np.int32) for a in (sb, sf, rb, rf)]
     vp = ctypes.c_void_p
     _l.check(s.L.cup2d_halo_plan(s.ctx, len(sb), arr[0].ctypes.data_as(vp), arr[1].ctypes.data_as(vp), len(rb),
@@ -317,11 +325,13 @@ def self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=0):
     ids = ctypes.create_string_buffer(_l.COMM_ID_BYTES)
     _l.check(s.L.cup2d_comm_unique_id(ids), "comm_unique_id")
     # receive i pairs with send i (RCCL matches the operations of a pair of ranks in issue order): the W ghosts
-    # (receive offset 0) take the E strips (send offset nby), the E ghosts the W strips
-    peer = np.zeros(2, dtype=np.int32)
-    soff = np.asarray([nby, 0], dtype=np.int32)
-    roff = np.asarray([0, nby], dtype=np.int32)
-    cnt = np.asarray([nby, nby], dtype=np.int32)
-    _l.check(s.L.cup2d_comm_init(s.ctx, 1, 0, ids, 2, peer.ctypes.data_as(vp), soff.ctypes.data_as(vp), roff.ctypes.data_as(vp),
+    # (receive offset 0) take the E strips (send offset nby), the E ghosts the W strips; likewise S <- N, N <- S
+    if axes == "x":
+        soff, roff, cnt = [nby, 0], [0, nby], [nby, nby]
+    else:
+        soff, roff, cnt = [nby, 0, 2 * nby + nbx, 2 * nby], [0, nby, 2 * nby, 2 * nby + nbx], [nby, nby, nbx, nbx]
+    peer = np.zeros(len(cnt), dtype=np.int32)
+    soff, roff, cnt = (np.asarray(a, dtype=np.int32) for a in (soff, roff, cnt))
+    _l.check(s.L.cup2d_comm_init(s.ctx, 1, 0, ids, len(cnt), peer.ctypes.data_as(vp), soff.ctypes.data_as(vp), roff.ctypes.data_as(vp),
                                  cnt.ctypes.data_as(vp), None), "comm_init")
     return s, g

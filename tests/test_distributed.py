@@ -40,9 +40,21 @@ def test_cartesian_dims():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 8, 16), (2, 1, 2, 16, 8), (4, 2, 2, 8, 8)])
+@pytest.mark.parametrize("world,px,py,nbx,nby", [(2, 2, 1, 8, 16), (2, 1, 2, 16, 8), (4, 2, 2, 8, 8), (8, 2, 4, 16, 16)])
 def test_decomposed_step_matches_global_oracle_gpu(world, px, py, nbx, nby):
+    """(8, 2, 4, 16, 16): the partitioning BASELINE.json configs[3] names (2 x 4 over 8 ranks, main.cpp:6494-6504), the eight
+    ranks sharing the one GPU: four of them have three ghost sides (S and N at once + one x side: halo-set patches meeting at
+    two corners, three peers per exchange), every functor STRICT bit for bit against the global CPU oracle"""
     launch("gpu", world, px, py, nbx, nby, 29711 + world + px, timeout=900)
+
+
+@pytest.mark.gpu
+def test_two_by_four_ranks_against_the_single_context_gpu():
+    """dist_worker.run_gpu_big on the 2 x 4 layout at 16 x 16 blocks per rank (a 256 x 512-cell global grid): STRICT functors
+    bit for bit against the single context on the whole grid, eight iterations of the two-launch MERGE 2 solver on 8 ranks =
+    the five sweeps on one context to 1e-10 of max|x|, the residual the N-rank recurrence carries = max|b - A x| of the
+    iterate assembled over the ranks, one bench step"""
+    launch("gpu_big", 8, 2, 4, 16, 16, 29761, timeout=900)
 
 
 @pytest.mark.gpu
@@ -152,7 +164,7 @@ def test_amr_trace_reads_on_small_grids():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,strips", [(2, "1"), (3, "1"), (2, "0")])
+@pytest.mark.parametrize("world,strips", [(2, "1"), (3, "1"), (2, "0"), (8, "1")])
 def test_amr_on_n_ranks_matches_the_reference_functors_gpu(world, strips):
     """strips = "1" (default): the ghost blocks are refreshed through the cell plans -- only the cells the kernels read travel --
     and start as NaN (CUP2D_POISON_GHOSTS), so a kernel that read a cell no plan delivered could not equal the reference's
@@ -184,7 +196,7 @@ def test_amr_regrid_on_n_ranks_moves_only_what_the_plan_names_cpu_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("px,py,comm", [(2, 1, "mpi"), (1, 2, "mpi"), (2, 2, "mpi"), (1, 1, "rccl")])
+@pytest.mark.parametrize("px,py,comm", [(2, 1, "mpi"), (1, 2, "mpi"), (2, 2, "mpi"), (2, 4, "mpi"), (1, 1, "rccl")])
 def test_cpp_mpi_driver_matches_the_single_rank_run_gpu(tmp_path, px, py, comm):
     """csrc/cup2d_run_mpi.cpp -- the N-rank time loop with the host side in C++ (Cartesian plan, cup2d_halo_plan, the
     callback transport over MPI; with one GPU per rank the same program takes the in-library RCCL communicator) -- on

@@ -108,12 +108,7 @@ struct DevPool {
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, bucket) -> buffers not in use
   std::map<void *, std::pair<int, size_t>> owner;              // every buffer the pool has handed out or holds
-  std::map<void *, void *> base;                               // skewed buffers: what hipMalloc returned
   size_t idle_bytes = 0;
-  int nbig = 0;
-  // CUP2D_ALLOC_SKEW: the k-th large buffer starts (k mod 16) * skew bytes into its allocation (experiment: vectors of 2^27
-  // bytes, each its own hipMalloc, all start at the same offset of the channel interleave)
-  const size_t skew = [] { const char *e = getenv("CUP2D_ALLOC_SKEW"); return (size_t)(e ? atol(e) : 0); }();
   const bool on = [] { const char *e = getenv("CUP2D_POOL"); return !e || atoi(e) != 0; }();
   const size_t cap = [] { const char *e = getenv("CUP2D_POOL_MAX_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
   static size_t bucket(size_t bytes) {
@@ -179,21 +174,14 @@ hipError_t dev_malloc_raw(void **p, size_t bytes) {
     }
   }
   if (!q) {
-    const bool big = P.skew > 0 && b >= ((size_t)8 << 20);
-    const size_t extra = big ? 16 * P.skew : 0;
-    e = hipMalloc(&q, b + extra);
+    e = hipMalloc(&q, b);
     if (e != hipSuccess) {  // out of memory with buffers idling in the pool: give them back and try once more
       (void)hipGetLastError();
       cup2d_trim_pool();
-      e = hipMalloc(&q, b + extra);
+      e = hipMalloc(&q, b);
       if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> g(P.mu);
-    if (big) {
-      void *raw = q;
-      q = static_cast<char *>(raw) + (size_t)(P.nbig++ % 16) * P.skew;
-      P.base[q] = raw;
-    }
     P.owner[q] = {dev, b};
   }
   // zero-filled, always: a recycled buffer must not look different from a fresh one
@@ -216,17 +204,25 @@ void dev_free(void *q) {
   }
   if (P.idle_bytes + it->second.second > P.cap) {
     P.owner.erase(it);
-    auto bt = P.base.find(q);
-    if (bt != P.base.end()) {
-      q = bt->second;
-      P.base.erase(bt);
-    }
     g.unlock();
     (void)hipFree(q);
     return;
   }
   P.idle[it->second].push_back(q);
   P.idle_bytes += it->second.second;
+}
+
+// back to the driver at once, past the pool: what a search allocated only to look at (krylov_fused.hip tune_placement) must not
+// idle in this process for its lifetime -- other ranks sharing the GPU, torch and RCCL in the same process see it as used
+void dev_release(void *q) {
+  if (!q) return;
+  DevPool &P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.owner.find(q);
+    if (it != P.owner.end()) P.owner.erase(it);
+  }
+  (void)hipFree(q);
 }
 
 // A pooled temporary of one call.  The pool hands a freed buffer to the next dev_malloc at once and fills it with zeros on
@@ -255,11 +251,15 @@ extern "C" int cup2d_trim_pool(void) {
   {
     HostResPool &HP = host_pool();
     std::lock_guard<std::mutex> g(HP.mu);
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;  // the caller's current device is the caller's (dev_malloc_raw retries on it)
     for (auto &kv : HP.idle) {
+      if (kv.second.empty()) continue;
       (void)hipSetDevice(kv.first);
       for (HostRes &r : kv.second) host_res_destroy(r);
       kv.second.clear();
     }
+    if (have_cur) (void)hipSetDevice(cur);
   }
   auto &P = cup2d::pool();
   std::vector<void *> drop;
@@ -268,9 +268,7 @@ extern "C" int cup2d_trim_pool(void) {
     for (auto &kv : P.idle)
       for (void *q : kv.second) {
         P.owner.erase(q);
-        auto bt = P.base.find(q);
-        drop.push_back(bt != P.base.end() ? bt->second : q);
-        if (bt != P.base.end()) P.base.erase(bt);
+        drop.push_back(q);
       }
     P.idle.clear();
     P.idle_bytes = 0;
@@ -1314,6 +1312,11 @@ int cup2d_halo_plan(cup2d_ctx *c, int nsend, const int32_t *sb, const int32_t *s
     if (sb[i] < 0 || sb[i] >= c->nblocks || sf[i] < 0 || sf[i] > 3) { set_error("halo_plan: send entry %d", i); return CUP2D_ERR_ARG; }
   for (int i = 0; i < nrecv; i++)
     if (rb[i] < c->nblocks || rb[i] >= c->ntotal || rf[i] < 0 || rf[i] > 3) { set_error("halo_plan: recv entry %d", i); return CUP2D_ERR_ARG; }
+  if (c->rccl) {  // its per-peer offsets, cell counts and in-place receive targets were derived from the plan it was given
+    set_error("halo_plan: the in-library communicator was initialised on the previous plan: cup2d_comm_finalize first, then "
+              "cup2d_halo_plan, cup2d_comm_init");
+    return CUP2D_ERR_ARG;
+  }
   HaloPlan &p = c->plan;
   // cup2d_halo_exchange is asynchronous: pack / unpack kernels of the OLD plan may still read these tables, and the pool
   // would hand them to the next dev_malloc (zero fill on the null stream) at once.  (The communicator's second stream hands

@@ -216,9 +216,10 @@ __global__ __launch_bounds__(WG) void k_pack_blocks(const double *__restrict__ v
     }
   }
 }
+// (rc->direct is agreed over all ranks in cup2d_comm_init -- the two paths have different wire formats, so a rank must not
+// choose alone; CUP2D_COMM_DIRECT=0 on any rank turns the in-place path off on every rank)
 bool comm_blocks_direct(const cup2d_ctx *c) {
-  static const bool on = [] { const char *e = getenv("CUP2D_COMM_DIRECT"); return !e || atoi(e) != 0; }();
-  return on && c->rccl && c->comm_user == (void *)c->rccl && c->rccl->direct && c->nghost > 0;
+  return c->rccl && c->comm_user == (void *)c->rccl && c->rccl->direct && c->nghost > 0;
 }
 int comm_blocks_wait(cup2d_ctx *c) {
   RcclComm *rc = c->rccl;
@@ -426,6 +427,24 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
   if (r != ncclSuccess) {
     set_error("ncclCommInitRank(%d of %d) -> %s", rank, nranks, api->GetErrorString(r));
     return CUP2D_ERR_COMM;
+  }
+  // The in-place receive of whole ghost blocks and the generic exchange differ on the wire (nv messages of cnt x 64 doubles per
+  // peer, vector-major, against one strip-major message): the choice is made by ALL ranks together -- a minimum over the ranks
+  // of "my ghost blocks are consecutive per peer and CUP2D_COMM_DIRECT is not 0 here".
+  {
+    static const bool env_on = [] { const char *e = getenv("CUP2D_COMM_DIRECT"); return !e || atoi(e) != 0; }();
+    const double mine = (rc->direct && env_on) ? 1.0 : 0.0;
+    double all = 0.0;
+    CUP2D_HIP_CHECK(hipMemcpy(rc->d_red, &mine, sizeof mine, hipMemcpyHostToDevice));
+    r = api->AllReduce(rc->d_red, rc->d_red, 1, ncclDouble, ncclMin, rc->red, c->stream);
+    if (r != ncclSuccess) {
+      set_error("comm_init: ncclAllReduce(direct) -> %s", api->GetErrorString(r));
+      return CUP2D_ERR_COMM;
+    }
+    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    CUP2D_HIP_CHECK(hipMemcpy(&all, rc->d_red, sizeof all, hipMemcpyDeviceToHost));
+    CUP2D_HIP_CHECK(hipMemset(rc->d_red, 0, sizeof(double) * 8));
+    rc->direct = all == 1.0;
   }
   CUP2D_TRY(cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red));
   return cup2d_set_comm_strip_capacity(c, (int)strip);  // three whole blocks per strip: allocated above

@@ -353,6 +353,7 @@ hipError_t dev_malloc_raw(void **p, size_t bytes);
 template <class T>
 inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_raw(reinterpret_cast<void **>(p), bytes); }
 void dev_free(void *p);
+void dev_release(void *p);  // hipFree past the pool (api.hip)
 // amr_host.hip: the Poisson operator of an adapted grid straight in the hybrid sliced-ELL form
 void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half, std::vector<int32_t> &reg,
                          std::vector<long long> &ptr, std::vector<int32_t> &ecol, std::vector<double> &eval, int *nregular);

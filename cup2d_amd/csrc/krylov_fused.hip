@@ -1147,14 +1147,17 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 // same again on every later solve; another process on the same box: 126, 117, 118, 127, ... (tools/gpu_placement_modes.py,
 // tools/gpu_calls/gpu_r04_call18.sh).  Start offsets inside the allocations move nothing, one large
 // allocation carved up is reproducibly the slow mode (round 3).  So the first fused solve of a context on a large grid
-// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 16) complete sets of the eleven vectors -- all held while it
+// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 8, within CUP2D_PLACEMENT_MAX_GB = 16 GB and a quarter of the free
+// memory) complete sets of the eleven vectors -- all held while it
 // looks, so that every set is other memory --, times three iterations' worth of the two launches on each (the MERGE 0
 // instances on zero-filled vectors with a scratch scalar record: no reduction finish, nothing of the context's state
 // touched), keeps the fastest set and gives the others back: 2 ms per set at 4096^2, once per context.  A set in the fast
 // mode turned up among 8 in four of five processes, among 12 in one of two (gpu_r04_call19.sh): the sets of a process are
 // not independent draws, and a process can be out of luck.
 static int tune_placement(cup2d_ctx *c) {
-  static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 16; }();
+  static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 8; }();
+  // what the search may hold beyond the context's own set while it looks (per process: ranks that share a GPU each search)
+  static const double budget_gb = [] { const char *e = getenv("CUP2D_PLACEMENT_MAX_GB"); return e ? atof(e) : 16.0; }();
   if (c->placement_tuned) return CUP2D_OK;
   c->placement_tuned = true;
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
@@ -1164,7 +1167,8 @@ static int tune_placement(cup2d_ctx *c) {
   size_t free_b = 0, total_b = 0;
   CUP2D_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
   int tries = tries_env > 48 ? 48 : tries_env;
-  while (tries > 1 && (size_t)(tries - 1) * NV * bytes > free_b / 2) tries--;  // never more than half of what is free
+  const size_t budget = std::min((size_t)(budget_gb * (double)((size_t)1 << 30)), free_b / 4);  // never more than a quarter of what is free
+  while (tries > 1 && (size_t)(tries - 1) * NV * bytes > budget) tries--;
   if (tries <= 1) return CUP2D_OK;
   StageClock clk("tune_placement");
   struct Cand { double *v[NV]; float ms; };
@@ -1214,7 +1218,7 @@ static int tune_placement(cup2d_ctx *c) {
     made = q + 1;
     if (!ok) {  // out of memory: what exists is enough
       (void)hipGetLastError();
-      for (int k = 0; k < NV; k++) dev_free(cand[q].v[k]);
+      for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
       made = q;
       break;
     }
@@ -1228,9 +1232,9 @@ static int tune_placement(cup2d_ctx *c) {
       worst = cand[q].ms > worst ? cand[q].ms : worst;
     }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  for (int q = 0; q < made; q++) {
+  for (int q = 0; q < made; q++) {  // the sets that lost go back to the driver, not into the process pool (dev_release)
     if (q == best) continue;
-    for (int k = 0; k < NV; k++) dev_free(cand[q].v[k]);
+    for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
   }
   for (int k = 0; k < NV; k++) *slot[k] = cand[best].v[k];
   // the survivors start a solve as every solver vector does: zero

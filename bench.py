@@ -97,7 +97,10 @@ def parse_args():
     ap.add_argument("--no-nrank-proxy", action="store_true", help="skip the N-rank-path leg (a self-periodic patch through RCCL on this GPU)")
     ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
     ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
-    return ap.parse_args()
+    # (ranks started by spawn_ranks get their arguments through the environment: torch.distributed.run's argparse rejects
+    # "--n" in front of it as an ambiguous abbreviation of its own options, wherever on the command line it stands)
+    argv = json.loads(os.environ["CUP2D_BENCH_ARGV"]) if "CUP2D_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ else None
+    return ap.parse_args(argv)
 
 
 def spawn_ranks(args):
@@ -112,8 +115,9 @@ def spawn_ranks(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     env = dict(os.environ)
+    env["CUP2D_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes)
     env.setdefault("OMP_NUM_THREADS", "8")
     sys.exit(subprocess.call(cmd, env=env))

@@ -408,6 +408,7 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   CUP2D_HIP_CHECK(dev_malloc(&c->d_ticket, sizeof(unsigned)));
   CUP2D_HIP_CHECK(hipMemset(c->d_ticket, 0, sizeof(unsigned)));
   CUP2D_HIP_CHECK(dev_malloc(&c->d_sc, sizeof(KrylovScalars)));
+  CUP2D_HIP_CHECK(dev_malloc(&c->d_sc2, sizeof(KrylovScalars)));
   if (!recycled) {
     CUP2D_HIP_CHECK(hipHostMalloc(&c->h_sc, sizeof(KrylovScalars)));
     CUP2D_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * 8));
@@ -440,6 +441,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->d_fault);
   dev_free(c->d_ticket);
   dev_free(c->d_sc);
+  dev_free(c->d_sc2);
   {  // stream, events and pinned words go back to the per-device free list (complete sets only; a few are kept)
     HostRes res;
     res.stream = c->own_stream;

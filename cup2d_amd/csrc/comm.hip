@@ -124,6 +124,7 @@ struct RcclComm {
   std::vector<int> rblock0;  // per peer: the first of its ghost blocks
   std::vector<int> csoff[CELL_SETS], croff[CELL_SETS], ccnt[CELL_SETS], crcnt[CELL_SETS];  // the same for the cell plans (cup2d_comm_set_cell_counts)
   bool direct = false;       // every peer's ghost blocks are consecutive: whole blocks can be received in place
+  bool defer_ok = false;     // ... on every rank, and every rank has ghost blocks: the reduction records may ride in the send/recv group
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
   long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
 };
@@ -189,7 +190,10 @@ static int rccl_exchange(void *user, double *send, double *recv, int strip_doubl
 // them -- the elements behind the packed ones; nothing of it touches what is packed (nu'')
 __global__ __launch_bounds__(WG) void k_pack_blocks(const double *__restrict__ v0, const double *__restrict__ v1,
                                                    const double *__restrict__ v2, double *__restrict__ buf,
-                                                   const int32_t *__restrict__ blocks, int nstrips, int nv, GhostRP G) {
+                                                   const int32_t *__restrict__ blocks, int nstrips, int nv, GhostRP G,
+                                                   const double *__restrict__ rec, double *__restrict__ rec_slot) {
+  // (records in the group: this rank's record into its own slot of the gathered records -- what the other ranks receive)
+  if (rec_slot && blockIdx.x == 0 && threadIdx.x < RED_REC) rec_slot[threadIdx.x] = rec[threadIdx.x];
   const size_t per = (size_t)nstrips * BC, total = per * nv;
   const bool ghosts = G.count > 0 && G.sc->status == 0;
   const size_t all = total + (ghosts ? G.count : 0);
@@ -227,21 +231,29 @@ int comm_blocks_wait(cup2d_ctx *c) {
   CUP2D_HIP_CHECK(hipStreamWaitEvent(c->stream, rc->ev_arrived, 0));
   return CUP2D_OK;
 }
-int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream, const GhostRP *ghosts) {
+const double *comm_gathered(const cup2d_ctx *c) { return c->rccl ? c->rccl->d_gather : nullptr; }
+int comm_nranks(const cup2d_ctx *c) { return c->rccl ? c->rccl->nranks : 1; }
+bool comm_defer_ok(const cup2d_ctx *c) { return c->rccl && c->comm_user == (void *)c->rccl && c->rccl->defer_ok; }
+int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream, const GhostRP *ghosts, bool records) {
   RcclComm *rc = c->rccl;
   rc->n_exchange++;
-  if (rc->peer.empty() || nv < 1 || nv > 3) return CUP2D_OK;
+  if (rc->peer.empty() || nv < 1 || nv > 3) {
+    if (records) { set_error("comm_exchange_blocks: records without a block exchange"); return CUP2D_ERR_ARG; }
+    return CUP2D_OK;
+  }
   hipStream_t xs = on_comm_stream ? rc->comm_stream : c->stream;
   double *vecs[3] = {v0, v1, v2};
   const int ns = c->plan.nsend;
   GhostRP G = ghosts ? *ghosts : GhostRP();
-  if (ns > 0 || G.count > 0) {
+  if (ns > 0 || G.count > 0 || records) {
     const size_t total = (size_t)ns * BC * nv + G.count;
     int grid = (int)((total + WG - 1) / WG);
     if (grid > c->grid) grid = c->grid;
+    if (grid < 1) grid = 1;
     ProfScope prof(c, CUP2D_T_HALO);
     hipLaunchKernelGGL(k_pack_blocks, dim3(grid), dim3(WG), 0, c->stream, (const double *)v0, (const double *)v1, (const double *)v2,
-                       rc->d_send, (const int32_t *)c->plan.d_send_block, ns, nv, G);
+                       rc->d_send, (const int32_t *)c->plan.d_send_block, ns, nv, G, (const double *)c->d_red,
+                       records ? rc->d_gather + (size_t)RED_REC * rc->rank : (double *)nullptr);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
   const auto fail = [&](ncclResult_t r, const char *what) {
@@ -254,6 +266,18 @@ int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v
   }
   ncclResult_t r = rc->api->GroupStart();
   if (r != ncclSuccess) return fail(r, "ncclGroupStart");
+  if (records) {  // rank by rank, in front of the blocks (RCCL pairs the operations of two ranks in issue order: every rank issues this order)
+    for (int q = 0; q < rc->nranks; q++)
+      if (q != rc->rank) {
+        r = rc->api->Recv(rc->d_gather + (size_t)RED_REC * q, RED_REC, ncclDouble, q, rc->p2p, xs);
+        if (r != ncclSuccess) return fail(r, "ncclRecv(record)");
+      }
+    for (int q = 0; q < rc->nranks; q++)
+      if (q != rc->rank) {
+        r = rc->api->Send(c->d_red, RED_REC, ncclDouble, q, rc->p2p, xs);
+        if (r != ncclSuccess) return fail(r, "ncclSend(record)");
+      }
+  }
   for (int v = 0; v < nv; v++)  // receives first, vector by vector and peer by peer: the order the peers send in
     for (size_t i = 0; i < rc->peer.size(); i++)
       if (rc->rcnt[i] > 0) {
@@ -289,7 +313,6 @@ static int rccl_allreduce(void *user, double *buf, int count, int op, void *stre
 // three doubles per rank), then ONE single-wave kernel that adds / maximises them in rank order -- a summation order that
 // does not depend on the algorithm RCCL picks, and a sum and a max in one collective -- and runs the scalar update of the
 // stage on the result (krylov_common.h scalars_update; stage < 0: only the reduced values, into red).
-constexpr int RED_REC = 8;  // doubles per rank in the gathered record (= the size of d_red)
 __global__ void k_gather_scalars(const double *__restrict__ g, int nranks, int nsum, int with_max, double *__restrict__ red,
                                  KrylovScalars *sc, int stage, int *host_status) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -301,12 +324,7 @@ __global__ void k_gather_scalars(const double *__restrict__ g, int nranks, int n
   // (a record per rank: RED_REC doubles -- up to five sums, krylov_common.h stage 5; with a maximum it is entry 2 and the
   // sums are at most two)
   double v[RED_REC];
-  for (int k = 0; k < RED_REC; k++) v[k] = 0.0;
-  for (int r = 0; r < nranks; r++) {
-    for (int k = 0; k < nsum && k < RED_REC; k++)
-      if (!(with_max && k == 2)) v[k] += g[RED_REC * r + k];
-    if (with_max) v[2] = fmax(v[2], g[RED_REC * r + 2]);
-  }
+  sum_records(g, nranks, nsum, with_max, v);
   for (int k = 0; k < RED_REC; k++) red[k] = v[k];
   if (stage >= 0) {
     scalars_update(sc, v, stage);
@@ -319,6 +337,14 @@ int comm_reduce_scalars(cup2d_ctx *c, int nsum, int with_max, int stage, int *ho
   CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, RED_REC, ncclDouble, rc->red, c->stream));
   hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, nsum, with_max, c->d_red, c->d_sc,
                      stage, host_status);
+  CUP2D_HIP_CB(hipGetLastError());
+  return 0;
+}
+
+int comm_apply_gathered(cup2d_ctx *c, int nsum, int with_max, int stage) {
+  RcclComm *rc = c->rccl;
+  hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, nsum, with_max, c->d_red, c->d_sc,
+                     stage, (int *)nullptr);
   CUP2D_HIP_CB(hipGetLastError());
   return 0;
 }
@@ -433,18 +459,22 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
   // of "my ghost blocks are consecutive per peer and CUP2D_COMM_DIRECT is not 0 here".
   {
     static const bool env_on = [] { const char *e = getenv("CUP2D_COMM_DIRECT"); return !e || atoi(e) != 0; }();
-    const double mine = (rc->direct && env_on) ? 1.0 : 0.0;
-    double all = 0.0;
-    CUP2D_HIP_CHECK(hipMemcpy(rc->d_red, &mine, sizeof mine, hipMemcpyHostToDevice));
-    r = api->AllReduce(rc->d_red, rc->d_red, 1, ncclDouble, ncclMin, rc->red, c->stream);
+    // [1]: the reduction records in the send/recv group and the scalar updates in the consumer sweeps (krylov_fused.hip
+    // "deferred"): every rank must have ghost blocks (a block exchange per reduction point to ride on); CUP2D_DEFER_SCALARS=0
+    static const bool defer_on = [] { const char *e = getenv("CUP2D_DEFER_SCALARS"); return !e || atoi(e) != 0; }();
+    const double mine[2] = {(rc->direct && env_on) ? 1.0 : 0.0, (rc->direct && env_on && defer_on && c->nghost > 0 && !rc->peer.empty()) ? 1.0 : 0.0};
+    double all[2] = {0.0, 0.0};
+    CUP2D_HIP_CHECK(hipMemcpy(rc->d_red, mine, sizeof mine, hipMemcpyHostToDevice));
+    r = api->AllReduce(rc->d_red, rc->d_red, 2, ncclDouble, ncclMin, rc->red, c->stream);
     if (r != ncclSuccess) {
       set_error("comm_init: ncclAllReduce(direct) -> %s", api->GetErrorString(r));
       return CUP2D_ERR_COMM;
     }
     CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-    CUP2D_HIP_CHECK(hipMemcpy(&all, rc->d_red, sizeof all, hipMemcpyDeviceToHost));
+    CUP2D_HIP_CHECK(hipMemcpy(all, rc->d_red, sizeof all, hipMemcpyDeviceToHost));
     CUP2D_HIP_CHECK(hipMemset(rc->d_red, 0, sizeof(double) * 8));
-    rc->direct = all == 1.0;
+    rc->direct = all[0] == 1.0;
+    rc->defer_ok = all[1] == 1.0;
   }
   CUP2D_TRY(cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red));
   return cup2d_set_comm_strip_capacity(c, (int)strip);  // three whole blocks per strip: allocated above

@@ -172,6 +172,7 @@ struct cup2d_ctx {
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
   cup2d::KrylovScalars *d_sc = nullptr;
+  cup2d::KrylovScalars *d_sc2 = nullptr;  // N ranks, deferred scalar updates (krylov_fused.hip): the state alternates between d_sc and this
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned
   static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)
   bool keep_last = false, have_last = false;  // cup2d_solver_keep_last: the solve leaves its LAST iterate in d_z
@@ -404,8 +405,16 @@ struct GhostRP {
   const KrylovScalars *sc = nullptr;
   size_t first = 0, count = 0;
 };
+// records: this rank's reduction record (d_red, RED_REC doubles) travels in the SAME ncclGroup -- to every other rank, into
+// slot `rank` of their gathered records (comm_gathered) -- and the pack launch copies it into this rank's own slot: one RCCL
+// kernel per reduction point, and no all-gather (the consumer sweep sums the records itself, krylov_edge.h MERGE 3)
 int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream = false,
-                         const GhostRP *ghosts = nullptr);
+                         const GhostRP *ghosts = nullptr, bool records = false);
+const double *comm_gathered(const cup2d_ctx *c);  // [nranks][RED_REC]
+int comm_nranks(const cup2d_ctx *c);
+bool comm_defer_ok(const cup2d_ctx *c);           // agreed over all ranks at cup2d_comm_init
+// the standalone form of what a MERGE 3 sweep does with the gathered records (the last pending stage of a solve)
+int comm_apply_gathered(cup2d_ctx *c, int nsum, int with_max, int stage);
 int comm_blocks_wait(cup2d_ctx *c);
 int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
 int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);

@@ -9,6 +9,18 @@
 
 namespace cup2d {
 
+constexpr int RED_REC = 8;  // doubles per rank in a gathered reduction record (= the size of d_red)
+// {sum, sum, max} (or up to RED_REC sums) of every rank's record, in RANK ORDER: a summation order that does not depend on
+// the transport, the same on every rank (comm.hip k_gather_scalars; krylov_edge.h MERGE 3)
+static __device__ __forceinline__ void sum_records(const double *__restrict__ g, int nranks, int nsum, int with_max, double (&v)[RED_REC]) {
+  for (int k = 0; k < RED_REC; k++) v[k] = 0.0;
+  for (int r = 0; r < nranks; r++) {
+    for (int k = 0; k < nsum && k < RED_REC; k++)
+      if (!(with_max && k == 2)) v[k] += g[RED_REC * r + k];
+    if (with_max) v[2] = fmax(v[2], g[RED_REC * r + 2]);
+  }
+}
+
 // One row of the hybrid sliced-ELL operator (ctx.h SellMatrix): slice s (= block; wave-uniform), lane = row.  Shared by
 // k_sell (krylov.hip) and k_hyb_rows (krylov_fused.hip).
 static __device__ __forceinline__ double sell_row(const double *__restrict__ x, int s, int lane,

@@ -139,9 +139,28 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
                                                  int *fault) {
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   constexpr bool AB = MODE == 0, CD = MODE == 1 || MODE == 3, CDX = MODE == 3, EAB = MODE == 2;
+  // MERGE 3 (N ranks): the scalar update of the PREVIOUS reduction point happens here -- every thread of every workgroup (and
+  // every rank) forms the same few dozen flops from the records gathered from all ranks, summed in rank order (what the
+  // one-wave kernel behind an all-gather did, comm.hip k_gather_scalars: two launches per reduction point fewer).  The state
+  // is read from sc and written -- by one thread of the launch -- to A.sc_out, ANOTHER record: nobody of this launch reads what
+  // it writes.  A launch behind a finished solve hands the state on and returns.
+  KrylovScalars ST;
+  if constexpr (MERGE == 3) {
+    ST = *sc;
+    if (ST.status == 0 && A.pstage >= 0) {
+      double v[RED_REC];
+      sum_records(A.pg, A.pn, A.pnsum, A.pmax, v);
+      scalars_update(&ST, v, A.pstage);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *A.sc_out = ST;
+      if (A.host_status) __hip_atomic_store(A.host_status, ST.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    sc = &ST;
+  }
   if (sc->status != 0) {
     // (as k_sweepE_y: the last launch of a group of iterations reports to the host, also behind a solve that has ended)
-    if (EAB && A.host_status && blockIdx.x == 0 && threadIdx.x == 0)
+    if (MERGE != 3 && EAB && A.host_status && blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(A.host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }

@@ -245,6 +245,11 @@ struct FusedArgs {
   int rev;  // k_edge: the tiles in descending order (krylov_edge.h "Direction")
   int prev; // k_edge: a workgroup walks CONSECUTIVE rounds and takes the z edges of the side two consecutive 16 x 8 patches share
             // from the exports of its previous round (krylov_edge.h "Previous round")
+  // k_edge MERGE 3 (N ranks, deferred scalar update): the records of the previous reduction point gathered from all ranks
+  // ([pn][RED_REC]), the stage they belong to (-1: none pending), and where the updated state goes (the kernel's sc is read only)
+  const double *pg;
+  int pn, pstage, pnsum, pmax;
+  KrylovScalars *sc_out;
 };
 
 // one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)

@@ -17,7 +17,13 @@ def launch(mode, world, px, py, nbx, nby, port, timeout=600, **extra_env):
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, mode, str(px), str(py), str(nbx), str(nby)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=timeout, cwd=ROOT)
     out = r.stdout.decode()
-    assert r.returncode == 0 and "DIST_OK" in out, out[-4000:]
+    if r.returncode != 0 or "DIST_OK" not in out:
+        # the first worker traceback (the launcher's own summary fills the tail and names no cause)
+        lines = out.splitlines()
+        first = next((i for i, l in enumerate(lines) if "Traceback (most recent call last)" in l and "torch/distributed/run.py" not in "".join(lines[i:i + 8])), None)
+        cause = "\n".join(lines[first:first + 40]) if first is not None else ""
+        errs = "\n".join(l for l in lines if ("Error" in l or "error" in l or "assert" in l) and "elastic" not in l)[:3000]
+        raise AssertionError("rc %d\n---- first worker traceback ----\n%s\n---- error lines ----\n%s\n---- tail ----\n%s" % (r.returncode, cause, errs, out[-1500:]))
     for line in out.splitlines():  # what rank 0 measured (shown with -s)
         if line.startswith(("gpu_big", "amr_big", "amr_regrid_cpu")):
             print(line)

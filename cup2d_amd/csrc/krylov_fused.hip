@@ -1009,19 +1009,22 @@ static int ghost_rp(cup2d_ctx *c, const double *p, const double *nu, const doubl
 // blocks [first, first + count) (a multiple of 16 blocks in front of it: the tiling is the whole range's); merge 0: the launch
 // leaves its partials at [poff, poff + grid) and a later launch of the same sweep finishes over all of them.  *G: its grid.
 template <int MODE>
-static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int count, int poff, int *G) {
+static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int count, int poff, int *G, KrylovScalars *sc_in = nullptr) {
   const int g = fused_grid(c, count);
   const int share = edge_share_mode(c, MODE);
   FusedArgs a2 = a;
   static const int wmask = [] { const char *e = getenv("CUP2D_EDGE_WALK"); return e ? atoi(e) : 0; }();  // experiment: the contiguous walk alone
   a2.prev = ((share >> 1) & 1) ? 1 : (((wmask >> MODE) & 1) ? 2 : 0);
   const auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials, first, count,
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, sc_in ? sc_in : c->d_sc, c->d_partials, first, count,
                        poff, share, c->d_red, c->d_ticket, c->d_fault);
   };
   if (merge == 1) go(k_edge<MODE, 1>);
   else if (merge == 2) go(k_edge<MODE, 2>);
-  else go(k_edge<MODE, 0>);
+  else if (merge == 3) {  // N ranks, deferred scalar update: MODE 2 / 3 only (the A+B of iteration 0 keeps the scalar kernel behind it)
+    if constexpr (MODE >= 2) go(k_edge<MODE, 3>);
+    else { set_error("eab_sweep: MERGE 3 is for MODE 2 / 3"); return CUP2D_ERR_ARG; }
+  } else go(k_edge<MODE, 0>);
   CUP2D_HIP_CHECK(hipGetLastError());
   if (G) *G = g;
   return CUP2D_OK;
@@ -1311,7 +1314,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_edge<1, 1>), reinterpret_cast<const void *>(&k_edge<1, 2>),
                         reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>),
                         reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>),
-                        reinterpret_cast<const void *>(&k_edge<2, 0>), reinterpret_cast<const void *>(&k_edge<3, 0>)};
+                        reinterpret_cast<const void *>(&k_edge<2, 0>), reinterpret_cast<const void *>(&k_edge<3, 0>),
+                        reinterpret_cast<const void *>(&k_edge<2, 3>), reinterpret_cast<const void *>(&k_edge<3, 3>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1407,6 +1411,17 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     static const bool split_on = [] { const char *e = getenv("CUP2D_SWEEP_SPLIT"); return e && atoi(e) != 0; }();
     const bool split = split_on && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
     const bool ghost_local = ghost_local_enabled() && merge == 2 && gb;  // r' and p'' of the ghost blocks formed here, nu'' travels (k_ghost_rp)
+    // N ranks with the in-library communicator, "deferred" (the default there): per reduction point ONE pack launch and ONE RCCL
+    // kernel -- the rank's reduction record travels to every rank inside the ncclGroup that carries the ghost blocks (no
+    // all-gather), and the scalar update happens in the prologue of the sweep that consumes it (k_edge MERGE 3: no one-wave
+    // kernel) -- where round 4 had pack, send/recv, all-gather and the scalar kernel (profiles/r04_nrank_timeline.txt: 77 us of
+    // an iteration outside the sweeps).  The state alternates between two records (a launch reads one and writes the other).
+    // The host learns of the end of the solve one launch later than before (C+D' of iteration k reports the state after
+    // iteration k - 1).  Agreed over all ranks at cup2d_comm_init (comm_defer_ok); CUP2D_DEFER_SCALARS=0 keeps round 4's form.
+    const bool defer = merge == 2 && direct && ghost_local && !split && comm_defer_ok(c);
+    KrylovScalars *S[2] = {c->d_sc, c->d_sc2};
+    int sq = 0, enqueued = 0;
+    if (defer) c->last_merge = 3;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       c->prof_sample = true;
@@ -1431,6 +1446,36 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       }
       c->prof_sample = (k % 8 == 0) && k < max_iter;
       const int o = k & 1, n = o ^ 1;
+      enqueued = k + 1;
+      if (defer) {
+        {
+          FusedArgs a = {};
+          a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t; a.rev = zigzag;
+          a.pg = comm_gathered(c); a.pn = comm_nranks(c); a.pstage = k == 0 ? -1 : 4; a.pnsum = 2; a.pmax = 1;  // {rhat.nu'', r'.r', max|r'|}
+          a.sc_out = S[sq ^ 1];
+          a.host_status = last_of_group ? &c->h_status[slot] : nullptr;
+          ProfScope prof(c, CUP2D_T_SWEEP_C);
+          CUP2D_TRY(eab_sweep<3>(c, a, 3, 0, nb, 0, nullptr, S[sq]));
+          sq ^= 1;
+        }
+        CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr, false, nullptr, true));  // t of the ghost blocks + the five sums
+        {
+          FusedArgs a = {};
+          a.in0 = P[o]; a.in1 = N[o]; a.in2 = R[o]; a.w = c->d_rhat; a.vout = P[n]; a.yout = N[n];
+          a.t = c->d_t; a.y0 = c->d_y; a.y1 = c->d_yopt; a.y2 = c->d_xopt; a.rout = R[n];
+          a.pg = comm_gathered(c); a.pn = comm_nranks(c); a.pstage = 5; a.pnsum = 5; a.pmax = 0;
+          a.sc_out = S[sq ^ 1];
+          ProfScope prof(c, CUP2D_T_SWEEP_EA);
+          CUP2D_TRY(eab_sweep<2>(c, a, 3, 0, nb, 0, nullptr, S[sq]));
+          sq ^= 1;
+        }
+        // nu'' of the ghost blocks + {rhat.nu'', r'.r', max|r'|}; r' and p'' of the ghost blocks formed here with the scalars that
+        // launch used (the record it wrote)
+        const GhostRP G = {P[o], N[o], R[o], c->d_t, R[n], P[n], S[sq], (size_t)nb * BC, (size_t)c->nghost * BC};
+        CUP2D_TRY(comm_exchange_blocks(c, 1, N[n], nullptr, nullptr, false, &G, true));
+        if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
+        continue;
+      }
       {
         FusedArgs a = {};
         a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t;
@@ -1501,6 +1546,13 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         }
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
+    }
+    if (defer && enqueued > 0) {
+      // the last pending update (stage 4 of the last iteration enqueued; a no-op behind a solve that has ended) in a launch of its
+      // own, on the context's first record: what follows (the last pass over x, the host's copy of the scalars) reads it there
+      if (sq == 1) CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->d_sc2, sizeof(KrylovScalars), hipMemcpyDeviceToDevice, c->stream));
+      ProfScope prof(c, CUP2D_T_SCALARS);
+      if (comm_apply_gathered(c, 2, 1, 4) != 0) return CUP2D_ERR_COMM;
     }
   }
   for (int k = 0; !eab && k < max_iter; k++) {

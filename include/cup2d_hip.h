@@ -193,7 +193,9 @@ int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 /* what the last FUSED solve ran in detail (diagnostic, for tests that must know which organisation they pinned): form =
  * CUP2D_FORM_FULL | _EDGE | _EAB as resolved for that solve; merge = 0 finish launches, 1 finish in the kernel on one GPU,
- * 2 finish in the kernel + reductions over the ranks; handover = bit mask by kind of sweep (bit 0 A+B, 1 C+D, 2 E+A+B,
+ * 2 finish in the kernel + reductions over the ranks (an all-gather and a one-wave scalar kernel per reduction point), 3 the
+ * same on the in-library communicator with the reduction records inside the ghost blocks' send/recv group and the scalar
+ * update in the consumer sweep (one pack launch + one RCCL kernel per reduction point); handover = bit mask by kind of sweep (bit 0 A+B, 1 C+D, 2 E+A+B,
  * 3 C+D') of the sweeps whose sibling waves handed z edges through LDS.  All zero after a five-sweep solve. */
 int cup2d_get_last_solver_form(cup2d_ctx *ctx, int *form, int *merge, int *handover);
 /* The placement search of the solver's vectors (krylov_fused.hip tune_placement: the durations of the two launches of an

@@ -343,17 +343,21 @@ def test_ghost_blocks_received_in_place_equal_the_generic_exchange(gpu_lib):
     res = {}
     # (direct, local): the default; the generic transport path; three vectors travelling instead of r' and p'' of the ghost
     # blocks being formed by the receiver (k_ghost_rp)
-    for key in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
-        env = dict(os.environ, CUP2D_COMM_DIRECT=key[0], CUP2D_GHOST_LOCAL=key[1], NCCL_SOCKET_IFNAME="lo")
+    # (direct, local, deferred): the default -- the reduction records ride in the send/recv group and the scalar updates happen
+    # in the consumer sweeps (k_edge MERGE 3) --; round 4's organisation (all-gather + one-wave kernel per reduction point); ...
+    for key in (("1", "1", "1"), ("1", "1", "0"), ("0", "1", "1"), ("1", "0", "1"), ("0", "0", "1")):
+        env = dict(os.environ, CUP2D_COMM_DIRECT=key[0], CUP2D_GHOST_LOCAL=key[1], CUP2D_DEFER_SCALARS=key[2], NCCL_SOCKET_IFNAME="lo")
         r = subprocess.run([sys.executable, "-c", _DIRECT_CHILD % (root, root)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         lines = [l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")]
         assert r.returncode == 0 and lines, r.stdout.decode()[-3000:]
         res[key] = json.loads(lines[0][7:])
-    ref = res[("1", "1")]
+    ref = res[("1", "1", "1")]
     for key, other in res.items():
         for k in ref:
             a, b = ref[k], other[k]
-            assert a["form"] == b["form"] == ["eab", 2, a["form"][2]] and a["iters"] == b["iters"] == 6, (key, a, b)
+            # the organisation that ran: two launches per iteration; MERGE 3 (deferred scalar updates) only in the default
+            assert a["form"] == ["eab", 3, a["form"][2]] and b["form"] == ["eab", 3 if key == ("1", "1", "1") else 2, a["form"][2]], (key, a, b)
+            assert a["iters"] == b["iters"] == 6, (key, a, b)
             assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (key, k, a, b)
             assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"], (key, a, b)
             assert a["conv_err"] <= 1e-8 or a["conv_iters"] >= a["cap"], (key, a)

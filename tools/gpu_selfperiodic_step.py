@@ -46,7 +46,7 @@ def run(sim, label):
 
 with cup2d_amd.Simulation(nbx, nby, nu=1e-3) as s:
     t_plain = run(s, "plain context")
-s, g = _self_periodic_sim(nbx, nby)
+s, g = _self_periodic_sim(nbx, nby, os.environ.get("AXES", "xy"))  # "xy": ghost blocks on all four sides (an interior rank)
 with s:
     s.nu = 1e-3
     print("self-periodic patch: %d blocks, %d ghost blocks, halo set of %d x %d-block patches, n_inner %d" % (g.nblocks, g.nghost, g.halo_tile, g.halo_tile, g.n_inner))

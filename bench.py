@@ -95,6 +95,7 @@ def parse_args():
                                                       "rNN tag without a suffix)")
     ap.add_argument("--cpu-functor-n", type=int, default=4096, help="grid of the reference-functor CPU baseline (the headline size)")
     ap.add_argument("--no-nrank-proxy", action="store_true", help="skip the N-rank-path leg (a self-periodic patch through RCCL on this GPU)")
+    ap.add_argument("--no-second-size", action="store_true", help="skip the 2048^2 leg (BASELINE.json configs[1])")
     ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
     ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
     # (ranks started by spawn_ranks get their arguments through the environment: torch.distributed.run's argparse rejects
@@ -292,6 +293,22 @@ class Runner:
         self.sim.close()
 
 
+def tolerance_leg(step, sync, nsteps=5):
+    """What a user of the reference waits for after step 10 (run.sh:13-14, main.cpp:7028-7030): the same step with the solve
+    ended by -poissonTol 1e-3 -poissonTolRel 1e-2 -maxPoissonRestarts 0 (cap 1000 = -maxPoissonIterations) instead of by the cap
+    of 50 -- a few (10-40) iterations and then the solve's fixed costs and whatever the host had enqueued behind convergence."""
+    recs = []
+    for _ in range(nsteps):
+        sync()
+        t0 = time.perf_counter()
+        r = step(tol=1e-3, rel_tol=1e-2, max_restarts=0, max_iter=1000)
+        sync()
+        recs.append({"iters": r["iters"], "ms": round((time.perf_counter() - t0) * 1e3, 3), "err": r["err"]})
+    ms = sorted(x["ms"] for x in recs)
+    return {"tolerances": "-poissonTol 1e-3 -poissonTolRel 1e-2 -maxPoissonRestarts 0 -maxPoissonIterations 1000 (run.sh:13-14)",
+            "steps": recs, "iters_median": sorted(x["iters"] for x in recs)[len(recs) // 2], "ms_per_step_median": ms[len(ms) // 2]}
+
+
 def _proxy_velocity(nbx, nby):
     nxp, nyp = nbx * 8, nby * 8
     hh = 1.0 / max(nxp, nyp)
@@ -311,7 +328,7 @@ def _proxy_time(args, s, nst):
     return (time.perf_counter() - t0) / nst, r
 
 
-def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step):
+def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step, with_tolerance_leg=False):
     """one self-periodic patch (axes "x": ghost blocks W and E; "xy": on all four sides, the shape of an interior rank) timed
     next to the plain context of the same size (plain_s_per_step None: timed here)"""
     import ctypes
@@ -334,6 +351,7 @@ def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step):
         del vel
         el, r = _proxy_time(args, s, nst)
         form = s.last_solver_form()
+        tol_leg = tolerance_leg(s.step, s.synchronize, 3) if with_tolerance_leg else None
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "comm_stats")
         L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
@@ -342,7 +360,7 @@ def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step):
             "plain_context_ms_per_step": round(plain_s_per_step * 1e3, 3), "ratio_to_plain": round(el / plain_s_per_step, 4),
             "fixed_us_per_iteration_over_plain": round((el - plain_s_per_step) / max(1, r["iters"]) * 1e6, 1),
             "iters": r["iters"], "solver_form": list(form), "ghost_blocks": g.nghost, "halo_set_patch": g.halo_tile,
-            "n_inner": g.n_inner, "exchanges": ex.value, "allgathers": ag.value}
+            "n_inner": g.n_inner, "exchanges": ex.value, "allgathers": ag.value, "solve_to_tolerance": tol_leg}
 
 
 def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
@@ -351,7 +369,7 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
     # the headline patch with ghost blocks on all four sides (an interior rank; the 2 x 4 layout's ranks have two or three), the
     # same with the two x sides only (round 4's figure), and BASELINE.json configs[3]'s per-rank patch (4096 x 2048 cells) on
     # four sides next to a plain context of that size
-    out = nrank_proxy_patch(args, device, nbx, nby, "xy", plain)
+    out = nrank_proxy_patch(args, device, nbx, nby, "xy", plain, with_tolerance_leg=True)
     out["what"] = ("the N-rank code path of the step on one GPU: a patch that is its own W, E, S and N neighbour (ghost blocks on "
                    "all four sides, four send/recv pairs per ncclGroup to self, all-gather reductions, MERGE 2 kernels)")
     out["timeline"] = "profiles/r05_nrank_timeline.txt"
@@ -388,6 +406,10 @@ def amr_leg(args, device):
         L.check(s.L.cup2d_synchronize(s._ctx), "synchronize")
         el = (time.perf_counter() - t0) / nst
         solver, stats = s.last_solver(), s.matrix_stats()
+        try:
+            amr_tol = tolerance_leg(s.step, lambda: L.check(s.L.cup2d_synchronize(s._ctx), "synchronize"), 3)
+        except Exception as e:  # informative
+            amr_tol = {"error": str(e)[:200]}
         # one regrid the way a run does it (tags from max|vorticity| per block: here the band moves with the thresholds)
         # regrids the way a run does them (tags from max|vorticity| per block: the band moves with the thresholds, a few
         # steps in between): the FIRST one of a process pays one-time costs (kernels loaded, pools empty: first_ms), a run
@@ -422,7 +444,7 @@ def amr_leg(args, device):
                         "iters on the assembled coarse-fine operator" % (8 << args.amr_lfine, args.iters),
             "blocks": g.nblocks, "cells": g.nblocks * 64, "blocks_per_level": np.bincount(g.blocks[:, 0]).tolist(),
             "value": round(g.nblocks * 64 / el / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_step": round(el * 1e3, 3),
-            "iters": r["iters"], "solver": solver, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
+            "iters": r["iters"], "solver": solver, "solve_to_tolerance": amr_tol, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
             "grid_build_ms": round(t_grid * 1e3, 1), "plan_on_8_ranks": plan8,
             "regrid": {"changed": bool(changed), "blocks_before": warm["blocks_before"], "blocks_after": nb_after,
                        "ms": round(t_adapt * 1e3, 1), "first_ms": regrids[0]["ms"], "all": regrids,
@@ -754,6 +776,24 @@ def main():
                  "families": {f: round(v, 4) for f, v in step_ms.items() if v},
                  "note": "final_x = the solve's last pass x = P_inv y (under a timer since round 4)"}
 
+    # the same workload with the solve ended by the reference's tolerances (what a run does after step 10)
+    tol_leg = None
+    if world == 1 and dist is None:
+        try:
+            sim.set_timing(False)
+            tol_leg = tolerance_leg(sim.step, sim.synchronize, 5)
+            if solver:
+                n_it, it_ms = tol_leg["iters_median"], solver["ms_per_iteration"]
+                outside = gpu_split["outside_the_sweeps"]
+                tol_leg.update({"ms_per_iteration_from_the_capped_run": it_ms, "gpu_ms_outside_the_sweeps_from_the_capped_run": outside,
+                                "ms_not_in_iterations_or_fringe": round(tol_leg["ms_per_step_median"] - n_it * it_ms - outside, 3),
+                                "note": "ms_not_in_iterations_or_fringe = median step - iterations x ms per iteration - the fringe of the "
+                                        "capped step: what the solve's end costs (launches the host had enqueued behind convergence -- it "
+                                        "looks once per group of 4 iterations and stays 2 groups ahead --, its final wait)"})
+        except Exception as e:  # informative
+            tol_leg = {"error": str(e)[:200]}
+        beat("tolerance leg")
+
     # where the solver's vectors lie (csrc/krylov_fused.hip tune_placement): the search the first solve of the context ran
     placement = None
     try:
@@ -868,6 +908,22 @@ def main():
                                                                                             verified.get("residual_recomputed")],
                             "last_iterate_relative_gap": li.get("relative_gap"), "eight_iterations_vs_five_sweeps": e8.get("relative"),
                             "error": verified.get("error")}
+    # BASELINE.json configs[1] (2048^2 uniform, 50 iterations per step) on the same box, same step: a second, driver-visible size
+    second_size = None
+    if rank == 0 and world == 1 and dist is None and args.n != 2048 and not args.no_second_size:
+        beat("second size")
+        try:
+            import cup2d_amd
+            with cup2d_amd.Simulation(256, 256, nu=1e-3, cfl=0.5, device=local_rank) as s2:
+                s2.set_math(args.math == "strict")
+                s2.set_solver(fused=args.solver == "fused", finish_in_kernel=args.finish == "kernel")
+                s2.vel = synthetic_velocity(2048, 2048, 0, 0, 2048, 2048, seed=20250117)
+                el2, r2 = _proxy_time(args, s2, max(5, min(args.steps, 20)))
+            second_size = {"workload": "2048x2048 uniform cells (BASELINE.json configs[1]), the same step", "value": round(2048 * 2048 / el2 / 1e6, 2),
+                           "unit": "Mcell-updates/s", "ms_per_step": round(el2 * 1e3, 3), "iters": r2["iters"]}
+        except Exception as e:  # informative
+            second_size = {"error": str(e)[:200]}
+
     if rank == 0:
         out = {
             "metric": "Mcell-updates/sec (advect-diffuse+Poisson sweep) at 4096^2",
@@ -886,9 +942,9 @@ def main():
                        "comm": comm_info},
             "verified": verified, "second_layout": second,
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
-            "gpu_ms_per_step": gpu_split,
+            "gpu_ms_per_step": gpu_split, "solve_to_tolerance": tol_leg,
             "kernels": timers, "roofline_extra_sampled_steps_outside_timed_region": extra_sampled_steps,
-            "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy, "placement": placement,
+            "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy, "placement": placement, "second_size": second_size,
         }
     if second is None or world == 1:
         run.close()

@@ -260,8 +260,23 @@ def have_reference_b2():
     return os.path.exists(REF_HARNESS_B2) and os.access(REF_HARNESS_B2, os.X_OK)
 
 
+def _base_grid(nx, ny):
+    """(levelStart, bpdx, bpdy) of an nx x ny-cell uniform grid in the reference's terms: bpdx x bpdy base blocks refined
+    levelStart times, the shorter side one base block (main.cpp:6338: h = extent / max(bpdx, bpdy) / 8 / 2^level)"""
+    n = min(nx, ny)
+    assert nx % n == 0 and ny % n == 0, "reference harness grids are (bpdx n) x (bpdy n), n = 8*2^k"
+    return _level(n), nx // n, ny // n
+
+
 def _run_ref(mode, n, d, _threads=None, _timeout=None, _hip=False, _env=None, _b2=False, **kw):
-    cmd = [REF_HARNESS_B2 if _b2 else (REF_HARNESS_HIP if _hip else REF_HARNESS), mode, str(_level(n)), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
+    """n: cells per side, or (nx, ny) for a rectangle of bpdx x bpdy base blocks"""
+    if isinstance(n, tuple):
+        lv, bx, by = _base_grid(*n)
+        if (bx, by) != (1, 1):
+            kw = dict(kw, bpdx=bx, bpdy=by)
+    else:
+        lv = _level(n)
+    cmd = [REF_HARNESS_B2 if _b2 else (REF_HARNESS_HIP if _hip else REF_HARNESS), mode, str(lv), d] + ["%s=%.17g" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in kw.items()]
     env = dict(os.environ)
     if _threads:
         env.update(OMP_NUM_THREADS=str(int(_threads)), OMP_PROC_BIND="close", OMP_PLACES="cores")
@@ -278,8 +293,8 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None, nomatrix=Fals
     Returns dict of arrays (see ref_harness.cpp 'functors').  nomatrix: the harness drops the Poisson triplets the
     reference's start-up assembles (the functors never read them; at 4096^2 that is most of the run time)."""
     vel = _c(vel)
-    n = vel.shape[0]
-    assert vel.shape == (n, n, 2)
+    ny, n = vel.shape[:2]   # (ny, nx, 2): a square, or a rectangle of whole base blocks (keys bpdx, bpdy of the harness)
+    assert vel.shape == (ny, n, 2)
     with tempfile.TemporaryDirectory() as d:
         vel.tofile(os.path.join(d, "vel.in"))
         if pres is not None:
@@ -293,12 +308,12 @@ def ref_functors(vel, nu, dt=None, pres=None, chi=None, udef=None, nomatrix=Fals
             kw["dt"] = float(dt)
         if nomatrix:
             kw["nomatrix"] = 1
-        _run_ref("functors", n, d, **kw)
+        _run_ref("functors", (n, ny), d, **kw)
         out = {}
         for name, dim in [("advdiff_rhs", 2), ("rk2_stage1", 2), ("rk2_vel", 2), ("vorticity", 1), ("pressure_rhs", 1),
                           ("poisson_b", 1), ("pgrad_tmpV", 2), ("projected_vel", 2)]:
             a = np.fromfile(os.path.join(d, name + ".out"))
-            out[name] = a.reshape(n, n, 2) if dim == 2 else a.reshape(n, n)
+            out[name] = a.reshape(ny, n, 2) if dim == 2 else a.reshape(ny, n)
         s = np.fromfile(os.path.join(d, "scalars.out"))
         out["dt_ref"], out["umax"], out["h"], out["dt"] = s
         out["block_order"] = np.fromfile(os.path.join(d, "block_order.out")).reshape(-1, 2).astype(np.int64)

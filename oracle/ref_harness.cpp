@@ -427,7 +427,8 @@ void __wrap__ZN15LocalSpMatDnVec13solveNoUpdateEddi(LocalSpMatDnVec *M, double e
 /* ------------------------------------------------------------------------ */
 /* harness proper                                                           */
 /* ------------------------------------------------------------------------ */
-static int g_n = 0; /* cells per side */
+static int g_n = 0; /* cells per side of one base block (-bpdx / -bpdy of them: keys bpdx, bpdy) */
+static int g_bpdx = 1, g_bpdy = 1, g_nx = 0, g_ny = 0; /* the grid is g_nx x g_ny cells, row-major arrays have rows of g_nx */
 
 #ifdef HARNESS_B2
 /* ---- seam B2: the call sites of main.cpp served by libcup2d_hip.so through include/cup2d_hip.h ----------------------
@@ -637,15 +638,15 @@ static void scatter(Grid *g, int dim, const std::vector<double> &glob) {
       for (int ix = 0; ix < _BS_; ix++)
         for (int c = 0; c < dim; c++)
           I.block[dim * (iy * _BS_ + ix) + c] =
-              glob[dim * ((size_t)(I.index[1] * _BS_ + iy) * g_n + I.index[0] * _BS_ + ix) + c];
+              glob[dim * ((size_t)(I.index[1] * _BS_ + iy) * g_nx + I.index[0] * _BS_ + ix) + c];
 }
 static std::vector<double> gather(Grid *g, int dim) {
-  std::vector<double> glob((size_t)g_n * g_n * dim);
+  std::vector<double> glob((size_t)g_nx * g_ny * dim);
   for (auto &I : g->infos)
     for (int iy = 0; iy < _BS_; iy++)
       for (int ix = 0; ix < _BS_; ix++)
         for (int c = 0; c < dim; c++)
-          glob[dim * ((size_t)(I.index[1] * _BS_ + iy) * g_n + I.index[0] * _BS_ + ix) + c] =
+          glob[dim * ((size_t)(I.index[1] * _BS_ + iy) * g_nx + I.index[0] * _BS_ + ix) + c] =
               I.block[dim * (iy * _BS_ + ix) + c];
   return glob;
 }
@@ -655,12 +656,12 @@ static void dump_grid(const std::string &path, Grid *g, int dim) {
 }
 /* x_/b_ of the linear system are in local block order (id*64+j, getVec main.cpp:6002-6018) */
 static std::vector<double> blockvec_to_global(const std::vector<double> &x) {
-  std::vector<double> glob((size_t)g_n * g_n);
+  std::vector<double> glob((size_t)g_nx * g_ny);
   auto &infos = var.tmp->infos;
   for (size_t i = 0; i < infos.size(); i++)
     for (int iy = 0; iy < _BS_; iy++)
       for (int ix = 0; ix < _BS_; ix++)
-        glob[(size_t)(infos[i].index[1] * _BS_ + iy) * g_n + infos[i].index[0] * _BS_ + ix] =
+        glob[(size_t)(infos[i].index[1] * _BS_ + iy) * g_nx + infos[i].index[0] * _BS_ + ix] =
             x[i * _BS_ * _BS_ + iy * _BS_ + ix];
   return glob;
 }
@@ -670,7 +671,7 @@ static void global_to_blockvec(const std::vector<double> &glob, std::vector<doub
     for (int iy = 0; iy < _BS_; iy++)
       for (int ix = 0; ix < _BS_; ix++)
         x[i * _BS_ * _BS_ + iy * _BS_ + ix] =
-            glob[(size_t)(infos[i].index[1] * _BS_ + iy) * g_n + infos[i].index[0] * _BS_ + ix];
+            glob[(size_t)(infos[i].index[1] * _BS_ + iy) * g_nx + infos[i].index[0] * _BS_ + ix];
 }
 
 static std::string g_shapes; /* key shapes=...: the reference's own -shapes descriptor (fish), e.g. "angle=0 L=0.2 xpos=0.5 ypos=0.5" */
@@ -679,7 +680,7 @@ static int run_reference_main(int levelStart, double nu, double cfl, double tend
   /* uniform n x n recipe: one base block, all blocks at
    * levelStart, refinement and compression disabled */
   std::vector<std::string> a = {"ref_harness",
-      "-bpdx", "1", "-bpdy", "1",
+      "-bpdx", std::to_string(g_bpdx), "-bpdy", std::to_string(g_bpdy),
       "-levelMax", std::to_string(levelMax > 0 ? levelMax : levelStart + 1), "-levelStart", std::to_string(levelStart),
       "-Rtol", "1e30", "-Ctol", "0", "-AdaptSteps", std::to_string(adaptSteps), "-extent", "1",
       "-CFL", std::to_string(cfl), "-tend", std::to_string(tend), "-lambda", "1e7",
@@ -739,7 +740,8 @@ static void usage() {
           "   amr      : the reference time loop with refinement on (levelmax= rtol= ctol= steps=), analytic vortex-pair IC;\n"
           "              writes blocks.final (level, i, j, vel, pres per block) and meta.txt\n"
           "   dump     : read <dir>/vel.in; write vel.{xyz.raw,attr.raw,xdmf2} with the reference's dump() (time = dt key)\n"
-          "  keys: nu dt cfl steps reps tol reltol restarts maxiter nomatrix (functors/bench/dump: do not assemble the matrix)\n");
+          "  keys: nu dt cfl steps reps tol reltol restarts maxiter nomatrix (functors/bench/dump: do not assemble the matrix)\n"
+          "        bpdx bpdy (base blocks of the reference's -bpdx / -bpdy: a (bpdx n) x (bpdy n)-cell grid, n = 8 * 2^levelStart)\n");
 }
 
 int main(int argc, char **argv) {
@@ -771,10 +773,14 @@ int main(int argc, char **argv) {
     else if (k == "ctol") ctol_amr = atof(v.c_str());
     else if (k == "nomatrix") nomatrix = atoi(v.c_str());
     else if (k == "shapes") g_shapes = v;
+    else if (k == "bpdx") g_bpdx = atoi(v.c_str());
+    else if (k == "bpdy") g_bpdy = atoi(v.c_str());
     else { usage(); return 2; }
   }
   g_n = _BS_ << levelStart;
-  const size_t N = (size_t)g_n * g_n;
+  if (g_bpdx < 1 || g_bpdy < 1) { usage(); return 2; }
+  g_nx = g_bpdx * g_n; g_ny = g_bpdy * g_n;
+  const size_t N = (size_t)g_nx * g_ny;
   hooks.forced_max_iter = maxiter;
 #ifndef HARNESS_HIP_SPMAT
   hooks.skip_matrix = nomatrix != 0 && (mode == "functors" || mode == "bench" || mode == "dump");
@@ -1097,7 +1103,7 @@ int main(int argc, char **argv) {
   }
   hooks.on_solve = nullptr;
   if ((size_t)var.vel->infos.size() * _BS_ * _BS_ != N) {
-    fprintf(stderr, "ref_harness: grid is not uniform %d^2 (blocks=%zu)\n", g_n, var.vel->infos.size());
+    fprintf(stderr, "ref_harness: grid is not uniform %d x %d (blocks=%zu)\n", g_nx, g_ny, var.vel->infos.size());
     return 3;
   }
   sim.nu = nu;

@@ -106,6 +106,54 @@ def test_functors_vs_live_reference_at_baseline_size(gpu_lib, oracle, n):
         assert np.array_equal(s.vel, O.add_scaled(G["rk2_vel"], gref, h))
 
 
+def test_functors_vs_live_reference_on_the_configs3_rectangle(gpu_lib, oracle):
+    """8192 x 2048 cells (the reference's -bpdx 4 -bpdy 1 -levelStart 8): the global grid of BASELINE.json configs[3] on two ranks
+    in x, whose single context is the reference of tests/test_distributed.py::test_decomposed_path_at_configs3_rank_size_gpu[2-1-..]
+    -- pinned here to the reference itself (oracle/_ref/ref_harness run live), every functor STRICT bit for bit: a rectangle's
+    h = extent / max(bpdx, bpdy) / 8 / 2^level (main.cpp:6338), its walls, 262 144 blocks in an order that is not the square's"""
+    import cup2d_amd
+    O = oracle
+    _need_reference(O)
+    nx, ny, nu = 8192, 2048, 1e-3
+    rng = np.random.default_rng(7 + nx)
+    vel = O.taylor_green(nx, noise=1e-3, seed=20250117, ny=ny)
+    x, y = (np.arange(nx) + 0.5) / nx, (np.arange(ny) + 0.5) / nx
+    X, Y = np.meshgrid(x, y, indexing="xy")
+    pres = np.cos(2 * np.pi * X) * np.cos(4 * np.pi * Y) + 1e-2 * rng.uniform(-1, 1, (ny, nx))
+    del X, Y
+    chi = rng.uniform(0, 1, (ny, nx))
+    udef = 0.1 * rng.uniform(-1, 1, (ny, nx, 2))
+    G = O.ref_functors(vel, nu, pres=pres, chi=chi, udef=udef, nomatrix=True)
+    dt = float(G["dt"])
+    with cup2d_amd.Simulation(nx // 8, ny // 8, nu=nu) as s:
+        assert s.h == float(G["h"]) == 1.0 / nx
+        s.set_math(True)
+        s.vel = vel
+        assert s.max_abs_vel() == float(G["umax"]) and s.compute_dt() == float(G["dt_ref"])
+        s.advect_diffuse_rhs(dt)
+        assert np.array_equal(s.tmpV, G["advdiff_rhs"])
+        s.advect_diffuse_rk2(dt)
+        assert np.array_equal(s.vel, G["rk2_vel"])
+        s.vorticity()
+        assert np.array_equal(s.tmp, G["vorticity"])
+        s.tmpV = udef
+        s.chi = chi
+        s.pressure_rhs(dt, use_bodies=True)
+        assert np.array_equal(s.tmp, G["pressure_rhs"])
+        s.pold = pres
+        s.laplacian_sub()
+        assert np.array_equal(s.tmp, G["poisson_b"])
+        s.pres = pres
+        s.pressure_correction(dt)
+        assert np.array_equal(s.tmpV, G["pgrad_tmpV"])
+        s.add_correction()
+        assert np.array_equal(s.vel, G["projected_vel"])
+        s.set_math(False)
+        s.vel = vel
+        s.advect_diffuse_rhs(dt)
+        assert np.abs(s.tmpV - G["advdiff_rhs"]).max() <= 2e-13 * np.abs(G["advdiff_rhs"]).max()
+
+
 def test_functor_pass_at_8192_vs_restatement(gpu_lib, oracle):
     """configs[3]'s global grid (1 048 576 blocks, 5.4 GB of fields) on one GPU: one pass of every block functor
     against oracle/liboracle.so, which tests/test_oracle_vs_reference.py pins bit for bit to the reference functors"""

@@ -97,3 +97,29 @@ def test_live_reference_if_present(oracle):
     pr = oracle.pressure_rhs(v2, h, dt)
     assert np.array_equal(pr, R["pressure_rhs"])
     assert np.array_equal(oracle.laplacian_sub(pres, pr), R["poisson_b"])
+
+
+@pytest.mark.parametrize("nx,ny", [(128, 32), (32, 128)])
+def test_live_reference_on_a_rectangle_if_present(oracle, nx, ny):
+    """-bpdx 4 -bpdy 1 and -bpdx 1 -bpdy 4 (run.sh itself runs -bpdx 2 -bpdy 1): the shape of BASELINE.json configs[3]'s grid on
+    two ranks (8192 x 2048 cells) and of its 2 x 4 layout's global grid -- h = extent / max(bpdx, bpdy) / 8 / 2^level
+    (main.cpp:6338), walls on a non-square domain: the restatement equals the reference's functors bit for bit"""
+    if not oracle.have_reference():
+        pytest.skip("oracle/_ref/ref_harness not built (needs /root/reference)")
+    vel = oracle.taylor_green(nx, noise=0.2, seed=7, ny=ny)
+    rng = np.random.default_rng(6)
+    pres, chi, udef = rng.uniform(-1, 1, (ny, nx)), rng.uniform(0, 1, (ny, nx)), 0.1 * rng.uniform(-1, 1, (ny, nx, 2))
+    R = oracle.ref_functors(vel, 1e-3, pres=pres, chi=chi, udef=udef, nomatrix=True)
+    h, dt = 1.0 / max(nx, ny), float(R["dt"])
+    assert float(R["h"]) == h and float(R["umax"]) == np.abs(vel).max()
+    assert oracle.compute_dt(h, 1e-3, 0.5, float(R["umax"])) == float(R["dt_ref"])
+    assert np.array_equal(oracle.advect_diffuse_rhs(vel, h, 1e-3, dt), R["advdiff_rhs"])
+    v2, _ = oracle.rk2_advect_diffuse(vel, h, 1e-3, dt)
+    assert np.array_equal(v2, R["rk2_vel"])
+    assert np.array_equal(oracle.vorticity(v2, h), R["vorticity"])
+    pr = oracle.pressure_rhs(v2, h, dt, udef, chi)
+    assert np.array_equal(pr, R["pressure_rhs"])
+    assert np.array_equal(oracle.laplacian_sub(pres, pr), R["poisson_b"])
+    g = oracle.pressure_correction(pres, h, dt)
+    assert np.array_equal(g, R["pgrad_tmpV"])
+    assert np.array_equal(oracle.add_scaled(v2, g, h), R["projected_vel"])

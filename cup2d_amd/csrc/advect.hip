@@ -265,13 +265,11 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
   ProfScope prof(c, (mode == 1 && vold != vel) ? CUP2D_T_ADVECT_STAGE2 : CUP2D_T_ADVECT_STAGE);  // stage 2 reads its own old values: 48 B/cell
   const double2 *v = (const double2 *)vel, *vo = (const double2 *)vold;
   double2 *o = (double2 *)out;
-  // groups (of 4 blocks) per workgroup; CUP2D_ADVECT_CHUNK=0 selects the persistent grid
-  static const int chunk = [] { const char *e = getenv("CUP2D_ADVECT_CHUNK"); return e ? atoi(e) : 16; }();
+  constexpr int chunk = 16;  // groups (of 4 blocks) per workgroup of the per-block kernel (0 would select the persistent grid)
   // FAST policy: quads of 2 x 2 blocks take the register-walk kernel, blocks without partners the per-block one
   // (CUP2D_ADVECT_WALK=0: everything per block, the round-1 kernel -- A/B timing aid)
   static const bool use_walk = [] { const char *e = getenv("CUP2D_ADVECT_WALK"); return !e || atoi(e) != 0; }();
-  static const int wchunk = [] { const char *e = getenv("CUP2D_WALK_CHUNK"); return e ? atoi(e) : 0; }();
-  static const int wprio = [] { const char *e = getenv("CUP2D_WALK_PRIO"); return e ? atoi(e) : 1; }();
+  constexpr int wchunk = 0, wprio = 1;  // the quad kernel: persistent grid, s_setprio around the arithmetic phases (measured: round 2)
   const int *list = nullptr;
   if (c->math != CUP2D_MATH_STRICT && use_walk && ((size_t)c->ntotal << 10) < (1ull << 32)) {  // 32-bit byte offsets into a vector slab
     const WalkPlan *p = walk_plan(c, first, count);

@@ -74,10 +74,6 @@ int resident_grid(cup2d_ctx *c, const void *kernel, int count) {
   if (per_cu == 0) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WG, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 8) per_cu = 8;
-    if (const char *e = getenv("CUP2D_WGS_PER_CU")) {  // tuning aid: cap the persistent grid
-      const int cap = atoi(e);
-      if (cap >= 1 && cap < per_cu) per_cu = cap;
-    }
     c->resident.emplace_back(kernel, per_cu);
   }
   const int groups = (count + WPG - 1) / WPG;
@@ -323,10 +319,6 @@ static int create_impl(cup2d_ctx *c, int nblocks, int nghost, int n_inner, const
   c->n_inner = n_inner;
   c->h = h;
   c->grid = MAX_GRID;
-  if (const char *e = getenv("CUP2D_SOLVER")) c->solver = e[0] == 'f' ? CUP2D_SOLVER_FUSED : CUP2D_SOLVER_SWEEPS;
-  if (const char *e = getenv("CUP2D_FINISH_IN_KERNEL")) c->finish_in_kernel = atoi(e) != 0;
-  if (const char *e = getenv("CUP2D_PRECOND"))  // A/B timing aid; cup2d_set_precond is the API
-    c->precond = e[0] == 'l' ? PRECOND_LDS : (e[0] == 'm' ? PRECOND_MFMA : PRECOND_FD);
   HostRes res;
   bool recycled = false;
   {
@@ -437,7 +429,6 @@ void cup2d_destroy(cup2d_ctx *c) {
   for (double *p : kv) dev_free(p);
   double *fv[] = {c->d_p2, c->d_nu2, c->d_s, c->d_y, c->d_yopt};
   for (double *p : fv) dev_free(p);
-  for (double *p : c->d_edge) dev_free(p);
   dev_free(c->d_fault);
   dev_free(c->d_ticket);
   dev_free(c->d_sc);
@@ -1134,7 +1125,7 @@ int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *r
   // diagonal = -(number of neighbours) -- is applied matrix-free from its four neighbour ids; only the other slices
   // (coarse-fine rows, rows with halo columns, anything else the caller assembled) keep stored entries.  On an adapted
   // grid that is ~5 % of the blocks; the stored form costs 12 B per entry and bounds the product otherwise.
-  static const bool hybrid = [] { const char *e = getenv("CUP2D_MATRIX_HYBRID"); return !e || atoi(e) != 0; }();
+  constexpr bool hybrid = true;
   std::vector<int32_t> reg((size_t)4 * c->nblocks, CUP2D_WALL);
   int nregular = 0;
   if (hybrid) {

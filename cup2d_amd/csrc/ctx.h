@@ -159,7 +159,6 @@ struct cup2d_ctx {
   int *d_fault = nullptr;    // k_edge's fault word (krylov_edge.h)
   int solver_form = 0;       // cup2d_fused_form (0: the process default, CUP2D_FUSED_FORM)
   int edge_share = -1;       // k_edge: sibling waves share z edges (-1: not yet decided from the neighbour table)
-  double *d_edge[8] = {nullptr};  // stored-edge ring (krylov_fused.hip): z, P_inv nu, z2, P_inv t on block edges, two buffers each
   int solver = 1;            // cup2d_solver_kind: 0 five sweeps (krylov.hip), 1 tile-fused (krylov_fused.hip)
   int last_solver = 0;       // what the last solve ran
   int last_form = 0, last_merge = 0, last_handover = 0;  // cup2d_get_last_solver_form

@@ -871,11 +871,8 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
   // 513, 533): it stays at most AHEAD iterations in front of the GPU by waiting on the event recorded
   // AHEAD iterations ago, and learns the outcome of that iteration from a pinned word its last
   // scalar kernel wrote.  At most AHEAD iterations of early-returning kernels are wasted.
-  static const int AHEAD = [] {
-    const char *e = getenv("CUP2D_SOLVE_AHEAD");
-    const int v = e ? atoi(e) : 4;
-    return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
-  }();
+  constexpr int AHEAD = 4;
+  static_assert(AHEAD <= cup2d_ctx::SOLVE_AHEAD, "event ring of the context");
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
   for (int k = 0; k < max_iter; k++) {  // (exactly max_iter: iterations behind the cap could only return at once)
     const int slot = k % AHEAD;

@@ -219,27 +219,18 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // tiles of 16 blocks; the 8 waves of a workgroup take 8 consecutive tiles per round, contiguous ranges per XCD
   const int ntiles = (count + TB - 1) / TB;
   int t_begin, t_end, t_stride;
-  // (the exports are the hand-over's: the host has checked that the grid allows them, edge_share_ok; MODE 2 / 3 only -- the
-  // A+B of iteration 0 runs once per solve and its registers are full)
-  const bool prev_on = (MODE >= 2) && A.prev == 1;
-  const bool contiguous = (MODE >= 2) && A.prev != 0;  // (A.prev == 2: the contiguous walk alone -- what the order costs by itself)
   {
     const int G = gridDim.x, w = blockIdx.x;
     if (G >= 8 && (G % 8) == 0) {
+      // strided walk inside the XCD's contiguous range: the 32 workgroups of an XCD sweep 32 ADJACENT 16 x 8 patches at the same
+      // time and meet in its L2 and in the memory-side cache (a contiguous piece per workgroup -- consecutive rounds as
+      // neighbouring patches, their shared side taken from the previous round's exports -- was built in round 4 and is
+      // slower: the walk costs 6-15 us per launch, the exports return 3-5)
       const int xcd = w & 7, slot = w >> 3, per = G >> 3;
       const long long lo = (long long)ntiles * xcd / 8, hi = (long long)ntiles * (xcd + 1) / 8;
-      if (contiguous) {
-        // Previous round: the workgroup owns a CONTIGUOUS piece of its XCD's range and walks it round by round, so that two
-        // consecutive rounds are neighbouring patches of the Hilbert order
-        const long long nr = (hi - lo + FWAVES - 1) / FWAVES, r0 = nr * slot / per, r1 = nr * (slot + 1) / per;
-        t_begin = (int)(lo + r0 * FWAVES) + wave;
-        t_end = (int)(lo + r1 * FWAVES < hi ? lo + r1 * FWAVES : hi);
-        t_stride = FWAVES;
-      } else {
-        t_begin = (int)lo + slot * FWAVES + wave;
-        t_end = (int)hi;
-        t_stride = per * FWAVES;
-      }
+      t_begin = (int)lo + slot * FWAVES + wave;
+      t_end = (int)hi;
+      t_stride = per * FWAVES;
     } else {
       t_begin = w * FWAVES + wave;
       t_end = ntiles;
@@ -267,10 +258,9 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     int is_ring, pad;                       // ... of which the ones to recompute (no tail padding: copies stay in registers)
   };
   // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the previous tile's)
-  // share: bit 0 = edges of the siblings of the SAME round are taken from their exports (a wait per sibling), bit 1 = ... of the
-  // workgroup's PREVIOUS round (tp0 = its first tile, -1: none; published long ago: no wait to speak of)
+  // share: edges of the siblings of the same round are taken from their exports (a wait per sibling)
   const bool share_now = (share & 1) != 0;
-  const auto classify = [&](int t, int nb, int tp0) -> Tile {
+  const auto classify = [&](int t, int nb) -> Tile {
     Tile T;
     T.b0 = first + t * TB;
     T.nvalid = min(TB, last - T.b0);
@@ -279,11 +269,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     // a sibling: another tile this workgroup holds in the same round (tiles t - wave .. t - wave + 7 below t_end)
     const int nt = (nb - first) / TB, t0 = t - wave;
     const bool sibling = share_now && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
-    const bool prevsib = prev_on && tp0 >= 0 && outside && nb >= first && nb < last && nt >= tp0 && nt < tp0 + FWAVES && nt < t_end;
     T.sib = sibling ? nt - t0 : -1;
     T.pmask = __ballot(outside);
-    T.is_ring = outside && !sibling && !prevsib;
-    T.pad = prevsib ? nt - tp0 : -1;  // the wave of the previous round that exported this slot's edge
+    T.is_ring = outside && !sibling;
+    T.pad = 0;
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (KNOCK & 6) ? 0 : __popcll(rmask);
     T.npass = (T.nring + TB - 1) / TB;
@@ -361,7 +350,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   Tile T;
   int j = tile_at(0) < t_end ? 0 : 1;
   if (tile_at(j) < t_end) {
-    T = classify(tile_at(j), load_nb(tile_at(j)), -1);
+    T = classify(tile_at(j), load_nb(tile_at(j)));
     issue_ring(Qa, T, 0, 0);  // (always: a batch set that is assigned on SOME paths only is live around the whole loop)
     issue_ring(Qb, T, 0, 1);
   }
@@ -480,7 +469,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     // this tile's ring list is dead: the NEXT tile is classified into it (past the wave's last tile: this tile once more --
     // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
-    N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb, more ? t - wave : -1);
+    N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb);
     nb_next = load_nb(tile_at(round + 2));
     if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
     // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
@@ -491,9 +480,8 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
       // this buffer held round - NXB: a sibling has read it by the END of that round of its own, i.e. once it has published
-      // the round after it.  Previous round: a sibling in round r also reads the exports of round r - 1, so a buffer may be
-      // overwritten only when every sibling has published the round BEHIND the one that read it last (one round later)
-      const int need = prev_on ? round - NXB + 3 : round - NXB + 2;
+      // the round after it
+      const int need = round - NXB + 2;
       if (need > 0) {
         for (int u = 0; u < FWAVES; u++)
           if (u != wave) edge_wait(pub, u, need, fault);
@@ -528,24 +516,6 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           const int slot = min((int)__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);  // (int: min(unsigned, int) resolves to the double overload)
 #pragma unroll
           for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[par][slot * BS + q];
-        }
-      }
-    }
-    // ---- ... or exported in the workgroup's previous round (published at least a tile's work ago) ----
-    if (prev_on && !(KNOCK & 4)) {
-      const int ppar = (round + NXB - 1) % NXB;
-      const int pb0 = first + tile_at(round - 1 < 0 ? 0 : round - 1) * TB - wave * TB;  // first block of the previous round's first tile
-      for (int u = 0; u < FWAVES; u++) {
-        const bool mine = T.pad == u;
-        if (__ballot(mine) == 0ull) continue;
-        edge_wait(pub, u, round, fault);
-        if (mine) {
-          const EdgeLds &O = LL[u];
-          const unsigned long long m = O.xmask[ppar];
-          const int bit = (T.nb - (pb0 + u * TB)) * 4 + (ss ^ 1);
-          const int slot = min((int)__popcll(m & ((1ull << bit) - 1ull)), EXP_SLOTS - 1);
-#pragma unroll
-          for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = O.X[ppar][slot * BS + q];
         }
       }
     }

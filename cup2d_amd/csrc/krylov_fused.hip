@@ -231,20 +231,12 @@ struct FusedArgs {
   const double *in0, *in1, *in2;  // AB: p, nu, r     CD: r, nu, -
   double *w;                      // AB: rhat (written on a restart)
   double *vout, *yout;            // AB: p', nu'      CD: s, t
-  // stored-edge ring (RE > 0), arrays of [block][side W,E,S,N][8] doubles:
-  //   AB reads  e0 = z edges of the p it reads, e1 = (P_inv nu) edges, e2 = z2 edges, e3 = (P_inv t) edges of the last CD
-  //      writes o0 = z' edges, o1 = (P_inv nu') edges
-  //   CD reads  e1 = (P_inv nu') edges AB has just written, e2, e3 as AB;  writes o0 = z2' edges, o1 = (P_inv t') edges
-  const double *e0, *e1, *e2, *e3;
-  double *o0, *o1;
   // k_edge MODE 2 (sweep E + the next A+B): t, the three buffers of the accumulated correction (k_sweepE_y), where r' goes,
   // and the host's status word when this launch is the one of its group that reports
   const double *t;
   double *y0, *y1, *y2, *rout;
   int *host_status;
   int rev;  // k_edge: the tiles in descending order (krylov_edge.h "Direction")
-  int prev; // k_edge: a workgroup walks CONSECUTIVE rounds and takes the z edges of the side two consecutive 16 x 8 patches share
-            // from the exports of its previous round (krylov_edge.h "Previous round")
   // k_edge MERGE 3 (N ranks, deferred scalar update): the records of the previous reduction point gathered from all ranks
   // ([pn][RED_REC]), the stage they belong to (-1: none pending), and where the updated state goes (the kernel's sc is read only)
   const double *pg;
@@ -307,22 +299,14 @@ static __device__ __forceinline__ void fused_reduce_store_max(double v, double *
 // slice with stored rows: the wave forms v and z = P_inv v of its blocks and stores them (v as always, z to zg), the rows
 // themselves are applied by k_hyb_rows from z in memory; a fused tile also stores the z of the blocks zmask names (the
 // ones those rows read).  Ring entries work as ever: the neighbour of a plain block is a block with p, nu, r in memory.
-// EDGES: neighbour ids >= nowned are ghost blocks whose z edges the owner rank computed (k_fused_edges; N ranks,
-// CUP2D_FUSED_GHOST=edges) -- compiled out otherwise: the path costs the one-rank kernel six spilled registers
-// RE (stored-edge ring, DESIGN.md 8a -> 4.5): P_inv is linear, so the z edge of a block outside the tile is a combination
-// of edges its OWNER had on the chip one launch earlier -- z' = beta (z - omega P_inv nu) + P_inv r with
-// P_inv r = z2 - omega_r P_inv t (sweep E's r = s - omega_r t) in AB, z2' = P_inv r - alpha P_inv nu' in CD.  RE >= 1: the
-// owner stores the edges of its tile-boundary sides (z after the tile job; P_inv y after one more 64-MFMA job on the
-// tile's y).  RE == 2: the ring entries are filled from those arrays (4 | 3 64-byte reads per entry) instead of whole
-// neighbour blocks (12 | 8 x 128 bytes) + a staging + MFMA job.  The first iteration of a solve runs RE = 1.
-template <int MODE, int MERGE, bool HYB = false, bool EDGES = false, int RE = 0>
+template <int MODE, int MERGE, bool HYB = false>
 __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__restrict__ Pinv,
                                                   const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                   int first, int count, int poff, int nowned,
                                                   double *__restrict__ zg, double *red, unsigned *ticket,
                                                   int dbg, const int32_t *__restrict__ zmask, const int32_t *__restrict__ tile0) {
-  // blocks [first, first + count) of the nowned owned blocks; neighbour ids >= nowned are ghost blocks whose z
-  // edges were computed by their owner rank (k_fused_edges) and unpacked into zg
+  // blocks [first, first + count); neighbour ids < nowned name blocks whose p, nu, r are in memory (owned blocks, and on N
+  // ranks the ghost blocks: solve_fused_impl passes ntotal)
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   if (sc->status != 0) return;
   constexpr bool DEEP = ((CUP2D_FUSED_DEEP >> MODE) & 1) != 0;
@@ -423,7 +407,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     T.is_ring = si < T.nvalid && nb >= 0 && nb < nowned && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (dbg & 1) ? 0 : __popcll(rmask);  // dbg 1: timing experiment without the ring -- WRONG results
-    T.npass = RE == 2 ? 0 : (T.nring + TB - 1) / TB;  // RE 2: no ring JOBS, the ring list feeds ring_from_edges
+    T.npass = (T.nring + TB - 1) / TB;
     T.gen = HYB && __ballot(si < T.nvalid && nb == FUSED_GENERAL) != 0ull;
     T.zm = HYB ? uniform(zmask[t]) : 0;
     if (T.is_ring) {
@@ -475,42 +459,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
     }
   };
 
-  // RE 2: the ring from stored edges.  State of the tile whose edges are in flight: values, ghost-edge slot, (block, side)
-  double redge[2][4];
-  int rdst[2] = {-1, -1}, rslot[2] = {-1, -1};
-  const double momega_r = RE == 2 ? -sc->omega_r : 0.0;
-  const auto ring_value = [&](const double (&e)[4]) -> double {
-    const double re = e[2] + momega_r * e[3];  // P_inv r on the edge
-    if (MODE == 0) {
-      if (restart) return re;
-      double v = e[0] + c1 * e[1];
-      v = v * beta;
-      return v + re;
-    }
-    return re + c1 * e[1];
-  };
-  // the first 16 entries of tile X's ring list (in LDS now): 8 lanes per entry read its 8 doubles of every edge array
-  const auto fetch_ring = [&](const Tile &X) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int idx = lane + 64 * h, e = idx >> 3, q = idx & 7;
-      const bool on = e < X.nring;
-      const int ee = on ? e : 0;
-      const int dst = L.ring_dst[ee];
-      const size_t at = X.nring > 0 ? ((size_t)L.ring_nb[ee] * 4 + ((dst & 3) ^ 1)) * BS + q : 0;
-      if (MODE == 0) redge[h][0] = A.e0[at];
-      redge[h][1] = A.e1[at];
-      redge[h][2] = A.e2[at];
-      redge[h][3] = A.e3[at];
-      rdst[h] = on ? dst * GS + q : -1;
-      rslot[h] = on ? dst : -1;
-    }
-  };
   Raw Ra, Rb;
   Tile T;
   if (t_begin < t_end) {
     T = classify(t_begin, load_nb(t_begin));
-    if constexpr (RE == 2) fetch_ring(T);
     issue(Ra, T, 0, 0);
     if (DEEP) issue(Rb, T, 0, 1);
   }
@@ -529,47 +481,6 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 #pragma unroll
       for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = 0.0;
     }
-    // RE 2: the stored edges of this tile's first 16 ring entries were requested one tile ago (fetch_ring, issued in
-    // front of the tile's own loads: the memory counter is in order, and a value consumed between the prefetch of the next
-    // tile and its use would make the wave wait for that prefetch); they are combined and written to the ghost-edge
-    // slots here, before the tile job.  Entries beyond 16 (block orders other than the Hilbert one) are fetched and
-    // written at once -- the ring list is still this tile's.
-    int cslot[2] = {-1, -1};
-    if constexpr (RE == 2) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        cslot[h] = rslot[h];
-        if (rdst[h] >= 0) L.GE[rdst[h]] = ring_value(redge[h]);
-      }
-      for (int j = 1; j * TB < T.nring; j++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int idx = lane + 64 * h, e = j * TB + (idx >> 3), q = idx & 7;
-          if (e < T.nring) {
-            const int dst = L.ring_dst[e];
-            const size_t at = ((size_t)L.ring_nb[e] * 4 + ((dst & 3) ^ 1)) * BS + q;
-            const double ev[4] = {MODE == 0 ? A.e0[at] : 0.0, A.e1[at], A.e2[at], A.e3[at]};
-            L.GE[dst * GS + q] = ring_value(ev);
-          }
-        }
-      }
-    }
-    // the edges of the tile-boundary sides of the staging tile -> arr.  With <= 16 such sides (every Hilbert tile) eight
-    // lanes write the eight doubles of one edge: full 64-byte lines; one lane per edge writes eight partial lines
-    const auto store_edges = [&](double *arr) {
-      if (RE == 2 && T.nring <= TB) {
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-          if (cslot[h] >= 0) {
-            const int d = cslot[h], q = lane & 7;
-            arr[((size_t)(b0 + (d >> 2)) * 4 + (d & 3)) * BS + q] = L.S[(d >> 2) * XS + edge_cell(d & 3, q)];
-          }
-      } else if (T.is_ring) {
-        double *dst = arr + ((size_t)(b0 + si) * 4 + ss) * BS;
-#pragma unroll
-        for (int q = 0; q < BS; q++) dst[q] = L.S[si * XS + edge_cell(ss, q)];
-      }
-    };
     // dot-product operand of the tile's cells in pair layout: s itself (CD); rhat (AB; r on a restart)
     double2 W[TB / 2];
     const auto stage = [&](const Raw &R, bool is_tile, int half) {
@@ -614,7 +525,6 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         // behind this tile's MFMA, edge fill and stencil
         N = classify(t + t_stride, nb_next);
         nb_next = load_nb(t + 2 * t_stride);
-        if constexpr (RE == 2) fetch_ring(N);
         issue(Ra, N, 0, 0);
         if (DEEP) issue(Rb, N, 0, 1);
       } else {
@@ -649,7 +559,6 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
         PH(1)
       }
     }
-    if constexpr (RE >= 1) store_edges(A.o0);  // the z edges of the tile-boundary sides, for the neighbour tiles of the next launch
     // ---- edges inside the tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost =
     //      edge cell), from the z tile: this lane's (block, side) slot ----
     if (HYB && T.gen) {  // rows with stored entries in this tile: k_hyb_rows applies them
@@ -658,15 +567,9 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
       continue;
     }
     if (si < nvalid && !T.is_ring) {
-      if (EDGES && T.nb >= nowned) {  // ghost block: the owner rank's z on the touching edge
-        const double *g = zg + (size_t)T.nb * BC;
+      const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
 #pragma unroll
-        for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = g[edge_cell(ss ^ 1, q)];
-      } else {
-        const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
-#pragma unroll
-        for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + edge_cell(sside, q)];
-      }
+      for (int q = 0; q < BS; q++) L.GE[lane * GS + q] = L.S[sblk * XS + edge_cell(sside, q)];
     }
     wave_lds_sync();
     PH(5)
@@ -693,15 +596,7 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
           acc[1] = __builtin_fma(yv.x, yv.x, acc[1]);
           acc[1] = __builtin_fma(yv.y, yv.y, acc[1]);
         }
-        // RE: y takes z's place in the staging tile (every lane has read this block pair's z: one wave, in order; the
-        // blocks still to come read their own z and the ghost edges only)
-        if constexpr (RE >= 1) *reinterpret_cast<double2 *>(L.S + blk * XS + c0) = yv;
       }
-    }
-    if constexpr (RE >= 1) {  // P_inv y on the tile-boundary sides: one more job on the matrix cores
-      wave_lds_sync();
-      tile_precond<PRECOND_DB>(L.S, PL, PR, lane, false);
-      store_edges(A.o1);
     }
     wave_lds_sync();  // the next tile overwrites S and GE
     PH(6)
@@ -709,8 +604,8 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
   }
 #ifdef FUSED_PHASES
   if (sc->iter == 5 && lane == 0 && blockIdx.x < 2 && (wave == 0 || wave == 5) && ntile > 0)
-    printf("PHASES mode %d re %d wg %d wave %d tiles %d cycles/tile: ring stage+wait %lld  ring mfma+edges %lld  tile stage+wait %lld  classify+issue %lld  "
-           "tile mfma %lld  edges %lld  stencil+stores(+2nd job) %lld\n", MODE, RE, (int)blockIdx.x, wave, ntile, ph[0] / ntile, ph[1] / ntile,
+    printf("PHASES mode %d wg %d wave %d tiles %d cycles/tile: ring stage+wait %lld  ring mfma+edges %lld  tile stage+wait %lld  classify+issue %lld  "
+           "tile mfma %lld  edges %lld  stencil+stores(+2nd job) %lld\n", MODE, (int)blockIdx.x, wave, ntile, ph[0] / ntile, ph[1] / ntile,
            ph[2] / ntile, ph[3] / ntile, ph[4] / ntile, ph[5] / ntile, ph[6] / ntile);
 #endif
   // MERGE 1: the last workgroup finishes the reduction and runs the scalar update (one GPU).  MERGE 2: it only sums
@@ -722,65 +617,6 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 }
 
 #include "krylov_edge.h"
-
-// ---- z on the faces other ranks need (multi-GPU) ---------------------------------------------------
-// For every (block, face) strip of the halo plan's send list: v of that block (the sweep's own formula),
-// z = P_inv v on the matrix cores, written to the block's place in zg.  The regular pack / exchange / unpack
-// of a width-1 scalar halo then delivers the face cells into the ghost blocks of the neighbour rank's zg,
-// where its k_fused picks up the edge it needs.  16 list entries per wave.
-template <int MODE>
-__global__ __launch_bounds__(WG, 2) void k_fused_edges(FusedArgs A, const double *__restrict__ Pinv,
-                                                       const int32_t *__restrict__ blocks, int n,
-                                                       double *__restrict__ zg, const KrylovScalars *__restrict__ sc) {
-  __shared__ double Ss[WPG][TB * XS];
-  if (sc->status != 0) return;
-  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  double *S = Ss[wave];
-  PinvFragments P;
-  P.load(Pinv, lane);
-  const double c1 = MODE == 0 ? -sc->omega : -sc->alpha;
-  const double beta = sc->beta;
-  const bool restart = MODE == 0 && sc->restart_flag != 0;
-  const int njobs = (n + TB - 1) / TB;
-  for (int job = blockIdx.x * WPG + wave; job < njobs; job += gridDim.x * WPG) {
-#pragma unroll
-    for (int e = 0; e < TB; e++) {
-      const size_t o = (size_t)uniform(blocks[min(job * TB + e, n - 1)]) * BC + lane;
-      const double a = A.in0[o], b = A.in1[o];
-      double v;
-      if (MODE == 0) {
-        const double c = A.in2[o];
-        if (restart) {
-          v = c;
-        } else {
-          v = a + c1 * b;
-          v = v * beta;
-          v = v + c;
-        }
-      } else {
-        v = a + c1 * b;
-      }
-      S[e * XS + lane] = v;
-    }
-    wave_lds_sync();
-    double xa[16];
-    const int ablk = lane & 15, akk = lane >> 4;
-#pragma unroll
-    for (int ks = 0; ks < 16; ks++) xa[ks] = S[ablk * XS + 4 * ks + akk];
-    v4f64 acc[4];
-    precond_tile(xa, P, acc);
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int e = job * TB + akk + 4 * v;
-      if (e < n) {
-        double *dst = zg + (size_t)blocks[e] * BC;
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) dst[16 * nt + ablk] = acc[nt][v];
-      }
-    }
-    wave_lds_sync();
-  }
-}
 
 // ---- the rows of the general tiles of the hybrid operator (k_fused HYB) -----------------------------
 // y = A z for the listed blocks, z from memory (k_fused stored it for exactly the blocks these rows read; the halo entries
@@ -907,11 +743,9 @@ static int fused_grid(const cup2d_ctx *c, int count) {
   return g < 1 ? 1 : g;
 }
 
-// One fused sweep (MODE 0: A+B, MODE 1: C+D) over all owned blocks.  With ghost blocks, edge form (CUP2D_FUSED_GHOST=edges;
-// the default is the ghost-block form below): z on the faces the
-// other ranks need first (k_fused_edges -> zg = the otherwise unused z vector), its width-1 halo exchange
-// overlapped with the tiles of the inner blocks, then the tiles of the halo blocks (computeA's split,
-// main.cpp:3035-3057).  *GP = number of per-workgroup partials written.
+// One fused sweep (MODE 0: A+B, MODE 1: C+D) over all owned blocks; *GP = number of per-workgroup partials written.  (N ranks:
+// whole ghost blocks of the sweep's input vectors are in place, solve_fused_impl -- the ghost-EDGE form of round 2, a pre-pass
+// for z on the send-list faces + a width-1 exchange + a second launch per sweep, is gone: DESIGN.md 7.)
 // The edge form of these two sweeps (krylov_edge.h MODE 0 / 1; CUP2D_FORM_EDGE) applies with the built-in preconditioner on
 // the same-level stencil: one rank, or N ranks in the ghost-block form.  Measured at 4096^2 in the first half of round 3
 // (tools/gpu_edge_check.py, tools/gpu_calls/gpu_r03_call3.sh; AB / CD in us, L2-miss traffic per launch from FETCH_SIZE /
@@ -930,10 +764,10 @@ static int form_of(const cup2d_ctx *c) {  // cup2d_set_solver_form, else the pro
   }();
   return c->solver_form != CUP2D_FORM_AUTO ? c->solver_form : env;
 }
-static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int re, int dbg) {
+static bool edge_form(const cup2d_ctx *c, bool ghost_blocks, int dbg) {
   const bool on = form_of(c) == CUP2D_FORM_EDGE;
   const bool ghosts = c->nghost > 0 && c->exchange;
-  return on && !c->custom_Pinv && !c->mat.active && re == 0 && dbg == 0 && (!ghosts || ghost_blocks);
+  return on && !c->custom_Pinv && !c->mat.active && dbg == 0 && (!ghosts || ghost_blocks);
 }
 // the organisation with sweep E and the next A+B in one launch (k_edge MODE 2 / 3): the default wherever the edge form
 // applies -- built-in preconditioner, same-level stencil -- on one GPU with the finish in the kernel.  CUP2D_FUSED_FORM =
@@ -944,15 +778,14 @@ static bool ghost_local_enabled() {
   static const bool on = [] { const char *e = getenv("CUP2D_GHOST_LOCAL"); return !e || atoi(e) != 0; }();
   return on;
 }
-static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool stored_ring, bool ghost_blocks) {
+static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool ghost_blocks) {
   const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
   const bool ghosts = c->nghost > 0 && c->exchange;
   // (N ranks: the widest message is two whole blocks per strip -- nu' and p' behind the A+B of iteration 0 -- when r' and p'' of
   // the ghost blocks are formed locally (k_ghost_rp, the default), three with CUP2D_GHOST_LOCAL=0: the caller's buffers must
   // be that wide, cup2d_set_comm_strip_capacity)
   const bool wide = !ghosts || c->strip_cap >= (ghost_local_enabled() ? 2 : 3) * BC;
-  return on && (merge == 1 || merge == 2) && !c->custom_Pinv && !c->mat.active && (!ghosts || (merge == 2 && ghost_blocks)) && dbg == 0 &&
-         !stored_ring && wide;
+  return on && (merge == 1 || merge == 2) && !c->custom_Pinv && !c->mat.active && (!ghosts || (merge == 2 && ghost_blocks)) && dbg == 0 && wide;
 }
 static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has <= 16 perimeter sides
   if (c->edge_share < 0) c->edge_share = edge_share_ok(c->h_nbr.data(), 0, c->nblocks) ? 1 : 0;
@@ -960,14 +793,10 @@ static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has 
 }
 // sharing between sibling waves per kind of sweep (it pays where the ring is four vectors wide, MODE 2; it costs the short
 // C+D sweep more in waiting than it saves): CUP2D_EDGE_SHARE = bit mask, bit MODE; default 0b0101 (A+B and MODE 2)
-// ... and the edges of the side two CONSECUTIVE rounds of a workgroup share taken from the previous round's exports (no wait;
-// the workgroup then walks a contiguous piece of the tiles): CUP2D_EDGE_PREV = bit mask by MODE, default 0 (experiment)
-// returns bit 0: same round, bit 1: previous round
 static int edge_share_mode(cup2d_ctx *c, int mode) {
   static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
-  static const int pmask = [] { const char *e = getenv("CUP2D_EDGE_PREV"); return e ? atoi(e) : 0; }();
   if (!edge_share_of(c)) return 0;
-  return ((mask >> mode) & 1) | (((pmask >> mode) & 1) << 1);
+  return (mask >> mode) & 1;
 }
 // N ranks, two-launch organisation: of the three vectors the launch that holds sweep E and the next A+B leaves behind -- r', p'',
 // nu'' -- only nu'' = A P_inv p'' is not a function of the same cells.  A rank holds p', nu', r and t of its ghost blocks (the
@@ -1012,9 +841,7 @@ template <int MODE>
 static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int count, int poff, int *G, KrylovScalars *sc_in = nullptr) {
   const int g = fused_grid(c, count);
   const int share = edge_share_mode(c, MODE);
-  FusedArgs a2 = a;
-  static const int wmask = [] { const char *e = getenv("CUP2D_EDGE_WALK"); return e ? atoi(e) : 0; }();  // experiment: the contiguous walk alone
-  a2.prev = ((share >> 1) & 1) ? 1 : (((wmask >> MODE) & 1) ? 2 : 0);
+  const FusedArgs &a2 = a;
   const auto go = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, sc_in ? sc_in : c->d_sc, c->d_partials, first, count,
                        poff, share, c->d_red, c->d_ticket, c->d_fault);
@@ -1033,9 +860,9 @@ template <int MODE>
 static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge) { return eab_sweep<MODE>(c, a, merge, 0, c->nblocks, 0, nullptr); }
 
 template <int MODE>
-static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks, int re = 0) {
+static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks) {
   const int nb = c->nblocks;
-  if (edge_form(c, ghost_blocks, re, dbg)) {
+  if (edge_form(c, ghost_blocks, dbg)) {
     const int share = edge_share_mode(c, MODE);
     const int g = fused_grid(c, nb);
     const auto go = [&](auto kernel) {
@@ -1071,8 +898,7 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
     if (M.ngen == 0) return CUP2D_OK;
     CUP2D_TRY(matrix_exchange(c, c->d_z));
     int g2 = (M.ngen + RWAVES - 1) / RWAVES;
-    static const int rows_per_cu = [] { const char *e = getenv("CUP2D_ROWS_WG_PER_CU"); return e ? atoi(e) : 1; }();
-    if (g2 > rows_per_cu * cus) g2 = rows_per_cu * cus;
+    if (g2 > cus) g2 = cus;  // (2 or 4 workgroups per CU change nothing: 7.89 / 8.03 / 8.06 ms per adapted-grid step, round 4)
     const double *w0 = MODE == 0 ? a.w : a.in0, *w1 = MODE == 0 ? nullptr : a.in1;
     const auto rows = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col,
@@ -1101,49 +927,17 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
     *GP = g;
     return CUP2D_OK;
   }
-  const bool ghosts = c->nghost > 0 && c->exchange;
-  const int n_in = ghosts ? c->n_inner : nb, n_ha = nb - n_in;
-  const int G_in = n_in > 0 ? fused_grid(c, n_in) : 0, G_ha = n_ha > 0 ? fused_grid(c, n_ha) : 0;
-  double *zg = c->d_z;
-  if (ghosts && c->plan.nsend > 0) {
-    const int njobs = (c->plan.nsend + TB - 1) / TB;
-    int g = (njobs + WPG - 1) / WPG;
-    if (g > 512) g = 512;
-    hipLaunchKernelGGL(k_fused_edges<MODE>, dim3(g), dim3(WG), 0, c->stream, a, c->d_Pinv, c->plan.d_send_block,
-                       c->plan.nsend, zg, c->d_sc);
-    CUP2D_HIP_CHECK(hipGetLastError());
-  }
-  if (ghosts) CUP2D_TRY(exchange_begin(c, zg, 1, 1));
-  // merge 1 (one GPU, one launch): the launch finishes the reduction and updates the scalars; merge 2: the LAST
-  // launch of the sweep sums this rank's partials, finish_local() does the rest
-  const auto launch = [&](int first, int count, int poff, int g, int mg) {
-    const auto go = [&](auto kernel) {
-      hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials,
-                         first, count, poff, nb, zg, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
-    };
-    if (ghosts) {
-      if (mg == 1) go(k_fused<MODE, 1, false, true>);
-      else if (mg == 2) go(k_fused<MODE, 2, false, true>);
-      else go(k_fused<MODE, 0, false, true>);
-    } else if (re == 1) {  // stored-edge ring, first iteration of a solve: ring recomputed, edges stored
-      if (mg == 1) go(k_fused<MODE, 1, false, false, 1>);
-      else if (mg == 2) go(k_fused<MODE, 2, false, false, 1>);
-      else go(k_fused<MODE, 0, false, false, 1>);
-    } else if (re == 2) {
-      if (mg == 1) go(k_fused<MODE, 1, false, false, 2>);
-      else if (mg == 2) go(k_fused<MODE, 2, false, false, 2>);
-      else go(k_fused<MODE, 0, false, false, 2>);
-    } else {
-      if (mg == 1) go(k_fused<MODE, 1>);
-      else if (mg == 2) go(k_fused<MODE, 2>);
-      else go(k_fused<MODE, 0>);
-    }
+  // one rank, same-level stencil: one launch over all blocks
+  const int g = fused_grid(c, nb);
+  const auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), FUSED_LDS_BYTES, c->stream, a, c->d_Pinv, c->d_nbr, c->d_sc, c->d_partials,
+                       0, nb, 0, nb, c->d_z, c->d_red, c->d_ticket, dbg, nullptr, nullptr);
   };
-  if (n_in > 0) launch(0, n_in, 0, G_in, n_ha > 0 && merge == 2 ? 0 : merge);
-  if (ghosts) CUP2D_TRY(exchange_end(c, zg, 1, 1));
-  if (n_ha > 0) launch(n_in, n_ha, G_in, G_ha, merge);
+  if (merge == 1) go(k_fused<MODE, 1>);
+  else if (merge == 2) go(k_fused<MODE, 2>);
+  else go(k_fused<MODE, 0>);
   CUP2D_HIP_CHECK(hipGetLastError());
-  *GP = G_in + G_ha;
+  *GP = g;
   return CUP2D_OK;
 }
 
@@ -1287,8 +1081,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // agent-scope ticket for that: 2048 workgroups cost the sweep 8 us more than 512 (measured 161.5 / 161.7 / 152.9 / 152.9 us
   // at 2048 / 1024 / 512 / 256 workgroups, 4096^2)
   int gridE = (int)((n / 2 + WG - 1) / WG);
-  static const int capE = [] { const char *e = getenv("CUP2D_GRID_E"); return e ? atoi(e) : 0; }();
-  const int cap = capE > 0 ? capE : 2 * (c->num_cus > 0 ? c->num_cus : 256);
+  const int cap = 2 * (c->num_cus > 0 ? c->num_cus : 256);
   if (gridE > cap) gridE = cap;
   if (gridE > c->grid) gridE = c->grid;
   if (!c->fused_lds_opt_in) {  // > 64 KiB of LDS is an opt-in per kernel AND device: remembered per context
@@ -1297,16 +1090,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_fused<1, 1>), reinterpret_cast<const void *>(&k_fused<1, 2>),
                         reinterpret_cast<const void *>(&k_fused<0, 0, true>), reinterpret_cast<const void *>(&k_fused<0, 1, true>),
                         reinterpret_cast<const void *>(&k_fused<0, 2, true>), reinterpret_cast<const void *>(&k_fused<1, 0, true>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>),
-                        reinterpret_cast<const void *>(&k_fused<0, 0, false, true>), reinterpret_cast<const void *>(&k_fused<0, 1, false, true>),
-                        reinterpret_cast<const void *>(&k_fused<0, 2, false, true>), reinterpret_cast<const void *>(&k_fused<1, 0, false, true>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, false, true>), reinterpret_cast<const void *>(&k_fused<1, 2, false, true>),
-                        reinterpret_cast<const void *>(&k_fused<0, 0, false, false, 1>), reinterpret_cast<const void *>(&k_fused<0, 1, false, false, 1>),
-                        reinterpret_cast<const void *>(&k_fused<0, 2, false, false, 1>), reinterpret_cast<const void *>(&k_fused<1, 0, false, false, 1>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, false, false, 1>), reinterpret_cast<const void *>(&k_fused<1, 2, false, false, 1>),
-                        reinterpret_cast<const void *>(&k_fused<0, 0, false, false, 2>), reinterpret_cast<const void *>(&k_fused<0, 1, false, false, 2>),
-                        reinterpret_cast<const void *>(&k_fused<0, 2, false, false, 2>), reinterpret_cast<const void *>(&k_fused<1, 0, false, false, 2>),
-                        reinterpret_cast<const void *>(&k_fused<1, 1, false, false, 2>), reinterpret_cast<const void *>(&k_fused<1, 2, false, false, 2>)};
+                        reinterpret_cast<const void *>(&k_fused<1, 1, true>), reinterpret_cast<const void *>(&k_fused<1, 2, true>)};
     for (const void *k : ks)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS_BYTES));
     const void *ke[] = {reinterpret_cast<const void *>(&k_edge<0, 0>), reinterpret_cast<const void *>(&k_edge<0, 1>),
@@ -1324,28 +1108,16 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // 2: N GPUs -- the last workgroup of the sweep's last launch sums this rank's partials, then all-reduce + k_scalars
   const int merge = !c->finish_in_kernel ? 0 : (c->allreduce || (c->nghost > 0 && c->exchange)) ? 2 : 1;
   // (restart in the hybrid form: rhat = r is written by k_fused for every block before k_hyb_rows reads it)
-  // N ranks: how a sweep learns z on the other side of a rank boundary.
-  //   blocks (default)  whole boundary blocks of nu', p', r are exchanged as they are produced -- nu' and p' in one
-  //                     message behind the reduction of AB, r behind the reduction of E -- and the sweeps recompute the
-  //                     z edge of a ghost block like that of any other block outside the tile: one launch per sweep,
-  //                     no exchange on its critical path
-  //   edges             per sweep: z of the send-list blocks (k_fused_edges), a width-1 exchange overlapped with the
-  //                     inner tiles, then a second launch for the tiles that touch ghost blocks
-  static const bool ghost_edges = [] { const char *e = getenv("CUP2D_FUSED_GHOST"); return e && !strcmp(e, "edges"); }();
-  const bool gb = c->nghost > 0 && c->exchange && !ghost_edges && !c->mat.active;
-  static const int dbg = [] { const char *e = getenv("CUP2D_FUSED_DBG"); return e ? atoi(e) : 0; }();
-  // the ring of the sweeps from stored edges (k_fused RE): one rank, same-level stencil.  CUP2D_FUSED_RING=stored|blocks
-  static const bool ring_stored = [] { const char *e = getenv("CUP2D_FUSED_RING"); return e && !strcmp(e, "stored"); }();
-  const bool stored = ring_stored && !c->mat.active && !(c->nghost > 0 && c->exchange);
-  if (stored) {
-    const size_t ebytes = (size_t)c->ntotal * 4 * BS * sizeof(double);
-    for (double *&p : c->d_edge)
-      if (!p) CUP2D_HIP_CHECK(dev_malloc(&p, ebytes));
-  }
+  // N ranks: how a sweep learns z on the other side of a rank boundary -- whole boundary blocks of nu', p', r are exchanged as
+  // they are produced (nu' and p' in one message behind the reduction of AB, r behind the reduction of E) and the sweeps
+  // recompute the z edge of a ghost block like that of any other block outside the tile: one launch per sweep, no exchange on
+  // its critical path
+  const bool gb = c->nghost > 0 && c->exchange && !c->mat.active;
+  const int dbg = 0;  // (k_fused's timing-only knock-outs: development builds pass a mask here)
 
   // the first solve of a context in the two-launch organisation chooses where its vectors lie (tune_placement) -- before
   // anything of this solve is in them; the sc record of this solve was uploaded above and the probe uses its own
-  if (eab_form(c, merge, dbg, stored, gb)) CUP2D_TRY(tune_placement(c));
+  if (eab_form(c, merge, dbg, gb)) CUP2D_TRY(tune_placement(c));
   int GP = 0;
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
@@ -1362,17 +1134,14 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     else CUP2D_TRY(exchange_halo(c, c->d_r, 1, BS));  // width 8 = the whole block
   }
 
-  static const int AHEAD = [] {
-    const char *e = getenv("CUP2D_SOLVE_AHEAD");
-    const int v = e ? atoi(e) : 4;
-    return v < 1 ? 1 : (v > cup2d_ctx::SOLVE_AHEAD ? cup2d_ctx::SOLVE_AHEAD : v);
-  }();
+  constexpr int AHEAD = 4;
+  static_assert(AHEAD <= cup2d_ctx::SOLVE_AHEAD, "event ring of the context");
   // Finish in the kernel (merge 1 | 2): the host looks at the solve once per GROUP of iterations -- the event record and
   // the system-scope store of the status word cost the stream 6 us of idle time between sweep E and the next AB
   // (tools/kernel_gaps.py), per iteration in round 2.  The last sweep E of a group reports (also when the
   // solve ended earlier in the group and its kernels returned at once); the host stays at most AHEAD groups in front, so at
   // most AHEAD * GROUP iterations of early-returning kernels are wasted behind a solve that has ended.  CUP2D_SOLVE_GROUP.
-  static const int GROUP_ENV = [] { const char *e = getenv("CUP2D_SOLVE_GROUP"); return e ? atoi(e) : 4; }();
+  constexpr int GROUP_ENV = 4;
   // merge 2 (N ranks): the status word is written by the one-wave kernel behind the last all-gather of an iteration
   // (comm.hip k_gather_scalars; callbacks: k_scalars), which reports for a finished solve as well -- same grouping.  Every
   // rank sees the same scalars and looks at the same group boundaries, so all ranks enqueue the same collectives.
@@ -1384,9 +1153,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   const int GROUP = merge == 1 ? (GROUP_ENV < 1 ? 1 : GROUP_ENV) : merge == 2 ? (GROUP_N_ENV < 1 ? 1 : GROUP_N_ENV) : 1;
   const int AHEAD_G = GROUP > 1 ? (AHEAD + 1) / 2 : AHEAD;  // groups the host may run ahead
   for (int i = 0; i < AHEAD; i++) c->h_status[i] = 0;
-  const bool eab = eab_form(c, merge, dbg, stored, gb);
+  const bool eab = eab_form(c, merge, dbg, gb);
   {  // cup2d_get_last_solver_form
-    const bool edge = !eab && edge_form(c, gb, stored ? 1 : 0, dbg);
+    const bool edge = !eab && edge_form(c, gb, dbg);
     c->last_form = eab ? CUP2D_FORM_EAB : edge ? CUP2D_FORM_EDGE : CUP2D_FORM_FULL;
     c->last_merge = merge;
     c->last_handover = 0;
@@ -1398,7 +1167,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // with the next A+B (MODE 2).  p, nu and r alternate between two buffers (r': ring entries re-read r of other tiles; the
     // second one is the s vector this organisation never stores)
     double *P[2] = {c->d_p2, c->d_p}, *N[2] = {c->d_nu2, c->d_nu}, *R[2] = {c->d_r, c->d_s};
-    static const int zigzag = [] { const char *e = getenv("CUP2D_EAB_ZIGZAG"); return e ? atoi(e) : 1; }();
+    constexpr int zigzag = 1;  // C+D' walks the tiles in descending order (krylov_edge.h "Direction": -1.5 % of a step, round 3)
     // N ranks, opt-in (CUP2D_SWEEP_SPLIT=1): sweep the halo set first and the inner blocks while its ghost blocks travel on
     // the communication stream -- computeA's split (main.cpp:3035-3057) for the Krylov sweeps.  The halo set is a whole number
     // of tiles when the host orders it in patches (grid.py); the inner blocks never read a ghost block, so the blocks arriving
@@ -1568,10 +1337,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     double *nu_in = (k & 1) ? c->d_nu2 : c->d_nu, *nu_out = (k & 1) ? c->d_nu : c->d_nu2;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      const int o = k & 1, n = o ^ 1;  // edge buffers: z 0-1, P_inv nu 2-3, z2 4-5, P_inv t 6-7
-      const FusedArgs a = {p_in, nu_in, c->d_r, c->d_rhat, p_out, nu_out,
-                           c->d_edge[o], c->d_edge[2 + o], c->d_edge[4 + o], c->d_edge[6 + o], c->d_edge[n], c->d_edge[2 + n]};
-      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb, stored ? (k == 0 ? 1 : 2) : 0));
+      FusedArgs a = {};
+      a.in0 = p_in; a.in1 = nu_in; a.in2 = c->d_r; a.w = c->d_rhat; a.vout = p_out; a.yout = nu_out;
+      CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb));
     }
     // CD needs the ghost nu', the next AB the ghost p': one message, in flight behind the reduction
     if (direct) CUP2D_TRY(comm_exchange_blocks(c, 2, nu_out, p_out, nullptr));
@@ -1581,10 +1349,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (gb && !direct) CUP2D_TRY(exchange_end_blocks2(c, nu_out, p_out));
     {
       ProfScope prof(c, CUP2D_T_SWEEP_C);
-      const int o = k & 1, n = o ^ 1;
-      const FusedArgs a = {c->d_r, nu_out, nullptr, nullptr, c->d_s, c->d_t,
-                           nullptr, c->d_edge[2 + n], c->d_edge[4 + o], c->d_edge[6 + o], c->d_edge[4 + n], c->d_edge[6 + n]};
-      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb, stored ? (k == 0 ? 1 : 2) : 0));
+      FusedArgs a = {};
+      a.in0 = c->d_r; a.in1 = nu_out; a.vout = c->d_s; a.yout = c->d_t;
+      CUP2D_TRY(fused_sweep<1>(c, a, merge, dbg, &GP, gb));
     }
     if (merge == 0) CUP2D_TRY(finish(c, GP, 2, 0, 2, true));
     if (merge == 2) CUP2D_TRY(finish_local(c, 2, 0, 2));

@@ -33,7 +33,6 @@ struct Body {
   double *d_udef = nullptr;     // [nblk][64][2]
   double *d_terms = nullptr;    // [nblk][64][7] integrands of (1)
   double cx = 0, cy = 0;
-  std::vector<double> h_terms;
   void release() {
     (void)hipFree(d_blocks); (void)hipFree(d_origin); (void)hipFree(d_chi); (void)hipFree(d_udef); (void)hipFree(d_terms);
     *this = Body();
@@ -230,7 +229,6 @@ int cup2d_body_set(cup2d_ctx *c, int body, int nblk, const int32_t *blocks, cons
   CUP2D_HIP_CHECK(hipMemcpy(B.d_origin, origin, n * 2 * sizeof(double), hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(B.d_chi, chi, n * BC * sizeof(double), hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(hipMemcpy(B.d_udef, udef, n * BC * 2 * sizeof(double), hipMemcpyHostToDevice));
-  B.h_terms.resize(n * BC * 7);
   return CUP2D_OK;
 }
 
@@ -244,18 +242,9 @@ int cup2d_body_momentum(cup2d_ctx *c, int body, double lambda, double dt, double
                        B.d_origin, B.d_chi, (const double2 *)B.d_udef, B.d_terms, B.nblk, B.cx, B.cy, lambda * dt, c->h, c->amr.h0,
                        c->amr.active ? c->amr.d_level : nullptr);
     CUP2D_HIP_CHECK(hipGetLastError());
-    static const bool host_sum = [] { const char *e = getenv("CUP2D_BODY_SUM"); return e && !strcmp(e, "host"); }();
-    if (host_sum) {  // the round-2 form (cross-check): every integrand to the host, added up there in the same order
-      CUP2D_HIP_CHECK(hipMemcpyAsync(B.h_terms.data(), B.d_terms, B.h_terms.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-      const double *t = B.h_terms.data();
-      for (size_t i = 0; i < (size_t)B.nblk * BC; i++)  // the reference's order: block by block, iy, ix (main.cpp:6649-6680)
-        for (int k = 0; k < 7; k++) q[k] += t[7 * i + k];
-      CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_red, q, 7 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    } else {
-      hipLaunchKernelGGL(k_body_sums, dim3(1), dim3(64), 0, c->stream, (const double *)B.d_terms, B.nblk, c->d_red);
-      CUP2D_HIP_CHECK(hipGetLastError());
-    }
+    // (the seven sums in the reference's order -- block by block, iy, ix, main.cpp:6649-6680 -- by one wave on the device)
+    hipLaunchKernelGGL(k_body_sums, dim3(1), dim3(64), 0, c->stream, (const double *)B.d_terms, B.nblk, c->d_red);
+    CUP2D_HIP_CHECK(hipGetLastError());
   } else {
     CUP2D_HIP_CHECK(hipMemsetAsync(c->d_red, 0, 7 * sizeof(double), c->stream));
   }

@@ -212,7 +212,7 @@ static int launch_smoother(cup2d_ctx *c, const double *x, const double *b, doubl
   // cache policy (bit 0: b loads, bit 1: out stores, bit 2: x loads non-temporal).  x' of one sweep is x of the next
   // and 134 MB at 4096^2: it survives in the 256 MB memory-side cache only if b, read once per sweep, does not
   // allocate.  Measured at 4096^2, us per sweep: 0: 92   1: 73.5   2: 76.5   4: 84   5: 80   6: 79   3, 7: 90-99.
-  static const int nt = [] { const char *e = getenv("CUP2D_SMOOTHER_NT"); return e ? atoi(e) : 1; }();
+  constexpr int nt = 1;
   const bool small = c->nblocks < JT;
   using K = void (*)(const double *, const double *, double *, const int *, int, int, double, double, double, double *,
                      unsigned *, double *);

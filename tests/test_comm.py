@@ -361,5 +361,7 @@ def test_ghost_blocks_received_in_place_equal_the_generic_exchange(gpu_lib):
             assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (key, k, a, b)
             assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"], (key, a, b)
             assert a["conv_err"] <= 1e-8 or a["conv_iters"] >= a["cap"], (key, a)
-            assert a["exchanges"] == b["exchanges"] > 12
+            # (the deferred organisation learns of the end of the converged solve one launch later: up to one dead iteration = two
+            # exchanges more than the others)
+            assert b["exchanges"] > 12 and 0 <= a["exchanges"] - b["exchanges"] <= 2, (key, k, a["exchanges"], b["exchanges"])
             assert b["vs_five_sweeps"] <= 1e-10, (key, k, b)  # (-1: not run on the x-periodic patches)

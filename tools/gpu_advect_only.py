@@ -28,7 +28,7 @@ with cup2d_amd.Simulation(n // 8) as s:
         s.advect_diffuse_rk2(dt)
     s.synchronize()
     ms, calls = s.get_timing(L.T_ADVECT_STAGE)
-    tag = "walk=%s chunk=%s" % (os.environ.get("CUP2D_ADVECT_WALK", "1"), os.environ.get("CUP2D_WALK_CHUNK", "default"))
+    tag = "walk=%s chunk=%s" % (os.environ.get("CUP2D_ADVECT_WALK", "1"), "persistent")
     print("advect_stage n=%d math=%s %s: %.1f us per launch over %d launches" % (n, "strict" if strict else "fast", tag, 1e3 * ms / calls, calls))
     if check:
         s.set_timing(False)

@@ -83,7 +83,6 @@ def run(what, env):
 
 variants = {"eab": {"CUP2D_FUSED_FORM": "eab"}, "eab-allshare": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EDGE_SHARE": "15"},
             "eab-noshare": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EDGE_SHARE": "0"},
-            "eab-nozigzag": {"CUP2D_FUSED_FORM": "eab", "CUP2D_EAB_ZIGZAG": "0"},
             "edge+share": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "15"}, "edge": {"CUP2D_FUSED_FORM": "edge", "CUP2D_EDGE_SHARE": "0"}, "full": {"CUP2D_FUSED_FORM": "full"}}
 only = os.environ.get("VARIANTS")
 if only:

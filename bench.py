@@ -95,6 +95,7 @@ def parse_args():
                                                       "rNN tag without a suffix)")
     ap.add_argument("--cpu-functor-n", type=int, default=4096, help="grid of the reference-functor CPU baseline (the headline size)")
     ap.add_argument("--no-nrank-proxy", action="store_true", help="skip the N-rank-path leg (a self-periodic patch through RCCL on this GPU)")
+    ap.add_argument("--no-north-star-floors", action="store_true", help="skip the timing-only builds of the north-star kernel")
     ap.add_argument("--no-second-size", action="store_true", help="skip the 2048^2 leg (BASELINE.json configs[1])")
     ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
     ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
@@ -758,6 +759,32 @@ def main():
                              "hbm_frac_of_copy_ceiling": round(gb / HBM_COPY_CEILING_GBS, 4),
                              "fp64_frac_of_measured_ceiling_32T": round(fr / 32.0, 4),
                              "measured_floor_us": floor_us, "floor": floor_what, "frac_of_floor": round(floor_us / (ssec * 1e6), 4)}
+        # the two floors of the quad form measured ON THIS BOX (timing-only builds of advect.hip, csrc/Makefile `variants`:
+        # -DWALK_KNOCKOUT=1 = no arithmetic, the memory skeleton; =2 = no loads / stores in the loop, the arithmetic alone), each
+        # in a child process through CUP2D_LIB, next to the product library timed the same way
+        if not args.no_north_star_floors and world == 1:
+            floors = {}
+            for tag, lib in (("product", None), ("memory_skeleton_no_arithmetic", "libcup2d_hip_walk_nomath.so"),
+                             ("arithmetic_no_loads_or_stores", "libcup2d_hip_walk_nomem.so")):
+                path = os.path.join(ROOT, "cup2d_amd", "variants", lib) if lib else None
+                if path and not os.path.exists(path):
+                    floors[tag] = {"error": "not built (make -C cup2d_amd/csrc variants)"}
+                    continue
+                try:
+                    env = dict(os.environ)
+                    if path:
+                        env["CUP2D_LIB"] = path
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_advect_stages.py"), str(nx), "10"], env=env,
+                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+                    line = [l for l in r.stdout.decode().splitlines() if "us per launch" in l][-1]
+                    tok = line.split(":")[-1].split()
+                    floors[tag] = {tok[k]: float(tok[k + 1]) for k in range(0, len(tok) - 1, 2)}
+                except Exception as e:  # informative
+                    floors[tag] = {"error": str(e)[:160]}
+                beat("north-star floors")
+            north["floors_on_this_box_us"] = dict(floors, what="host clock over 10 back-to-back launches at %d^2 (tools/gpu_advect_stages.py): rhs = the "
+                                                              "functor alone, stage1 / stage2 = the fused RK stages; a launch can be no shorter than "
+                                                              "the larger of its two floors" % nx)
         north["target_note"] = ("0.70 of HBM peak at 40 B/cell = 120 us per launch: below stage 2's measured memory floor (142 us) and "
                                 "6 % above stage 1's arithmetic floor (113 us); the ceiling of this design is 0.66 (DESIGN.md 4.1)")
     # one BiCGSTAB iteration = sweeps A..E + 3 scalar kernels (sum of the sampled average durations)

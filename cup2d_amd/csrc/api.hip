@@ -425,6 +425,12 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) dev_free(c->d_field[f]);
   dev_free(c->d_vscratch);
+  if (c->vec_arena) {  // the solver's eleven vectors are pieces of one allocation (krylov_fused.hip tune_placement)
+    double **piece[] = {&c->d_r, &c->d_s, &c->d_p, &c->d_p2, &c->d_nu, &c->d_nu2, &c->d_t, &c->d_y, &c->d_yopt, &c->d_xopt, &c->d_rhat};
+    for (double **q : piece) *q = nullptr;
+    (void)hipFree(c->vec_arena);
+    c->vec_arena = nullptr;
+  }
   double *kv[] = {c->d_r, c->d_rhat, c->d_p, c->d_nu, c->d_t, c->d_z, c->d_z2, c->d_xopt, c->d_Pinv, c->d_fd, c->d_partials, c->d_red_own};
   for (double *p : kv) dev_free(p);
   double *fv[] = {c->d_p2, c->d_nu2, c->d_s, c->d_y, c->d_yopt};

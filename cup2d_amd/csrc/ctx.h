@@ -171,6 +171,7 @@ struct cup2d_ctx {
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
   cup2d::KrylovScalars *d_sc = nullptr;
+  void *vec_arena = nullptr;  // the eleven vectors of the two-launch solver are pieces of this one allocation (tune_placement), or null
   cup2d::KrylovScalars *d_sc2 = nullptr;  // N ranks, deferred scalar updates (krylov_fused.hip): the state alternates between d_sc and this
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned
   static constexpr int SOLVE_AHEAD = 16;  // upper bound of the iterations the host may run ahead of the GPU (default 4)

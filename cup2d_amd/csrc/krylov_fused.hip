@@ -973,9 +973,27 @@ static int tune_placement(cup2d_ctx *c) {
   while (tries > 1 && (size_t)(tries - 1) * NV * bytes > budget) tries--;
   if (tries <= 1) return CUP2D_OK;
   StageClock clk("tune_placement");
-  struct Cand { double *v[NV]; float ms; };
+  // Candidate kinds: the context's own vectors (set 0); ARENAS -- one allocation carved into the eleven vectors at a stride of
+  // bytes + pad, for every pad of CUP2D_PLACEMENT_ARENA="pad,pad,..." (bytes; experiment: a vector is 2^27 bytes at 4096^2, and
+  // eleven streams an exact power of two apart is the one arrangement known to be slow) --; then separate
+  // allocations, each its own hipMalloc
+  static const std::vector<size_t> arena_pads = [] {
+    std::vector<size_t> v;
+    if (const char *e = getenv("CUP2D_PLACEMENT_ARENA"))
+      for (const char *q = e; *q;) {
+        char *end = nullptr;
+        const long long x = strtoll(q, &end, 10);
+        if (end == q) break;
+        if (x >= 0) v.push_back((size_t)x & ~(size_t)255);
+        q = *end == ',' ? end + 1 : end;
+      }
+    return v;
+  }();
+  struct Cand { double *v[NV]; float ms; void *arena; long long pad; };
   std::vector<Cand> cand((size_t)tries);
+  for (auto &C : cand) { C.arena = nullptr; C.pad = -1; C.ms = 0.f; }
   for (int k = 0; k < NV; k++) cand[0].v[k] = *slot[k];
+  cand[0].arena = c->vec_arena;
   KrylovScalars hs;
   ::memset(&hs, 0, sizeof hs);
   hs.alpha = hs.beta = hs.omega = hs.omega_r = hs.rho_prev = hs.rho_curr = 1.0;
@@ -1016,11 +1034,23 @@ static int tune_placement(cup2d_ctx *c) {
   for (int q = 1; q < tries && rc == CUP2D_OK; q++) {
     bool ok = true;
     for (int k = 0; k < NV; k++) cand[q].v[k] = nullptr;
-    for (int k = 0; k < NV && ok; k++) ok = dev_malloc(&cand[q].v[k], bytes) == hipSuccess;  // (zero-filled)
+    if ((size_t)(q - 1) < arena_pads.size()) {
+      const size_t stride = bytes + arena_pads[(size_t)(q - 1)];
+      void *A = nullptr;
+      ok = hipMalloc(&A, stride * NV) == hipSuccess && hipMemsetAsync(A, 0, stride * NV, c->stream) == hipSuccess;
+      if (ok) {
+        cand[q].arena = A;
+        cand[q].pad = (long long)arena_pads[(size_t)(q - 1)];
+        for (int k = 0; k < NV; k++) cand[q].v[k] = reinterpret_cast<double *>(static_cast<char *>(A) + (size_t)k * stride);
+      } else if (A) (void)hipFree(A);
+    } else {
+      for (int k = 0; k < NV && ok; k++) ok = dev_malloc(&cand[q].v[k], bytes) == hipSuccess;  // (zero-filled)
+    }
     made = q + 1;
     if (!ok) {  // out of memory: what exists is enough
       (void)hipGetLastError();
-      for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
+      if (!cand[q].arena)
+        for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
       made = q;
       break;
     }
@@ -1036,9 +1066,12 @@ static int tune_placement(cup2d_ctx *c) {
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   for (int q = 0; q < made; q++) {  // the sets that lost go back to the driver, not into the process pool (dev_release)
     if (q == best) continue;
-    for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
+    if (cand[q].arena) (void)hipFree(cand[q].arena);
+    else
+      for (int k = 0; k < NV; k++) dev_release(cand[q].v[k]);
   }
   for (int k = 0; k < NV; k++) *slot[k] = cand[best].v[k];
+  c->vec_arena = cand[best].arena;  // (interior pointers then: cup2d_destroy frees the arena, not the vectors)
   // the survivors start a solve as every solver vector does: zero
   for (int k = 0; k < NV; k++) CUP2D_HIP_CHECK(hipMemsetAsync(cand[best].v[k], 0, bytes, c->stream));
   CUP2D_HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));
@@ -1051,7 +1084,9 @@ static int tune_placement(cup2d_ctx *c) {
   c->placement_worst_us = 1e3 * worst;
   c->placement_first_us = 1e3 * cand[0].ms;
   if (clk.on) {
-    for (int q = 0; q < made; q++) fprintf(stderr, "[cup2d timing] tune_placement: set %d: %.1f us per iteration%s\n", q, 1e3 * cand[q].ms, q == best ? "  <- kept" : "");
+    for (int q = 0; q < made; q++)
+      fprintf(stderr, "[cup2d timing] tune_placement: set %d (%s, pad %lld, first vector at %p): %.1f us per iteration%s\n", q,
+              cand[q].arena ? "arena" : "separate", cand[q].pad, (void *)cand[q].v[0], 1e3 * cand[q].ms, q == best ? "  <- kept" : "");
     clk.lap("search");
   }
   return rc;

@@ -782,7 +782,7 @@ def main():
                 except Exception as e:  # informative
                     floors[tag] = {"error": str(e)[:160]}
                 beat("north-star floors")
-            north["floors_on_this_box_us"] = dict(floors, what="host clock over 10 back-to-back launches at %d^2 (tools/gpu_advect_stages.py): rhs = the "
+            north["floors_on_this_box_us"] = dict(floors, what="HIP events around each of 10 launches at %d^2 (tools/gpu_advect_stages.py): rhs = the "
                                                               "functor alone, stage1 / stage2 = the fused RK stages; a launch can be no shorter than "
                                                               "the larger of its two floors" % nx)
         north["target_note"] = ("0.70 of HBM peak at 40 B/cell = 120 us per launch: below stage 2's measured memory floor (142 us) and "

@@ -40,13 +40,14 @@ static __device__ __forceinline__ void amr_slot(int s, int q, int &gi, int &e1, 
 //                           fillcases (main.cpp:7174-7179 passes tmp's buffers), so none are written (6021-6043)
 template <int OP>
 __global__ __launch_bounds__(WG) void k_amr_scalar(const double *__restrict__ x, double *__restrict__ y, AmrDev T,
-                                                   int nblocks, double dt) {
+                                                   int nblocks, double dt, const int32_t *__restrict__ list) {
   __shared__ double labs[WPG][LAB1 * LAB1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *lab = labs[wave];
   const int ix = lane & 7, iy = lane >> 3;
   const int c0 = (iy + 1) * LAB1 + ix + 1;
-  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+  for (int i = blockIdx.x * WPG + wave; i < nblocks; i += gridDim.x * WPG) {
+    const int b = list ? uniform(list[i]) : i;  // (list: the inner or the halo blocks of an N-rank patch, amr_phase_lists)
     lab[c0] = x[(size_t)b * BC + lane];
     wave_lds_sync();
     int s = lane >> 3, q = lane & 7, gi = 0, e1 = 0, e2 = 0, kind = AMR_WALL;
@@ -84,14 +85,15 @@ __global__ __launch_bounds__(WG) void k_amr_scalar(const double *__restrict__ x,
 template <int OP>
 __global__ __launch_bounds__(WG) void k_amr_vector(const double2 *__restrict__ vel, const double2 *__restrict__ udef,
                                                    const double *__restrict__ chi, double *__restrict__ out, AmrDev T,
-                                                   int nblocks, double dt) {
+                                                   int nblocks, double dt, const int32_t *__restrict__ list) {
   __shared__ double2 vlabs[WPG][LAB1 * LAB1];
   __shared__ double2 ulabs[WPG][LAB1 * LAB1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double2 *vlab = vlabs[wave], *ulab = ulabs[wave];
   const int ix = lane & 7, iy = lane >> 3;
   const int c0 = (iy + 1) * LAB1 + ix + 1;
-  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+  for (int i = blockIdx.x * WPG + wave; i < nblocks; i += gridDim.x * WPG) {
+    const int b = list ? uniform(list[i]) : i;
     vlab[c0] = vel[(size_t)b * BC + lane];
     if (OP == 1) ulab[c0] = udef[(size_t)b * BC + lane];
     wave_lds_sync();
@@ -187,14 +189,16 @@ struct AmrField2 {
 // coarse-fine faces (main.cpp:5504-5570); faces2: [nblocks][4][8][2]
 template <class W>
 __global__ __launch_bounds__(WG) void k_amr_advect(const double2 *__restrict__ vel, double2 *__restrict__ out, AmrDev T,
-                                                   double *__restrict__ faces2, int nblocks, double nu, double dt) {
+                                                   double *__restrict__ faces2, int nblocks, double nu, double dt,
+                                                   const int32_t *__restrict__ list) {
   __shared__ AdvectLds lds[WPG];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   AdvectLds &L = lds[wave];
   RimSlot rim;
   rim.init(L, lane);
   const int ix = lane & 7, iy = lane >> 3;
-  for (int b = blockIdx.x * WPG + wave; b < nblocks; b += gridDim.x * WPG) {
+  for (int i = blockIdx.x * WPG + wave; i < nblocks; i += gridDim.x * WPG) {
+    const int b = list ? uniform(list[i]) : i;
     L.lab[(iy + 3) * LABS + ix + 3] = vel[(size_t)b * BC + lane];
     wave_lds_sync();
     double2 g[4];
@@ -292,6 +296,66 @@ static int amr_refresh(cup2d_ctx *c, const double *field, int dim, int set) {
   if (c->cells[set].active) return exchange_cells(c, set, const_cast<double *>(field), dim);
   return exchange_halo(c, const_cast<double *>(field), dim, BS);
 }
+// ... in two halves: pack + the transfer under way (on the communicator's own stream where it has one) | arrival + unpack
+static int amr_refresh_begin(cup2d_ctx *c, const double *field, int dim, int set) {
+  if (c->cells[set].active) return exchange_cells_begin(c, set, const_cast<double *>(field), dim);
+  return exchange_begin(c, field, dim, BS);
+}
+static int amr_refresh_end(cup2d_ctx *c, const double *field, int dim, int set) {
+  if (c->cells[set].active) return exchange_cells_end(c, set, const_cast<double *>(field), dim);
+  return exchange_end(c, const_cast<double *>(field), dim, BS);
+}
+// The inner / halo split of computeA (main.cpp:3035-3057) on an adapted grid: which owned blocks read a ghost block is not a
+// matter of position (coarse-fine sides read two rings, the halo-3 tile the tangential sides of a coarser neighbour), so the
+// lists come from the kernels' own ghost expressions run with a recording accessor (amr_host.hip amr_blocks_reading_ghosts)
+// on the host copies of the tables, once per topology and operator family.
+static int amr_phase_lists(cup2d_ctx *c, int set, const AmrTopo::Phase **out) {
+  AmrTopo::Phase &P = c->amr.phase[set];
+  if (!P.built) {
+    std::vector<int32_t> inner, halo;
+    amr_blocks_reading_ghosts(c->nblocks, c->ntotal, c->amr.h_kind.data(), c->amr.h_nbr2.data(), c->amr.h_half.data(), set, inner, halo);
+    CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    dev_free(P.d_inner); dev_free(P.d_halo);
+    P.d_inner = P.d_halo = nullptr;
+    P.n_inner = (int)inner.size(); P.n_halo = (int)halo.size();
+    if (P.n_inner) {
+      CUP2D_HIP_CHECK(dev_malloc(&P.d_inner, sizeof(int32_t) * inner.size()));
+      CUP2D_HIP_CHECK(hipMemcpy(P.d_inner, inner.data(), sizeof(int32_t) * inner.size(), hipMemcpyHostToDevice));
+    }
+    if (P.n_halo) {
+      CUP2D_HIP_CHECK(dev_malloc(&P.d_halo, sizeof(int32_t) * halo.size()));
+      CUP2D_HIP_CHECK(hipMemcpy(P.d_halo, halo.data(), sizeof(int32_t) * halo.size(), hipMemcpyHostToDevice));
+    }
+    P.built = true;
+  }
+  *out = &P;
+  return CUP2D_OK;
+}
+void amr_phase_release(cup2d_ctx *c) {
+  for (auto &P : c->amr.phase) {
+    dev_free(P.d_inner); dev_free(P.d_halo);
+    P = AmrTopo::Phase();
+  }
+}
+// One block functor over the phases of `blocks` (ctx.h): launch(list, n) runs it on n blocks (list == nullptr: blocks 0 .. n-1).
+// ALL on N ranks: `field` (the last of the fields the functor reads across block sides; the others were refreshed by the
+// caller) travels while the inner blocks are swept.
+template <class Launch>
+static int amr_phased(cup2d_ctx *c, int blocks, const double *field, int dim, int set, Launch launch) {
+  const bool ghosts = c->nghost > 0 && c->exchange;
+  if (blocks == CUP2D_BLOCKS_ALL && !ghosts) {
+    launch((const int32_t *)nullptr, c->nblocks);
+    return CUP2D_OK;
+  }
+  const AmrTopo::Phase *P = nullptr;
+  CUP2D_TRY(amr_phase_lists(c, set, &P));
+  if (blocks == CUP2D_BLOCKS_ALL) CUP2D_TRY(amr_refresh_begin(c, field, dim, set));
+  if (blocks != CUP2D_BLOCKS_HALO && P->n_inner) launch((const int32_t *)P->d_inner, P->n_inner);
+  if (blocks == CUP2D_BLOCKS_ALL) CUP2D_TRY(amr_refresh_end(c, field, dim, set));
+  if (blocks != CUP2D_BLOCKS_INNER && P->n_halo) launch((const int32_t *)P->d_halo, P->n_halo);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
 // the face arrays (BlockCase::d, REC doubles per block) of the blocks in the send list -> the peers' ghost slots: the
 // coarse side of a coarse-fine face adds the fine side's fluxes, and the fine blocks may live on another rank
 // (main.cpp:1819-1825 exchanges exactly these)
@@ -323,45 +387,49 @@ static int amr_exchange_faces(cup2d_ctx *c, double *faces, int rec) {
   return CUP2D_OK;
 }
 
-static int amr_grid(const cup2d_ctx *c) {
-  int g = (c->nblocks + WPG - 1) / WPG;
+static int amr_grid(const cup2d_ctx *c, int n = -1) {
+  int g = ((n < 0 ? c->nblocks : n) + WPG - 1) / WPG;
   return g > c->grid ? c->grid : (g < 1 ? 1 : g);
 }
 
-int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract) {
+int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int blocks) {
   const AmrDev T = amr_dev(c);
-  CUP2D_TRY(amr_refresh(c, x, 1, CUP2D_CELLS_HALO1));
-  if (subtract) {
-    hipLaunchKernelGGL(k_amr_scalar<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
+  CUP2D_TRY(amr_phased(c, blocks, x, 1, CUP2D_CELLS_HALO1, [&](const int32_t *list, int n) {
+    if (subtract) hipLaunchKernelGGL(k_amr_scalar<0>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, x, y, T, n, 0.0, list);
+    else hipLaunchKernelGGL(k_amr_scalar<1>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, x, y, T, n, 0.0, list);
+  }));
+  if (subtract && blocks != CUP2D_BLOCKS_INNER) {  // the flux correction needs the face arrays of every block (and of the peers' blocks)
     CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces, 4 * BS));
     hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, y, T, c->nblocks);
-  } else {
-    hipLaunchKernelGGL(k_amr_scalar<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, x, y, T, c->nblocks, 0.0);
   }
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
-int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt) {
-  CUP2D_TRY(amr_refresh(c, pres, 1, CUP2D_CELLS_HALO1));
-  hipLaunchKernelGGL(k_amr_scalar<2>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, pres, tmpV, amr_dev(c), c->nblocks, dt);
-  CUP2D_HIP_CHECK(hipGetLastError());
-  return CUP2D_OK;
-}
-int amr_vorticity(cup2d_ctx *c, const double *vel, double *out) {
-  CUP2D_TRY(amr_refresh(c, vel, 2, CUP2D_CELLS_HALO1));
-  hipLaunchKernelGGL(k_amr_vector<0>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, nullptr, nullptr, out,
-                     amr_dev(c), c->nblocks, 0.0);
-  CUP2D_HIP_CHECK(hipGetLastError());
-  return CUP2D_OK;
-}
-int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt) {
+int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt, int blocks) {
   const AmrDev T = amr_dev(c);
-  CUP2D_TRY(amr_refresh(c, vel, 2, CUP2D_CELLS_HALO1));
-  CUP2D_TRY(amr_refresh(c, udef, 2, CUP2D_CELLS_HALO1));
-  hipLaunchKernelGGL(k_amr_vector<1>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (const double2 *)udef,
-                     chi, out, T, c->nblocks, dt);
-  CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces, 4 * BS));
-  hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, out, T, c->nblocks);
+  return amr_phased(c, blocks, pres, 1, CUP2D_CELLS_HALO1, [&](const int32_t *list, int n) {
+    hipLaunchKernelGGL(k_amr_scalar<2>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, pres, tmpV, T, n, dt, list);
+  });
+}
+int amr_vorticity(cup2d_ctx *c, const double *vel, double *out, int blocks) {
+  const AmrDev T = amr_dev(c);
+  return amr_phased(c, blocks, vel, 2, CUP2D_CELLS_HALO1, [&](const int32_t *list, int n) {
+    hipLaunchKernelGGL(k_amr_vector<0>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, (const double2 *)vel, (const double2 *)nullptr,
+                       (const double *)nullptr, out, T, n, 0.0, list);
+  });
+}
+int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt, int blocks) {
+  const AmrDev T = amr_dev(c);
+  // two fields cross block sides: the first is refreshed at once, the second travels while the inner blocks are swept
+  if (blocks == CUP2D_BLOCKS_ALL) CUP2D_TRY(amr_refresh(c, vel, 2, CUP2D_CELLS_HALO1));
+  CUP2D_TRY(amr_phased(c, blocks, udef, 2, CUP2D_CELLS_HALO1, [&](const int32_t *list, int n) {
+    hipLaunchKernelGGL(k_amr_vector<1>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, (const double2 *)vel, (const double2 *)udef, chi,
+                       out, T, n, dt, list);
+  }));
+  if (blocks != CUP2D_BLOCKS_INNER) {
+    CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces, 4 * BS));
+    hipLaunchKernelGGL(k_amr_fillcases, dim3(amr_grid(c)), dim3(WG), 0, c->stream, out, T, c->nblocks);
+  }
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
@@ -490,17 +558,20 @@ int amr_project(cup2d_ctx *c, double dt) {
 }
 
 // tmpV = KernelAdvectDiffuse(vel) with the flux correction (main.cpp:6611-6617 / 6627-6633)
-int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt) {
+int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt, int blocks) {
   const AmrDev T = amr_dev(c);
-  CUP2D_TRY(amr_refresh(c, vel, 2, CUP2D_CELLS_HALO3));
-  if (c->math == CUP2D_MATH_STRICT)
-    hipLaunchKernelGGL(k_amr_advect<WenoStrict>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV,
-                       T, c->amr.d_faces2, c->nblocks, nu, dt);
-  else
-    hipLaunchKernelGGL(k_amr_advect<WenoFast>, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV, T,
-                       c->amr.d_faces2, c->nblocks, nu, dt);
-  CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces2, 4 * BS * 2));
-  hipLaunchKernelGGL(k_amr_fillcases2, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)tmpV, T, c->amr.d_faces2, c->nblocks);
+  CUP2D_TRY(amr_phased(c, blocks, vel, 2, CUP2D_CELLS_HALO3, [&](const int32_t *list, int n) {
+    if (c->math == CUP2D_MATH_STRICT)
+      hipLaunchKernelGGL(k_amr_advect<WenoStrict>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV,
+                         T, c->amr.d_faces2, n, nu, dt, list);
+    else
+      hipLaunchKernelGGL(k_amr_advect<WenoFast>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV, T,
+                         c->amr.d_faces2, n, nu, dt, list);
+  }));
+  if (blocks != CUP2D_BLOCKS_INNER) {
+    CUP2D_TRY(amr_exchange_faces(c, c->amr.d_faces2, 4 * BS * 2));
+    hipLaunchKernelGGL(k_amr_fillcases2, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)tmpV, T, c->amr.d_faces2, c->nblocks);
+  }
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }

@@ -219,6 +219,52 @@ extern "C" int cup2d_amr_trace_reads(int nblocks, const int32_t *kind, const int
 
 namespace cup2d {
 
+// Which owned blocks read a ghost block (id >= nowned) in the operators of family `set` (0: the 32 cross ghosts of the halo-1
+// operators, 1: the 96 of the halo-3 tile): the kernels' own expressions with an accessor that only looks at the block id.
+// A block further than three neighbour steps from every ghost block cannot (a halo-3 tile reaches one block across a side
+// and, across a coarser one, that block's tangential neighbours), and is not traced.
+void amr_blocks_reading_ghosts(int nowned, int ntotal, const int32_t *kind, const int32_t *nbr2, const int32_t *half, int set,
+                               std::vector<int32_t> &inner, std::vector<int32_t> &halo) {
+  inner.clear();
+  halo.clear();
+  std::vector<unsigned char> near((size_t)ntotal, 0), next;
+  for (int b = nowned; b < ntotal; b++) near[(size_t)b] = 1;
+  for (int step = 0; step < 3; step++) {
+    next = near;
+    for (int b = 0; b < ntotal; b++) {
+      if (near[(size_t)b]) continue;
+      for (int e = 0; e < 8 && !next[(size_t)b]; e++) {
+        if (kind[4 * b + (e >> 1)] == CUP2D_AMR_WALL) continue;
+        const int nb = nbr2[8 * b + e];
+        if (nb >= 0 && nb < ntotal && near[(size_t)nb]) next[(size_t)b] = 1;
+      }
+    }
+    near.swap(next);
+  }
+  AmrDev T;
+  T.kind = kind; T.nbr2 = nbr2; T.half = half; T.level = nullptr; T.faces = nullptr; T.h0 = 0.0;
+  for (int b = 0; b < nowned; b++) {
+    bool reads = false;
+    if (near[(size_t)b]) {
+      if (set == 0) {
+        for (int s = 0; s < 4 && !reads; s++)
+          for (int q = 0; q < BS && !reads; q++) {
+            const auto get = [&](int blk, int) { reads = reads || blk >= nowned; return 0.0; };
+            (void)amr_ghost(get, kind[4 * b + s], nbr2[(4 * b + s) * 2], nbr2[(4 * b + s) * 2 + 1], half[4 * b + s], s, q, 0.0, 0.0, 1.0);
+          }
+      } else {
+        for (int s = 0; s < 4 && !reads; s++)
+          for (int k = 0; k < 3 && !reads; k++)
+            for (int q = 0; q < BS && !reads; q++) {
+              const auto get = [&](int blk, int) { reads = reads || blk >= nowned; return double2{0.0, 0.0}; };
+              (void)amr_ghost3(get, T, b, s, k, q, double2{0.0, 0.0}, double2{0.0, 0.0});
+            }
+      }
+    }
+    (reads ? halo : inner).push_back(b);
+  }
+}
+
 // The same operator straight in the hybrid form cup2d_set_matrix_coo arrives at (ctx.h SellMatrix) for the `nowned` first
 // blocks of tables that cover `nowned` + ghost blocks: a block whose four sides are walls or same-level OWNED blocks is
 // plain -- no row is built for it --, every other block gets its 64 rows as sliced-ELL entries, each row's entries in

@@ -467,6 +467,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->mat.d_reg);
   dev_free(c->amr.d_level); dev_free(c->amr.d_kind); dev_free(c->amr.d_nbr2); dev_free(c->amr.d_half);
   dev_free(c->amr.d_faces); dev_free(c->amr.d_faces2);
+  amr_phase_release(c);
   for (auto &cp : c->cells) { dev_free(cp.d_send); dev_free(cp.d_recv); cp = cup2d::CellPlan(); }
   dev_free(c->plan.d_send_block); dev_free(c->plan.d_send_face);
   dev_free(c->plan.d_recv_block); dev_free(c->plan.d_recv_face);
@@ -685,6 +686,7 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   cup2d::AmrTopo &A = c->amr;
   dev_free(A.d_level); dev_free(A.d_kind); dev_free(A.d_nbr2); dev_free(A.d_half); dev_free(A.d_faces); dev_free(A.d_faces2);
+  amr_phase_release(c);
   A = cup2d::AmrTopo();
   CUP2D_HIP_CHECK(dev_malloc(&A.d_level, sizeof(int32_t) * nb));
   CUP2D_HIP_CHECK(dev_malloc(&A.d_kind, sizeof(int32_t) * nb * 4));
@@ -715,17 +717,20 @@ int cup2d_amr_set_finest_level(cup2d_ctx *c, int level_finest) {
   c->amr.h_min = c->amr.h0 / (double)(1 << level_finest);
   return CUP2D_OK;
 }
-#define AMR_ALL_BLOCKS(c, phase)                                                                \
-  if ((c)->amr.active && (phase) != CUP2D_BLOCKS_ALL) {                                         \
-    set_error("%s: adapted grids take CUP2D_BLOCKS_ALL", __func__);                             \
+// Adapted grids take the three phases as well (computeA's split works on any grid, main.cpp:3035-3057): _ALL refreshes the
+// ghost copies itself -- the blocks that read no ghost block are swept while they travel --, _INNER / _HALO are its two halves
+// for a caller that exchanges in between (cup2d_halo_exchange); the flux correction of ALL blocks rides on _HALO (amr.hip)
+#define AMR_PHASE_OK(c, phase)                                                                  \
+  if ((phase) != CUP2D_BLOCKS_ALL && (phase) != CUP2D_BLOCKS_INNER && (phase) != CUP2D_BLOCKS_HALO) { \
+    set_error("%s: phase %d", __func__, (int)(phase));                                          \
     return CUP2D_ERR_ARG;                                                                       \
   }
 
 // ---- block operators --------------------------------------------------------------------------
 int cup2d_advect_diffuse_rhs(cup2d_ctx *c, double nu, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
-  AMR_ALL_BLOCKS(c, phase);
-  if (c->amr.active) return amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt);
+  AMR_PHASE_OK(c, phase);
+  if (c->amr.active) return amr_advect_diffuse_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], nu, dt, phase);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   return launch_advect(c, c->d_field[CUP2D_VEL], nullptr, c->d_field[CUP2D_TMPV], 0, nu, dt, 0.0, first, count);
@@ -735,7 +740,7 @@ int cup2d_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage, in
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   if (c->amr.active) {  // the reference's un-fused stage (flux correction between the functor and the update)
-    AMR_ALL_BLOCKS(c, phase);
+    if (phase != CUP2D_BLOCKS_ALL) { set_error("advect_diffuse_stage: a whole stage on an adapted grid takes CUP2D_BLOCKS_ALL (cup2d_advect_diffuse_rhs has the phases)"); return CUP2D_ERR_ARG; }
     if (stage != 1 && stage != 2) { set_error("advect_diffuse_stage: stage %d", stage); return CUP2D_ERR_ARG; }
     return amr_advect_diffuse_stage(c, nu, dt, stage);
   }
@@ -769,8 +774,7 @@ int cup2d_vorticity(cup2d_ctx *c, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
-  AMR_ALL_BLOCKS(c, phase);
-  if (c->amr.active) return amr_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP]);
+  if (c->amr.active) return amr_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP], phase);
   return launch_vorticity(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMP], first, count);
 }
 int cup2d_pressure_rhs(cup2d_ctx *c, double dt, int use_bodies, int phase) {
@@ -778,9 +782,8 @@ int cup2d_pressure_rhs(cup2d_ctx *c, double dt, int use_bodies, int phase) {
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
   if (!(dt > 0)) { set_error("pressure_rhs: dt"); return CUP2D_ERR_ARG; }
-  AMR_ALL_BLOCKS(c, phase);
   if (c->amr.active)  // the chi / udef terms are always evaluated (chi = 0 without bodies), as the reference does
-    return amr_pressure_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], c->d_field[CUP2D_CHI], c->d_field[CUP2D_TMP], dt);
+    return amr_pressure_rhs(c, c->d_field[CUP2D_VEL], c->d_field[CUP2D_TMPV], c->d_field[CUP2D_CHI], c->d_field[CUP2D_TMP], dt, phase);
   return launch_pressure_rhs(c, c->d_field[CUP2D_VEL], use_bodies ? c->d_field[CUP2D_TMPV] : nullptr,
                              use_bodies ? c->d_field[CUP2D_CHI] : nullptr, nullptr, c->d_field[CUP2D_TMP], dt, first, count);
 }
@@ -788,8 +791,7 @@ int cup2d_laplacian_sub(cup2d_ctx *c, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
-  AMR_ALL_BLOCKS(c, phase);
-  if (c->amr.active) return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1);
+  if (c->amr.active) return amr_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1, phase);
   return launch_laplacian(c, c->d_field[CUP2D_POLD], c->d_field[CUP2D_TMP], 1, first, count);
 }
 // zero_pres = false (cup2d_step only): the solve that follows is told that its initial guess is zero (ctx.h x0_is_zero)
@@ -825,8 +827,7 @@ int cup2d_pressure_correction(cup2d_ctx *c, double dt, int phase) {
   CUP2D_CHECK_CTX(c);
   int first, count;
   CUP2D_TRY(phase_range(c, phase, &first, &count));
-  AMR_ALL_BLOCKS(c, phase);
-  if (c->amr.active) return amr_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], dt);
+  if (c->amr.active) return amr_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], dt, phase);
   return launch_pressure_correction(c, c->d_field[CUP2D_PRES], c->d_field[CUP2D_TMPV], nullptr, dt, 0, first, count);
 }
 int cup2d_add_correction(cup2d_ctx *c) {

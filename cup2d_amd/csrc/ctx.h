@@ -128,6 +128,14 @@ struct AmrTopo {
   double *d_faces = nullptr;     // [nblocks][4][8] fluxes recorded by the functors (BlockCase::d, main.cpp:513-517)
   double *d_faces2 = nullptr;    // [nblocks][4][8][2] the same for vector functors (KernelAdvectDiffuse)
   std::vector<int32_t> h_kind, h_nbr2, h_half;  // host copies: cup2d_amr_install_poisson assembles from them
+  // N ranks: the owned blocks by whether their operators read a ghost block (computeA's inner / halo split on an adapted
+  // grid, main.cpp:3035-3057), per operator family: 0 the halo-1 operators, 1 the halo-3 tile (amr.hip amr_phase_lists; built
+  // on first use from the kernels' own ghost expressions)
+  struct Phase {
+    bool built = false;
+    int n_inner = 0, n_halo = 0;
+    int32_t *d_inner = nullptr, *d_halo = nullptr;
+  } phase[2];
 };
 
 }  // namespace cup2d
@@ -370,15 +378,23 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
 int finish(cup2d_ctx *c, int G, int nsum, int with_max, int stage, bool guarded, int *host_status = nullptr);
 int finish_local(cup2d_ctx *c, int nsum, int with_max, int stage, int *host_status = nullptr);
 // halo-1 block operators on a block-AMR grid (amr.hip)
-int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract);
-int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt);
-int amr_vorticity(cup2d_ctx *c, const double *vel, double *out);
-int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt);
+// blocks: CUP2D_BLOCKS_ALL = refresh the ghost copies (inner blocks swept while they travel), the functor on every block, the
+// flux correction; _INNER = the functor on the blocks that read no ghost block, no exchange; _HALO = the functor on the
+// others + the flux correction of all blocks (the caller has refreshed the ghost copies in between: cup2d_halo_exchange)
+int amr_laplacian(cup2d_ctx *c, const double *x, double *y, int subtract, int blocks = CUP2D_BLOCKS_ALL);
+int amr_pressure_correction(cup2d_ctx *c, const double *pres, double *tmpV, double dt, int blocks = CUP2D_BLOCKS_ALL);
+int amr_vorticity(cup2d_ctx *c, const double *vel, double *out, int blocks = CUP2D_BLOCKS_ALL);
+int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt, int blocks = CUP2D_BLOCKS_ALL);
+void amr_phase_release(cup2d_ctx *c);
+// amr_host.hip: owned blocks [0, nowned) by whether the operators of family `set` (0 halo 1, 1 halo 3) read a block >= nowned
+void amr_blocks_reading_ghosts(int nowned, int ntotal, const int32_t *kind, const int32_t *nbr2, const int32_t *half, int set,
+                               std::vector<int32_t> &inner, std::vector<int32_t> &halo);
 int amr_advect_diffuse_rk2(cup2d_ctx *c, double nu, double dt);
 int amr_advect_diffuse_stage(cup2d_ctx *c, double nu, double dt, int stage);
 int amr_poisson_rhs(cup2d_ctx *c, double dt);
 int amr_project(cup2d_ctx *c, double dt);
-int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt);
+int amr_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi, double *out, double dt,
+                     int blocks = CUP2D_BLOCKS_ALL);
 int halo_pack_impl(cup2d_ctx *c, const double *src, int dim, int width, double *buf);
 int halo_unpack_impl(cup2d_ctx *c, double *dst, int dim, int width, const double *buf);
 // ghost-strip exchange of a device vector through the comm callbacks (no-ops without ghosts):
@@ -389,6 +405,8 @@ int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width);
 // the same through a cell plan (cup2d_halo_plan_cells), blocking like exchange_halo: gather the listed cells, transport with
 // strip_doubles = CUP2D_CELL_STRIP(set, dim), scatter into the ghost blocks.  dst == nullptr: into vec's own ghost blocks
 int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim);
+int exchange_cells_begin(cup2d_ctx *c, int set, double *vec, int dim);  // pack + the transfer under way
+int exchange_cells_end(cup2d_ctx *c, int set, double *vec, int dim);    // arrival + unpack
 // whole blocks of two scalar vectors in one message (128 doubles per strip)
 int exchange_begin_blocks2(cup2d_ctx *c, const double *v0, const double *v1);
 int exchange_end_blocks2(cup2d_ctx *c, double *v0, double *v1);

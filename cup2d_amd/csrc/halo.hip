@@ -188,19 +188,16 @@ __global__ __launch_bounds__(WG) void k_cells(double *__restrict__ field, double
     else field[at] = buf[i];
   }
 }
-int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim) {
+int exchange_cells_begin(cup2d_ctx *c, int set, double *vec, int dim) {
   if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
   const CellPlan &P = c->cells[set];
   if (!P.active) { set_error("exchange_cells: no cell plan %d", set); return CUP2D_ERR_ARG; }
   if (!c->d_send || !c->d_recv) { set_error("exchange_cells: a cell plan needs both buffers of cup2d_set_comm"); return CUP2D_ERR_ARG; }
-  const auto grid_for_n = [&](size_t total) {
-    int g = (int)((total + WG - 1) / WG);
-    return g > c->grid ? c->grid : (g < 1 ? 1 : g);
-  };
   {
     ProfScope prof(c, CUP2D_T_HALO);
     if (P.nsend > 0) {
-      hipLaunchKernelGGL(k_cells<true>, dim3(grid_for_n((size_t)P.nsend * dim)), dim3(WG), 0, c->stream, vec, c->d_send, P.d_send, P.nsend, dim);
+      int g = (int)(((size_t)P.nsend * dim + WG - 1) / WG);
+      hipLaunchKernelGGL(k_cells<true>, dim3(g > c->grid ? c->grid : (g < 1 ? 1 : g)), dim3(WG), 0, c->stream, vec, c->d_send, P.d_send, P.nsend, dim);
       CUP2D_HIP_CHECK(hipGetLastError());
     }
   }
@@ -208,16 +205,26 @@ int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim) {
     set_error("exchange callback failed (cell plan %d)", set);
     return CUP2D_ERR_COMM;
   }
+  return CUP2D_OK;
+}
+int exchange_cells_end(cup2d_ctx *c, int set, double *vec, int dim) {
+  if (c->nghost == 0 || !c->exchange) return CUP2D_OK;
+  const CellPlan &P = c->cells[set];
   if (c->wait && c->wait(c->comm_user, c->stream) != 0) {
     set_error("wait callback failed");
     return CUP2D_ERR_COMM;
   }
   if (P.nrecv > 0) {
     ProfScope prof(c, CUP2D_T_HALO);
-    hipLaunchKernelGGL(k_cells<false>, dim3(grid_for_n((size_t)P.nrecv * dim)), dim3(WG), 0, c->stream, vec, c->d_recv, P.d_recv, P.nrecv, dim);
+    int g = (int)(((size_t)P.nrecv * dim + WG - 1) / WG);
+    hipLaunchKernelGGL(k_cells<false>, dim3(g > c->grid ? c->grid : (g < 1 ? 1 : g)), dim3(WG), 0, c->stream, vec, c->d_recv, P.d_recv, P.nrecv, dim);
     CUP2D_HIP_CHECK(hipGetLastError());
   }
   return CUP2D_OK;
+}
+int exchange_cells(cup2d_ctx *c, int set, double *vec, int dim) {
+  CUP2D_TRY(exchange_cells_begin(c, set, vec, dim));
+  return exchange_cells_end(c, set, vec, dim);
 }
 int exchange_halo(cup2d_ctx *c, double *vec, int dim, int width) {
   CUP2D_TRY(exchange_begin(c, vec, dim, width));

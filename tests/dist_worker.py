@@ -352,6 +352,19 @@ def run_amr_gpu(rank, world):
         s.set_field(L.VEL, F["vel"][own])
         s.advect_diffuse_rhs(dt)  # halo-3 tile: two rings of ghost blocks, dim-2 face exchange
         assert np.array_equal(s.get_field(L.TMPV), F["advdiff"][own]), "advect_diffuse rank %d" % rank
+        # computeA's split by hand (main.cpp:3035-3057): the blocks that read no ghost block, the ghost copies refreshed (whole
+        # blocks through the block plan), then the others + the flux correction -- the same bits
+        s.set_field(L.POLD, F["pold"][own])
+        s.set_field(L.TMP, F["tmp_in"][own])
+        L.check(s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER), "laplacian_sub inner")
+        L.check(s.L.cup2d_halo_exchange(s._ctx, L.POLD, 8), "halo_exchange")
+        L.check(s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_HALO), "laplacian_sub halo")
+        assert np.array_equal(s.get_field(L.TMP), F["tmp_out"][own]), "laplacian_sub in two phases, rank %d" % rank
+        s.set_field(L.VEL, F["vel"][own])
+        L.check(s.L.cup2d_advect_diffuse_rhs(s._ctx, s.nu, dt, L.BLOCKS_INNER), "advect inner")
+        L.check(s.L.cup2d_halo_exchange(s._ctx, L.VEL, 8), "halo_exchange")
+        L.check(s.L.cup2d_advect_diffuse_rhs(s._ctx, s.nu, dt, L.BLOCKS_HALO), "advect halo")
+        assert np.array_equal(s.get_field(L.TMPV), F["advdiff"][own]), "advect_diffuse in two phases, rank %d" % rank
         # ---- a whole step against the single-context path on the same grid ----
         with AmrSimulation(G, nu=float(F["nu"])) as ref:
             ref.set_math(True)

@@ -717,8 +717,44 @@ def test_amr_unsupported_entry_points_say_so(gpu_lib):
     F = golden("amr_functors.npz")
     with AmrSimulation(AmrBlockGrid(F["blocks"])) as s:
         assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 3, L.BLOCKS_ALL) == -1  # a stage that does not exist
-        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 1, L.BLOCKS_INNER) == -1
-        assert s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER) == -1  # CUP2D_ERR_ARG: adapted grids take all blocks
+        assert s.L.cup2d_advect_diffuse_stage(s._ctx, 1e-3, 1e-3, 1, L.BLOCKS_INNER) == -1  # a whole stage takes all blocks
+        assert s.L.cup2d_laplacian_sub(s._ctx, 7) == -1  # no such phase
+
+
+@pytest.mark.gpu
+def test_amr_block_operators_in_two_phases_gpu(gpu_lib):
+    """computeA's inner / halo split (main.cpp:3035-3057) on an adapted grid through the public phases: CUP2D_BLOCKS_INNER (the
+    functor on the blocks that read no ghost block; on one rank: all of them) followed by CUP2D_BLOCKS_HALO (the functor on the
+    others + the flux correction of all blocks) leaves what CUP2D_BLOCKS_ALL leaves, bit for bit -- and that is the reference's
+    functor (golden vectors).  The N-rank form of the same (ghost copies travelling in between) is in tests/dist_worker.py."""
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, AmrSimulation
+    F = golden("amr_functors.npz")
+    dt = float(F["dt"])
+    with AmrSimulation(AmrBlockGrid(F["blocks"]), nu=float(F["nu"])) as s:
+        s.set_math(True)
+        s.set_field(L.POLD, F["pold"])
+        s.set_field(L.TMP, F["tmp_in"])
+        L.check(s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_INNER), "inner")
+        assert not np.array_equal(s.get_field(L.TMP), F["tmp_out"])   # the flux correction is still missing
+        L.check(s.L.cup2d_laplacian_sub(s._ctx, L.BLOCKS_HALO), "halo")
+        assert np.array_equal(s.get_field(L.TMP), F["tmp_out"])
+        s.set_field(L.VEL, F["vel"])
+        s.set_field(L.TMPV, F["udef"])
+        s.set_field(L.CHI, F["chi"])
+        for ph in (L.BLOCKS_INNER, L.BLOCKS_HALO):
+            L.check(s.L.cup2d_pressure_rhs(s._ctx, dt, 1, ph), "pressure_rhs")
+        assert np.array_equal(s.get_field(L.TMP), F["prhs"])
+        for ph in (L.BLOCKS_INNER, L.BLOCKS_HALO):
+            L.check(s.L.cup2d_vorticity(s._ctx, ph), "vorticity")
+        assert np.array_equal(s.get_field(L.TMP), F["vort"])
+        s.set_field(L.PRES, F["pres"])
+        for ph in (L.BLOCKS_INNER, L.BLOCKS_HALO):
+            L.check(s.L.cup2d_pressure_correction(s._ctx, dt, ph), "pressure_correction")
+        assert np.array_equal(s.get_field(L.TMPV), F["pcorr"])
+        for ph in (L.BLOCKS_INNER, L.BLOCKS_HALO):
+            L.check(s.L.cup2d_advect_diffuse_rhs(s._ctx, s.nu, dt, ph), "advect_diffuse_rhs")
+        assert np.array_equal(s.get_field(L.TMPV), F["advdiff"])
 
 
 @pytest.mark.gpu

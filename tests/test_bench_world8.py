@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_at_world_8_sharing_one_gpu():
     env = dict(os.environ, CUP2D_BENCH_SHARE_GPU="1", CUP2D_BENCH_WATCHDOG_S="200", OMP_NUM_THREADS="4")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "256", "--steps", "2", "--warmup", "1",
-           "--layout", "configs3", "--configs3-n", "2048", "--iters", "20", "--no-cpu-baseline"]
+           "--layout", "configs3", "--configs3-n", "1024", "--iters", "20", "--no-cpu-baseline"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=840, cwd=ROOT)
     err = r.stderr.decode("utf-8", "replace")
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -26,7 +26,7 @@ def test_bench_line_at_world_8_sharing_one_gpu():
     J = json.loads(lines[0])
     assert J["n_gpus"] == 8 and J["steps"] == 2 and J["warmup"] == 1 and J["unit"] == "Mcell-updates/s" and J["value"] > 0
     assert J["scaling"] == "strong" and J["config"]["layout"] == "configs3" and J["config"]["parallelism"] == "cart2x4"
-    assert J["config"]["global_grid"] == "2048x2048" and J["config"]["global_cells"] == 2048 * 2048
+    assert J["config"]["global_grid"] == "1024x1024" and J["config"]["global_cells"] == 1024 * 1024
     comm = J["config"]["comm"]
     assert comm["shared_gpu"] is True and comm["cartesian"] == "2x4" and comm["peers_of_rank0"] == 2, comm
     second = J["second_layout"]

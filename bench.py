@@ -601,6 +601,27 @@ def main():
             if st["nranks"] != args.gpus:
                 raise SystemExit("bench.py: RCCL communicator has %d ranks, --gpus %d" % (st["nranks"], args.gpus))
 
+    # ---- N > 1: the three organisations of a reduction point, timed back to back on this layout (diagnostic: one run on N GPUs
+    # says which one the links favour; the headline above ran the default) ------------------------------------------------
+    organisations = None
+    if world > 1:
+        organisations = {}
+        for name, (dfr, spl) in (("deferred_unsplit (default with the in-library communicator)", (1, 0)),
+                                 ("allgather_and_scalar_kernel_per_reduction_point (round 4)", (0, 0)),
+                                 ("split_sweeps_halo_set_first (computeA's split; round-off differs)", (0, 1))):
+            try:
+                sim.set_nrank_organisation(dfr, spl)
+                run.one_step()
+                el_o, _ = run.timed_steps(max(2, min(args.steps, 5)), False)
+                form = sim.last_solver_form()
+                organisations[name] = {"ms_per_step": round(el_o / max(2, min(args.steps, 5)) * 1e3, 3), "solver_form": list(form)}
+            except Exception as e:  # informative
+                organisations[name] = {"error": str(e)[:200]}
+            beat("organisation")
+        sim.set_nrank_organisation(-1, -1)
+        if comm_info is not None:
+            comm_info["organisations"] = organisations
+
     # ---- the other layout (N > 1): same command, second timed region -------------------------------------------
     second = None
     beat("first layout")

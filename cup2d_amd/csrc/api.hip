@@ -931,6 +931,13 @@ int cup2d_set_solver(cup2d_ctx *c, int kind, int finish_in_kernel) {
   c->finish_in_kernel = finish_in_kernel != 0;
   return CUP2D_OK;
 }
+int cup2d_set_nrank_organisation(cup2d_ctx *c, int deferred, int split) {
+  CUP2D_CHECK_CTX(c);
+  if (deferred < -1 || deferred > 1 || split < -1 || split > 1) { set_error("set_nrank_organisation: -1 (default), 0 or 1"); return CUP2D_ERR_ARG; }
+  c->org_defer = deferred;
+  c->org_split = split;
+  return CUP2D_OK;
+}
 int cup2d_set_solver_form(cup2d_ctx *c, int form) {
   CUP2D_CHECK_CTX(c);
   if (form < CUP2D_FORM_AUTO || form > CUP2D_FORM_EAB) { set_error("set_solver_form: form %d", form); return CUP2D_ERR_ARG; }

@@ -179,6 +179,7 @@ struct cup2d_ctx {
   double *d_partials = nullptr;  // [NSLOT][grid]
   double *d_red = nullptr;       // [8] local sums handed to the allreduce callback
   cup2d::KrylovScalars *d_sc = nullptr;
+  int org_defer = -1, org_split = -1;  // cup2d_set_nrank_organisation: -1 = the process default (environment), 0 / 1
   void *vec_arena = nullptr;  // the eleven vectors of the two-launch solver are pieces of this one allocation (tune_placement), or null
   cup2d::KrylovScalars *d_sc2 = nullptr;  // N ranks, deferred scalar updates (krylov_fused.hip): the state alternates between d_sc and this
   cup2d::KrylovScalars *h_sc = nullptr;  // pinned

@@ -1213,7 +1213,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // 12 us: 23.3 ms per step against 21.9 in one launch with the exchange behind it, 14.1 against 13.5 on a 4096 x 2048
     // patch.  Off by default; what it would gain with a slower link than a copy on one GPU is what an N-GPU run has to show.
     static const bool split_on = [] { const char *e = getenv("CUP2D_SWEEP_SPLIT"); return e && atoi(e) != 0; }();
-    const bool split = split_on && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
+    const bool split = (c->org_split < 0 ? split_on : c->org_split != 0) && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
     const bool ghost_local = ghost_local_enabled() && merge == 2 && gb;  // r' and p'' of the ghost blocks formed here, nu'' travels (k_ghost_rp)
     // N ranks with the in-library communicator, "deferred" (the default there): per reduction point ONE pack launch and ONE RCCL
     // kernel -- the rank's reduction record travels to every rank inside the ncclGroup that carries the ghost blocks (no
@@ -1222,7 +1222,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // an iteration outside the sweeps).  The state alternates between two records (a launch reads one and writes the other).
     // The host learns of the end of the solve one launch later than before (C+D' of iteration k reports the state after
     // iteration k - 1).  Agreed over all ranks at cup2d_comm_init (comm_defer_ok); CUP2D_DEFER_SCALARS=0 keeps round 4's form.
-    const bool defer = merge == 2 && direct && ghost_local && !split && comm_defer_ok(c);
+    const bool defer = merge == 2 && direct && ghost_local && !split && comm_defer_ok(c) && c->org_defer != 0;
     KrylovScalars *S[2] = {c->d_sc, c->d_sc2};
     int sq = 0, enqueued = 0;
     if (defer) c->last_merge = 3;

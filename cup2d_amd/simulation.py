@@ -210,6 +210,10 @@ class Simulation(BodyOps):
         _l.check(self.L.cup2d_get_last_solver(self._ctx, ctypes.byref(k)), "get_last_solver")
         return "fused" if k.value == _l.SOLVER_FUSED else "sweeps"
 
+    def set_nrank_organisation(self, deferred=-1, split=-1):
+        """cup2d_set_nrank_organisation: how a reduction point of the N-rank solver is organised (-1 = the default)"""
+        _l.check(self.L.cup2d_set_nrank_organisation(self._ctx, int(deferred), int(split)), "set_nrank_organisation")
+
     def last_solver_form(self):
         """(form, merge, handover mask) of the last fused solve (cup2d_get_last_solver_form): form 'full' | 'edge' | 'eab'"""
         f, m, h = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

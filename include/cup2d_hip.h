@@ -189,6 +189,15 @@ int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
  *                    rho = rhat.r comes from the sums of C+D (rhat.s - omega rhat.t) instead of its own pass over r. */
 typedef enum { CUP2D_FORM_AUTO = 0, CUP2D_FORM_FULL = 1, CUP2D_FORM_EDGE = 2, CUP2D_FORM_EAB = 3 } cup2d_fused_form;
 int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
+/* N ranks, two launches per iteration: which organisation of a reduction point the next solves take (every rank must ask for
+ * the same one).  deferred: 1 the reduction records ride in the ghost blocks' send/recv group and the scalar update happens in
+ * the consumer sweep (in-library communicator with in-place ghost blocks on every rank, else ignored), 0 an all-gather and a
+ * one-wave scalar kernel per reduction point; split: 1 a sweep as halo-set-first + inner launches with the ghost blocks
+ * travelling in between (computeA's split, main.cpp:3035-3057), 0 one launch with the exchange behind it.  -1 = the process
+ * default (CUP2D_DEFER_SCALARS, CUP2D_SWEEP_SPLIT; deferred, unsplit).  deferred and unsplit are the same numbers bit for bit;
+ * split changes the order of the partial sums (round-off).  bench.py --gpus N times all three so that one N-GPU run says which
+ * one the links favour. */
+int cup2d_set_nrank_organisation(cup2d_ctx *ctx, int deferred, int split);
 /* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 /* what the last FUSED solve ran in detail (diagnostic, for tests that must know which organisation they pinned): form =

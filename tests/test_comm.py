@@ -304,6 +304,20 @@ for nbx, nby, axes in ((32, 16, "x"), (64, 64, "x"), (32, 32, "xy")) + (((512, 2
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "stats")
         form = list(s.last_solver_form())
+        # the same six iterations with the organisation chosen through the API (cup2d_set_nrank_organisation): round 4's reduction
+        # points, then the split sweeps -- the first the same bits, the second to round-off (other order of the partial sums)
+        for dfr, spl in ((0, 0), (0, 1)):
+            s.set_nrank_organisation(dfr, spl)
+            s.fill(L.PRES, 0.0)
+            ro = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=6)
+            s.last_iterate_to(L.POLD)
+            xo = s.pold
+            assert ro["iters"] == 6 and s.last_solver_form()[1] == 2, (dfr, spl, s.last_solver_form())
+            if spl == 0:
+                assert np.array_equal(xo, x), "organisation (0, 0) differs from the default"
+            else:
+                assert np.abs(xo - x).max() <= 1e-11 * np.abs(x).max(), float(np.abs(xo - x).max())
+        s.set_nrank_organisation(-1, -1)
         d5 = -1.0
         if axes == "xy":  # eight iterations of the two-launch MERGE 2 organisation against the five sweeps on the same periodic operator
             s.set_precond(L.PRECOND_MFMA)

@@ -387,7 +387,10 @@ int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const in
 
 /* ---------------------------------------------------------------- whole step ------------- */
 /* One pass of the body-free time-loop body main.cpp:6576-7187:
- * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL. */
+ * dt -> RK2 advect-diffuse -> Poisson rhs -> solve -> projection.  Outputs may be NULL.
+ * The projection is enqueued behind the solve's last pass before the host has seen the solve end (one host wait per step):
+ * when the step returns an error (a failed solve, a lost hand-over, a communicator error) VEL, PRES and the cached max|u|
+ * partials are UNDEFINED -- restore the fields (cup2d_upload) before the next call. */
 int cup2d_step(cup2d_ctx *ctx, double nu, double cfl, double max_error, double max_rel_error,
                int max_restarts, int max_iter, double *dt, int *iters, double *linf);
 

@@ -96,6 +96,7 @@ def parse_args():
     ap.add_argument("--cpu-functor-n", type=int, default=4096, help="grid of the reference-functor CPU baseline (the headline size)")
     ap.add_argument("--no-nrank-proxy", action="store_true", help="skip the N-rank-path leg (a self-periodic patch through RCCL on this GPU)")
     ap.add_argument("--no-north-star-floors", action="store_true", help="skip the timing-only builds of the north-star kernel")
+    ap.add_argument("--no-tolerance-leg", action="store_true", help="skip the tolerance-terminated steps (run.sh:13-14)")
     ap.add_argument("--no-second-size", action="store_true", help="skip the 2048^2 leg (BASELINE.json configs[1])")
     ap.add_argument("--no-amr", action="store_true", help="skip the block-AMR leg (BASELINE.json configs[4] shape, one GPU)")
     ap.add_argument("--amr-lfine", type=int, default=9, help="finest AMR level: 2^L blocks per side (9 = 4096^2-equivalent)")
@@ -826,7 +827,7 @@ def main():
 
     # the same workload with the solve ended by the reference's tolerances (what a run does after step 10)
     tol_leg = None
-    if world == 1 and dist is None:
+    if world == 1 and dist is None and not args.no_tolerance_leg:
         try:
             sim.set_timing(False)
             tol_leg = tolerance_leg(sim.step, sim.synchronize, 5)

@@ -8,7 +8,7 @@ TAG=${1:-r03}
 STEPS=3 bash tools/gpu_profile.sh $TAG
 bash tools/gpu_r02_sq.sh $TAG
 OUT=gpurun_out
-BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amr --no-nrank-proxy --no-kernel-timers --no-verify"
+BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amr --no-nrank-proxy --no-second-size --no-north-star-floors --no-tolerance-leg --no-kernel-timers --no-verify"
 rm -rf $OUT/tcc_$TAG $OUT/tcc2_$TAG
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc_$TAG -o pmc -- $BENCH > $OUT/tcc_$TAG.log 2>&1; echo "tcc rc=$?"
 timeout 300 rocprofv3 --pmc TCC_READ_sum TCC_WRITE_sum --output-format csv -d $OUT/tcc2_$TAG -o pmc -- $BENCH > $OUT/tcc2_$TAG.log 2>&1; echo "tcc2 rc=$?"

@@ -5,7 +5,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 TAG=${1:-r02}
-BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amr --no-nrank-proxy --no-kernel-timers --no-verify"
+BENCH="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-amr --no-nrank-proxy --no-second-size --no-north-star-floors --no-tolerance-leg --no-kernel-timers --no-verify"
 rm -rf $OUT/sq1_$TAG $OUT/sq2_$TAG
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1_$TAG -o pmc -- $BENCH > $OUT/sq1_$TAG.log 2>&1; echo "sq1 rc=$?"
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_MFMA --output-format csv -d $OUT/sq2_$TAG -o pmc -- $BENCH > $OUT/sq2_$TAG.log 2>&1; echo "sq2 rc=$?"

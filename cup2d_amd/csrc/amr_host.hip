@@ -217,6 +217,31 @@ extern "C" int cup2d_amr_trace_reads(int nblocks, const int32_t *kind, const int
   return CUP2D_OK;
 }
 
+// computeA's inner / halo split on an adapted grid (the lists behind CUP2D_BLOCKS_INNER / _HALO, amr.hip amr_phase_lists) as a
+// host routine that needs no context: reads_ghost[b] = 1 where the operators of family `set` (0: halo-1 operators, 1: the halo-3
+// tile of KernelAdvectDiffuse) of owned block b read a cell of a block >= nowned, else 0
+extern "C" int cup2d_amr_blocks_reading_ghosts(int nowned, int ntotal, const int32_t *kind, const int32_t *nbr2, const int32_t *half,
+                                               int set, int32_t *reads_ghost) {
+  if (nowned < 0 || ntotal < nowned || !kind || !nbr2 || !half || !reads_ghost || set < 0 || set > 1) {
+    cup2d::set_error("amr_blocks_reading_ghosts: bad argument");
+    return CUP2D_ERR_ARG;
+  }
+  for (int b = 0; b < ntotal; b++)
+    for (int e = 0; e < 8; e++) {
+      const int k = kind[4 * b + (e >> 1)], nb = nbr2[8 * b + e];
+      if (k < CUP2D_AMR_WALL || k > CUP2D_AMR_FINER || (k != CUP2D_AMR_WALL && (e & 1) == 0 && (nb < 0 || nb >= ntotal)) ||
+          (k == CUP2D_AMR_FINER && (nb < 0 || nb >= ntotal))) {
+        cup2d::set_error("amr_blocks_reading_ghosts: block %d side %d: kind %d neighbour %d", b, e >> 1, k, nb);
+        return CUP2D_ERR_ARG;
+      }
+    }
+  std::vector<int32_t> inner, halo;
+  cup2d::amr_blocks_reading_ghosts(nowned, ntotal, kind, nbr2, half, set, inner, halo);
+  for (int b : inner) reads_ghost[b] = 0;
+  for (int b : halo) reads_ghost[b] = 1;
+  return CUP2D_OK;
+}
+
 namespace cup2d {
 
 // Which owned blocks read a ghost block (id >= nowned) in the operators of family `set` (0: the 32 cross ghosts of the halo-1

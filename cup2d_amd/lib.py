@@ -22,7 +22,7 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 
 # every symbol include/cup2d_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "cup2d_amr_trace_reads", "cup2d_halo_plan_cells", "cup2d_comm_set_cell_counts",
+    "cup2d_amr_trace_reads", "cup2d_amr_blocks_reading_ghosts", "cup2d_halo_plan_cells", "cup2d_comm_set_cell_counts",
     "cup2d_create", "cup2d_destroy", "cup2d_last_error", "cup2d_version", "cup2d_set_stream", "cup2d_get_stream",
     "cup2d_synchronize", "cup2d_set_math", "cup2d_upload", "cup2d_download", "cup2d_upload_slab",
     "cup2d_download_slab", "cup2d_field_ptr", "cup2d_fill", "cup2d_copy_field", "cup2d_advect_diffuse_rhs",
@@ -147,6 +147,7 @@ def load_library():
     L.cup2d_set_comm.argtypes = [vp, EXCHANGE_FN, WAIT_FN, ALLREDUCE_FN, vp, vp, vp, vp]
     L.cup2d_set_comm_strip_capacity.argtypes = [vp, ctypes.c_int]
     L.cup2d_amr_trace_reads.argtypes = [i, vp, vp, vp, i, vp, i, vp]
+    L.cup2d_amr_blocks_reading_ghosts.argtypes = [i, i, vp, vp, vp, i, vp]
     L.cup2d_halo_plan_cells.argtypes = [vp, i, i, vp, i, vp]
     L.cup2d_comm_set_cell_counts.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.cup2d_amr_set_finest_level.argtypes = [vp, i]

@@ -381,6 +381,12 @@ int cup2d_amr_regrid_device(cup2d_ctx *dst, cup2d_ctx *src, int nblocks, const i
  * jobs == NULL: counts only.  Returns njobs. */
 long long cup2d_amr_regrid_jobs(int nblocks, const int32_t *blocks, int bpdx, int bpdy, int level_max, const int32_t *states,
                                 long long cap_jobs, int32_t *jobs, long long cap_prolong, int32_t *corners, long long *nprolong);
+/* N ranks, computeA's inner / halo split (main.cpp:3035-3057) on an adapted grid: which owned blocks [0, nowned) of tables that
+ * cover ntotal = owned + ghost blocks read a cell of a ghost block in the operators of family `set` (CUP2D_CELLS_HALO1 |
+ * CUP2D_CELLS_HALO3) -- by the kernels' own ghost expressions, as cup2d_amr_trace_reads.  reads_ghost[nowned] = 0 | 1.  These are
+ * the blocks CUP2D_BLOCKS_HALO sweeps (the others: CUP2D_BLOCKS_INNER).  Host routine, no context. */
+int cup2d_amr_blocks_reading_ghosts(int nowned, int ntotal, const int32_t *kind, const int32_t *nbr2, const int32_t *half, int set,
+                                    int32_t *reads_ghost);
 int cup2d_download_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, double *host);
 int cup2d_upload_blocks(cup2d_ctx *ctx, int field, int n, const int32_t *blocks, const double *host);
 int cup2d_copy_blocks(cup2d_ctx *ctx, cup2d_ctx *src, int field, int n, const int32_t *dst_blocks, const int32_t *src_blocks);

@@ -95,7 +95,15 @@ def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib, axes):
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(e), ctypes.byref(ar), ctypes.byref(ag)), "stats")
         st = dict(nranks=n.value, peers=p.value, exchanges=e.value)
         assert st == dict(nranks=1, peers=npeers, exchanges=3)
+        # a new halo plan under a live in-library communicator is refused (its offsets, cell counts and in-place receive targets
+        # were derived from the plan it was initialised on): finalize first
+        one = np.zeros(1, dtype=np.int32)
+        gid = np.asarray([g.nblocks], dtype=np.int32)
+        vp = ctypes.c_void_p
+        assert s.L.cup2d_halo_plan(s.ctx, 1, one.ctypes.data_as(vp), one.ctypes.data_as(vp), 1, gid.ctypes.data_as(vp), one.ctypes.data_as(vp)) == -1
+        assert b"cup2d_comm_finalize first" in s.L.cup2d_last_error()
         L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
+        L.check(s.L.cup2d_halo_plan(s.ctx, 1, one.ctypes.data_as(vp), one.ctypes.data_as(vp), 1, gid.ctypes.data_as(vp), one.ctypes.data_as(vp)), "halo_plan")
 
 
 @pytest.mark.gpu

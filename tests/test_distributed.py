@@ -129,6 +129,42 @@ def test_amr_partition_plans_are_consistent(nranks):
         assert cells * (2 if which == L.CELLS_HALO3 else 4) <= blocks, (which, cells, blocks)
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_amr_inner_and_halo_blocks_of_a_rank(nranks):
+    """computeA's inner / halo split on an adapted grid (cup2d_amr_blocks_reading_ghosts, the lists behind CUP2D_BLOCKS_INNER /
+    _HALO): a rank's owned blocks whose operators read a ghost block, by the kernels' own expressions.  The library skips the
+    trace for blocks further than three neighbour steps from every ghost block; here every owned block of every rank is traced
+    on its own (cup2d_amr_trace_reads with one reader) and must get the same verdict -- an inner block that read a ghost cell
+    would be swept before the cell has arrived.  Halo-1 operators and the halo-3 tile, the golden grid and a 1 000-block band."""
+    import ctypes
+    import numpy as np
+    from cup2d_amd import lib as L
+    from cup2d_amd.amr import AmrBlockGrid, circle_band_grid
+    from cup2d_amd.amr_dist import AmrPartition
+    lib = L.load_library()
+    vp = ctypes.c_void_p
+    for G in (AmrBlockGrid(np.load(os.path.join(ROOT, "tests", "golden", "amr_functors.npz"))["blocks"]), circle_band_grid(6)):
+        for rank in range(nranks):
+            P = AmrPartition(G, nranks, rank)
+            nt = P.nowned + P.nghost
+            k, n2, h = (np.ascontiguousarray(a, dtype=np.int32) for a in (P.kind, P.nbr2, P.half))
+            for which in (L.CELLS_HALO1, L.CELLS_HALO3):
+                got = np.full(P.nowned, -1, dtype=np.int32)
+                L.check(lib.cup2d_amr_blocks_reading_ghosts(P.nowned, nt, k.ctypes.data_as(vp), n2.ctypes.data_as(vp), h.ctypes.data_as(vp), which,
+                                                            got.ctypes.data_as(vp)), "blocks_reading_ghosts")
+                want = np.zeros(P.nowned, dtype=np.int32)
+                for b in range(P.nowned):
+                    mask = np.zeros(nt, dtype=np.uint64)
+                    rd = np.asarray([b], dtype=np.int32)
+                    L.check(lib.cup2d_amr_trace_reads(nt, k.ctypes.data_as(vp), n2.ctypes.data_as(vp), h.ctypes.data_as(vp), 1, rd.ctypes.data_as(vp),
+                                                      which, mask.ctypes.data_as(vp)), "trace")
+                    want[b] = int(mask[P.nowned:].any())
+                assert np.array_equal(got, want), (G.nblocks, nranks, rank, which, np.flatnonzero(got != want)[:10])
+                if nranks > 1 and P.nghost:
+                    assert want.any() and (G.nblocks < 200 or not want.all()), (rank, which, int(want.sum()), P.nowned)
+    assert lib.cup2d_amr_blocks_reading_ghosts(1, 0, None, None, None, 0, None) == -1
+
+
 def test_amr_trace_reads_on_small_grids():
     """cup2d_amr_trace_reads (the kernels' own ghost expressions with a recording accessor) on grids small enough to count by
     hand: two same-level blocks; one coarse block next to four fine ones"""

@@ -32,6 +32,7 @@ def test_comm_argument_checks_without_a_gpu():
     assert lib.cup2d_halo_exchange(None, L.VEL, 3) == -1
     assert lib.cup2d_comm_stats(None, None, None, None, None, None) == -1
     assert lib.cup2d_halo_plan_cells(None, 0, 0, None, 0, None) == -1 and lib.cup2d_comm_set_cell_counts(None, 0, 0, None, None, None, None) == -1
+    assert lib.cup2d_set_nrank_organisation(None, 1, 0) == -1 and b"null context" in lib.cup2d_last_error()
     # the trace of the kernels' ghost reads is host code: bad tables, sets and readers are refused
     import numpy as np
     k, n2, h = np.zeros((2, 4), dtype=np.int32), -np.ones((2, 4, 2), dtype=np.int32), np.zeros((2, 4), dtype=np.int32)

@@ -23,13 +23,13 @@
 namespace cup2d {
 
 // Three implementations of the block-Jacobi preconditioner z_b = P_inv p_b, selectable with
-// CUP2D_PRECOND for A/B timing (all three apply the same operator; they differ by round-off only):
+// cup2d_set_precond (all three apply the same operator; they differ by round-off only):
 //   fd   (default) fast diagonalisation: A_loc = T (x) I + I (x) T with T = tridiag(-1,2,-1) = Q diag(lam) Q^T,
 //                  so P_inv = -(Q (x) Q) diag(1/(lam_i+lam_j)) (Q (x) Q)^T: four 8x8x8 products per block
 //                  (32 FMAs per cell instead of 64), one wave per block, coalesced loads
 //   mfma           dense 64x64 product on v_mfma_f64_16x16x4_f64 (precond_mfma.h), 16 blocks per wave
 //   lds            dense product with P_inv in LDS and scalar FMAs (the first version)
-// (enum PRECOND_* in ctx.h; the context's default comes from CUP2D_PRECOND, cup2d_set_precond overrides it)
+// (enum PRECOND_* in ctx.h; cup2d_set_precond selects)
 static bool use_mfma(const cup2d_ctx *c) { return c->precond == PRECOND_MFMA; }
 // grid of the MFMA sweeps: 2 workgroups (8 waves) per CU; every wave keeps P_inv in 128 VGPRs
 static int mfma_grid(const cup2d_ctx *c, int count) {

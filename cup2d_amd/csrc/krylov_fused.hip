@@ -1175,7 +1175,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
   // the system-scope store of the status word cost the stream 6 us of idle time between sweep E and the next AB
   // (tools/kernel_gaps.py), per iteration in round 2.  The last sweep E of a group reports (also when the
   // solve ended earlier in the group and its kernels returned at once); the host stays at most AHEAD groups in front, so at
-  // most AHEAD * GROUP iterations of early-returning kernels are wasted behind a solve that has ended.  CUP2D_SOLVE_GROUP.
+  // most AHEAD * GROUP iterations of early-returning kernels are wasted behind a solve that has ended.
   constexpr int GROUP_ENV = 4;
   // merge 2 (N ranks): the status word is written by the one-wave kernel behind the last all-gather of an iteration
   // (comm.hip k_gather_scalars; callbacks: k_scalars), which reports for a finished solve as well -- same grouping.  Every

@@ -12,7 +12,7 @@
 // for (1) a kernel writes the seven integrands of every cell of the body's blocks and a one-wave kernel adds them up in the
 // reference's order (block by block, row by row, one serial chain per integral: k_body_sums) -- a few hundred blocks per
 // body, and the sums, the 3 x 3 LU solve and therefore u, v, omega are bit-identical to the reference's single-threaded
-// loop; seven doubles per body cross PCIe (round 2 downloaded every integrand and summed on the host: CUP2D_BODY_SUM=host).  No FMA contraction in this translation unit (-ffp-contract=off): every expression below keeps
+// loop; seven doubles per body cross PCIe (round 2 downloaded every integrand and summed on the host).  No FMA contraction in this translation unit (-ffp-contract=off): every expression below keeps
 // the reference's operation order.
 #include <math.h>
 #include <stdlib.h>

@@ -173,8 +173,7 @@ int cup2d_set_precond(cup2d_ctx *ctx, int kind);
  *                       assembled operator in its hybrid form -- elsewhere SWEEPS is used.
  * finish_in_kernel != 0: the last workgroup of a reducing sweep finishes the reduction and updates the device
  * scalars instead of a separate single-workgroup launch (ignored when an all-reduce callback is installed).
- * Defaults: FUSED where it applies, finish in the kernel; CUP2D_SOLVER (sweeps|fused) and
- * CUP2D_FINISH_IN_KERNEL (0|1) override them at cup2d_create. */
+ * Defaults: FUSED where it applies, finish in the kernel. */
 typedef enum { CUP2D_SOLVER_SWEEPS = 0, CUP2D_SOLVER_FUSED = 1 } cup2d_solver_kind;
 int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
 /* Form of the FUSED organisation (same recurrences; they differ by round-off and in bytes per iteration):

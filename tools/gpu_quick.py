@@ -13,7 +13,7 @@ import cup2d_amd  # noqa: E402
 from cup2d_amd import lib as L  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-kind = os.environ.get("CUP2D_PRECOND", "default")
+kind = os.environ.get("PRECOND", "default")  # (applied below through cup2d_set_precond)
 ok = True
 
 

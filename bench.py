@@ -373,7 +373,8 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
     # four sides next to a plain context of that size
     out = nrank_proxy_patch(args, device, nbx, nby, "xy", plain, with_tolerance_leg=True)
     out["what"] = ("the N-rank code path of the step on one GPU: a patch that is its own W, E, S and N neighbour (ghost blocks on "
-                   "all four sides, four send/recv pairs per ncclGroup to self, all-gather reductions, MERGE 2 kernels)")
+                   "all four sides, four send/recv pairs per ncclGroup to self with the reduction records riding in the group, the scalar "
+                   "update in the consumer sweeps: k_edge MERGE 3)")
     out["timeline"] = "profiles/r05_nrank_timeline.txt"
     others = []
     for (bx, by, axes, pl) in ((nbx, nby, "x", plain), (nbx, max(1, nby // 2), "xy", None)):

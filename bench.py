@@ -610,7 +610,8 @@ def main():
         organisations = {}
         for name, (dfr, spl) in (("deferred_unsplit (default with the in-library communicator)", (1, 0)),
                                  ("allgather_and_scalar_kernel_per_reduction_point (round 4)", (0, 0)),
-                                 ("split_sweeps_halo_set_first (computeA's split; round-off differs)", (0, 1))):
+                                 ("split_sweeps_halo_set_first (computeA's split; round-off differs)", (0, 1)),
+                                 ("overlap: split sweeps + deferred update, block transfer behind the inner launch", (1, 1))):
             try:
                 sim.set_nrank_organisation(dfr, spl)
                 run.one_step()

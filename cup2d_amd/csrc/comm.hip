@@ -341,6 +341,14 @@ int comm_reduce_scalars(cup2d_ctx *c, int nsum, int with_max, int stage, int *ho
   return 0;
 }
 
+// this rank's record (d_red) to slot `rank` of every rank's gathered records: one all-gather on the compute stream, no kernel
+// behind it (the consumer sweep sums the records in its prologue)
+int comm_gather_records(cup2d_ctx *c) {
+  RcclComm *rc = c->rccl;
+  rc->n_allgather++;
+  CUP2D_NCCL(rc, rc->api->AllGather(c->d_red, rc->d_gather, RED_REC, ncclDouble, rc->red, c->stream));
+  return 0;
+}
 int comm_apply_gathered(cup2d_ctx *c, int nsum, int with_max, int stage) {
   RcclComm *rc = c->rccl;
   hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, c->stream, rc->d_gather, rc->nranks, nsum, with_max, c->d_red, c->d_sc,

@@ -434,6 +434,7 @@ int comm_nranks(const cup2d_ctx *c);
 bool comm_defer_ok(const cup2d_ctx *c);           // agreed over all ranks at cup2d_comm_init
 // the standalone form of what a MERGE 3 sweep does with the gathered records (the last pending stage of a solve)
 int comm_apply_gathered(cup2d_ctx *c, int nsum, int with_max, int stage);
+int comm_gather_records(cup2d_ctx *c);  // d_red of every rank -> the gathered records (one all-gather, compute stream)
 int comm_blocks_wait(cup2d_ctx *c);
 int exchange_begin_blocks3(cup2d_ctx *c, const double *v0, const double *v1, const double *v2);
 int exchange_end_blocks3(cup2d_ctx *c, double *v0, double *v1, double *v2);

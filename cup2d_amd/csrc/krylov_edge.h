@@ -144,8 +144,12 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   // one-wave kernel behind an all-gather did, comm.hip k_gather_scalars: two launches per reduction point fewer).  The state
   // is read from sc and written -- by one thread of the launch -- to A.sc_out, ANOTHER record: nobody of this launch reads what
   // it writes.  A launch behind a finished solve hands the state on and returns.
+  // MERGE 4: the same prologue on a launch that finishes nothing (the halo-set launch of a split sweep: the inner launch
+  // behind it -- MERGE 3 with no stage pending and no sc_out -- sums the partials of both)
+  constexpr bool PRO = MERGE >= 3;            // deferred scalar update in the prologue
+  constexpr int FIN = MERGE == 4 ? 0 : MERGE; // what the epilogue does: 0 partials only, 1 finish + scalars, 2 / 3 this rank's sums
   KrylovScalars ST;
-  if constexpr (MERGE == 3) {
+  if constexpr (PRO) {
     ST = *sc;
     if (ST.status == 0 && A.pstage >= 0) {
       double v[RED_REC];
@@ -153,14 +157,14 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       scalars_update(&ST, v, A.pstage);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      *A.sc_out = ST;
+      if (A.sc_out) *A.sc_out = ST;
       if (A.host_status) __hip_atomic_store(A.host_status, ST.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     sc = &ST;
   }
   if (sc->status != 0) {
     // (as k_sweepE_y: the last launch of a group of iterations reports to the host, also behind a solve that has ended)
-    if (MERGE != 3 && EAB && A.host_status && blockIdx.x == 0 && threadIdx.x == 0)
+    if (!PRO && EAB && A.host_status && blockIdx.x == 0 && threadIdx.x == 0)
       __hip_atomic_store(A.host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
@@ -563,9 +567,9 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   }
   // this wave publishes nothing more: nobody may wait for it
   if (lane == 0) __hip_atomic_store(pub + wave, 1 << 30, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  fused_reduce_store<FWAVES, NDOT, MERGE != 0>(acc, partials + poff);
-  if constexpr (EAB) fused_reduce_store_max<FWAVES, MERGE != 0>(rmax[0], partials + 2 * PSTRIDE + poff);
-  if (MERGE && arrive_last(ticket)) {  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
+  fused_reduce_store<FWAVES, NDOT, FIN != 0>(acc, partials + poff);
+  if constexpr (EAB) fused_reduce_store_max<FWAVES, FIN != 0>(rmax[0], partials + 2 * PSTRIDE + poff);
+  if (FIN && arrive_last(ticket)) {  // (arrive_last's barrier: every wave of this workgroup is done with the dynamic LDS)
     // MERGE 1: the scalar update too; MERGE 2 (N ranks): this rank's sums into red, the reduction over the ranks and the
     // scalar kernel follow on the stream
     if constexpr (EAB) {

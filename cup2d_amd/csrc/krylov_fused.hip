@@ -848,9 +848,11 @@ static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int
   };
   if (merge == 1) go(k_edge<MODE, 1>);
   else if (merge == 2) go(k_edge<MODE, 2>);
-  else if (merge == 3) {  // N ranks, deferred scalar update: MODE 2 / 3 only (the A+B of iteration 0 keeps the scalar kernel behind it)
-    if constexpr (MODE >= 2) go(k_edge<MODE, 3>);
-    else { set_error("eab_sweep: MERGE 3 is for MODE 2 / 3"); return CUP2D_ERR_ARG; }
+  else if (merge == 3 || merge == 4) {  // N ranks, deferred scalar update: MODE 2 / 3 only (the A+B of iteration 0 keeps the scalar kernel behind it)
+    if constexpr (MODE >= 2) {
+      if (merge == 3) go(k_edge<MODE, 3>);
+      else go(k_edge<MODE, 4>);
+    } else { set_error("eab_sweep: MERGE 3 / 4 are for MODE 2 / 3"); return CUP2D_ERR_ARG; }
   } else go(k_edge<MODE, 0>);
   CUP2D_HIP_CHECK(hipGetLastError());
   if (G) *G = g;
@@ -1134,7 +1136,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_edge<2, 1>), reinterpret_cast<const void *>(&k_edge<3, 1>),
                         reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>),
                         reinterpret_cast<const void *>(&k_edge<2, 0>), reinterpret_cast<const void *>(&k_edge<3, 0>),
-                        reinterpret_cast<const void *>(&k_edge<2, 3>), reinterpret_cast<const void *>(&k_edge<3, 3>)};
+                        reinterpret_cast<const void *>(&k_edge<2, 3>), reinterpret_cast<const void *>(&k_edge<3, 3>),
+                        reinterpret_cast<const void *>(&k_edge<2, 4>), reinterpret_cast<const void *>(&k_edge<3, 4>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1222,10 +1225,17 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // an iteration outside the sweeps).  The state alternates between two records (a launch reads one and writes the other).
     // The host learns of the end of the solve one launch later than before (C+D' of iteration k reports the state after
     // iteration k - 1).  Agreed over all ranks at cup2d_comm_init (comm_defer_ok); CUP2D_DEFER_SCALARS=0 keeps round 4's form.
-    const bool defer = merge == 2 && direct && ghost_local && !split && comm_defer_ok(c) && c->org_defer != 0;
+    const bool defer_any = merge == 2 && direct && ghost_local && comm_defer_ok(c) && c->org_defer != 0;
+    const bool defer = defer_any && !split;
+    // ... and with SPLIT sweeps ("overlap": cup2d_set_nrank_organisation(ctx, 1, 1)): the halo-set launch of the consumer sweep
+    // runs the pending update in its prologue (MERGE 4: it finishes nothing), its ghost blocks travel on the communication
+    // stream while the inner launch runs (MERGE 3 with nothing pending: it sums the partials of both launches), and the records
+    // go round in ONE all-gather behind it -- per reduction point one small collective is exposed, the block transfer is not
+    const bool overlap = defer_any && split;
     KrylovScalars *S[2] = {c->d_sc, c->d_sc2};
     int sq = 0, enqueued = 0;
     if (defer) c->last_merge = 3;
+    if (overlap) c->last_merge = 4;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       c->prof_sample = true;
@@ -1251,6 +1261,41 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       c->prof_sample = (k % 8 == 0) && k < max_iter;
       const int o = k & 1, n = o ^ 1;
       enqueued = k + 1;
+      if (overlap) {
+        const int nh = nb - c->n_inner;
+        int gh = 0;
+        {  // C+D': halo set (pending: stage 4 of the previous iteration), t of the ghost blocks on its way, inner blocks, records
+          FusedArgs a = {};
+          a.in0 = R[o]; a.in1 = N[o]; a.w = c->d_rhat; a.yout = c->d_t; a.rev = zigzag;
+          a.pg = comm_gathered(c); a.pn = comm_nranks(c); a.pstage = k == 0 ? -1 : 4; a.pnsum = 2; a.pmax = 1;
+          a.sc_out = S[sq ^ 1];
+          a.host_status = last_of_group ? &c->h_status[slot] : nullptr;
+          { ProfScope prof(c, CUP2D_T_SWEEP_C); CUP2D_TRY(eab_sweep<3>(c, a, 4, c->n_inner, nh, 0, &gh, S[sq])); }
+          sq ^= 1;
+          CUP2D_TRY(comm_exchange_blocks(c, 1, c->d_t, nullptr, nullptr, true));
+          a.pstage = -1; a.sc_out = nullptr; a.host_status = nullptr;
+          { ProfScope prof(c, CUP2D_T_SWEEP_C); CUP2D_TRY(eab_sweep<3>(c, a, 3, 0, c->n_inner, gh, nullptr, S[sq])); }
+          if (comm_gather_records(c) != 0) return CUP2D_ERR_COMM;
+          CUP2D_TRY(comm_blocks_wait(c));
+        }
+        {  // E+A+B: halo set (pending: stage 5), nu'' of the ghost blocks on its way (r', p'' of them formed here), inner blocks
+          FusedArgs a = {};
+          a.in0 = P[o]; a.in1 = N[o]; a.in2 = R[o]; a.w = c->d_rhat; a.vout = P[n]; a.yout = N[n];
+          a.t = c->d_t; a.y0 = c->d_y; a.y1 = c->d_yopt; a.y2 = c->d_xopt; a.rout = R[n];
+          a.pg = comm_gathered(c); a.pn = comm_nranks(c); a.pstage = 5; a.pnsum = 5; a.pmax = 0;
+          a.sc_out = S[sq ^ 1];
+          { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 4, c->n_inner, nh, 0, &gh, S[sq])); }
+          sq ^= 1;
+          const GhostRP G = {P[o], N[o], R[o], c->d_t, R[n], P[n], S[sq], (size_t)nb * BC, (size_t)c->nghost * BC};
+          CUP2D_TRY(comm_exchange_blocks(c, 1, N[n], nullptr, nullptr, true, &G));
+          a.pstage = -1; a.sc_out = nullptr;
+          { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 3, 0, c->n_inner, gh, nullptr, S[sq])); }
+          if (comm_gather_records(c) != 0) return CUP2D_ERR_COMM;
+          CUP2D_TRY(comm_blocks_wait(c));
+        }
+        if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
+        continue;
+      }
       if (defer) {
         {
           FusedArgs a = {};
@@ -1351,7 +1396,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       }
       if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
     }
-    if (defer && enqueued > 0) {
+    if ((defer || overlap) && enqueued > 0) {
       // the last pending update (stage 4 of the last iteration enqueued; a no-op behind a solve that has ended) in a launch of its
       // own, on the context's first record: what follows (the last pass over x, the host's copy of the scalars) reads it there
       if (sq == 1) CUP2D_HIP_CHECK(hipMemcpyAsync(c->d_sc, c->d_sc2, sizeof(KrylovScalars), hipMemcpyDeviceToDevice, c->stream));

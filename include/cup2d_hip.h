@@ -193,9 +193,12 @@ int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
  * the consumer sweep (in-library communicator with in-place ghost blocks on every rank, else ignored), 0 an all-gather and a
  * one-wave scalar kernel per reduction point; split: 1 a sweep as halo-set-first + inner launches with the ghost blocks
  * travelling in between (computeA's split, main.cpp:3035-3057), 0 one launch with the exchange behind it.  -1 = the process
- * default (CUP2D_DEFER_SCALARS, CUP2D_SWEEP_SPLIT; deferred, unsplit).  deferred and unsplit are the same numbers bit for bit;
- * split changes the order of the partial sums (round-off).  bench.py --gpus N times all three so that one N-GPU run says which
- * one the links favour. */
+ * default (CUP2D_DEFER_SCALARS, CUP2D_SWEEP_SPLIT; deferred, unsplit).  (1, 1) = "overlap": split sweeps whose halo-set launch
+ * runs the pending scalar update in its prologue; the ghost blocks travel on the communication stream while the inner launch
+ * runs and the records go round in one all-gather behind it.  With the same `split` the deferred and the undeferred forms are
+ * the same numbers bit for bit; split changes the order of the partial sums (round-off).  bench.py --gpus N times all four so
+ * that one N-GPU run says which one the links favour.  cup2d_get_last_solver_form reports merge = 2 (undeferred), 3 (deferred,
+ * unsplit) or 4 (overlap). */
 int cup2d_set_nrank_organisation(cup2d_ctx *ctx, int deferred, int split);
 /* the organisation the last cup2d_poisson_solve actually ran (FUSED falls back to SWEEPS where it does not apply) */
 int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);

@@ -29,8 +29,8 @@ def test_bench_line_at_world_8_sharing_one_gpu():
     assert J["config"]["global_grid"] == "1024x1024" and J["config"]["global_cells"] == 1024 * 1024
     comm = J["config"]["comm"]
     assert comm["shared_gpu"] is True and comm["cartesian"] == "2x4" and comm["peers_of_rank0"] == 2, comm
-    org = comm["organisations"]   # the three organisations of a reduction point timed back to back (over callbacks: MERGE 2 in all)
-    assert len(org) == 3 and all("error" not in v and v["ms_per_step"] > 0 and v["solver_form"][0] == "eab" for v in org.values()), org
+    org = comm["organisations"]   # the four organisations of a reduction point timed back to back (over callbacks: MERGE 2 in all)
+    assert len(org) == 4 and all("error" not in v and v["ms_per_step"] > 0 and v["solver_form"][0] == "eab" for v in org.values()), org
     second = J["second_layout"]
     assert second["layout"] == "weak" and second["scaling"] == "weak" and "error" not in second, second
     assert second["cells_per_rank"] == "256x256" and second["global_cells"] == 8 * 256 * 256 and second["value"] > 0

@@ -313,19 +313,32 @@ for nbx, nby, axes in ((32, 16, "x"), (64, 64, "x"), (32, 32, "xy")) + (((512, 2
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "stats")
         form = list(s.last_solver_form())
+        out_form_overlap = None
         # the same six iterations with the organisation chosen through the API (cup2d_set_nrank_organisation): round 4's reduction
         # points, then the split sweeps -- the first the same bits, the second to round-off (other order of the partial sums)
-        for dfr, spl in ((0, 0), (0, 1)):
+        split_x = None
+        for dfr, spl in ((0, 0), (0, 1), (1, 1)):
             s.set_nrank_organisation(dfr, spl)
             s.fill(L.PRES, 0.0)
             ro = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=6)
             s.last_iterate_to(L.POLD)
             xo = s.pold
-            assert ro["iters"] == 6 and s.last_solver_form()[1] == 2, (dfr, spl, s.last_solver_form())
+            fo = s.last_solver_form()
+            assert ro["iters"] == 6 and fo[0] == "eab" and fo[1] in (2, 3, 4), (dfr, spl, fo)
             if spl == 0:
                 assert np.array_equal(xo, x), "organisation (0, 0) differs from the default"
             else:
                 assert np.abs(xo - x).max() <= 1e-11 * np.abs(x).max(), float(np.abs(xo - x).max())
+                # "overlap" (split sweeps + deferred update, merge 4 where the communicator allows it) = the split sweeps of round 4
+                if split_x is not None:
+                    assert np.array_equal(xo, split_x), "organisation (1, 1) differs from (0, 1)"
+                    out_form_overlap = list(fo)
+                split_x = xo
+            # a converged solve under this organisation as well (the end of the solve is learnt a launch later when deferred)
+            s.fill(L.PRES, 0.0)
+            rc_ = s.poisson_solve(tol=1e-8, max_restarts=100, max_iter=cap)
+            assert rc_["iters"] == conv["iters"] or spl == 1, (dfr, spl, rc_, conv)
+            assert rc_["err"] <= 1e-8 or rc_["iters"] >= cap, (dfr, spl, rc_)
         s.set_nrank_organisation(-1, -1)
         d5 = -1.0
         if axes == "xy":  # eight iterations of the two-launch MERGE 2 organisation against the five sweeps on the same periodic operator
@@ -342,7 +355,7 @@ for nbx, nby, axes in ((32, 16, "x"), (64, 64, "x"), (32, 32, "xy")) + (((512, 2
             assert abs(xs[0][1] - xs[1][1]) <= 1e-9 * xs[1][1], (xs[0][1], xs[1][1])
             s.set_precond(L.PRECOND_FD)
         out["%%dx%%d%%s" %% (nbx, nby, axes)] = dict(sum=float(np.abs(x).sum()), hash=int(np.frombuffer(x.tobytes(), dtype=np.uint64).sum() %% (1 << 62)),
-                                        iters=r["iters"], err=e, conv_err=conv["err"], conv_iters=conv["iters"], cap=cap, form=form, exchanges=ex.value, vs_five_sweeps=d5)
+                                        iters=r["iters"], err=e, conv_err=conv["err"], conv_iters=conv["iters"], cap=cap, form=form, form_overlap=out_form_overlap, exchanges=ex.value, vs_five_sweeps=d5)
         L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
 print("RESULT " + json.dumps(out))
 '''
@@ -383,6 +396,12 @@ def test_ghost_blocks_received_in_place_equal_the_generic_exchange(gpu_lib):
             # the organisation that ran: two launches per iteration; MERGE 3 (deferred scalar updates) only in the default
             assert a["form"] == ["eab", 3, a["form"][2]] and b["form"] == ["eab", 3 if key == ("1", "1", "1") else 2, a["form"][2]], (key, a, b)
             assert a["iters"] == b["iters"] == 6, (key, a, b)
+            # (1, 1) through the API is the overlap organisation (merge 4) where the transport allows the deferred update and
+            # the patch splits (halo set a whole number of tiles), else round 4's split sweeps (merge 2)
+            # (a patch whose halo set is not a whole number of tiles does not split: the deferred unsplit form, merge 3)
+            assert b["form_overlap"][1] in ((2, 3, 4) if key == ("1", "1", "1") else (2,)), (key, k, b["form_overlap"])
+            if key == ("1", "1", "1") and k.startswith("512x256"):
+                assert b["form_overlap"][1] == 4, (k, b["form_overlap"])   # configs[3]'s rank size does run the overlap organisation
             assert a["hash"] == b["hash"] and a["sum"] == b["sum"] and a["err"] == b["err"], (key, k, a, b)
             assert a["conv_iters"] == b["conv_iters"] and a["conv_err"] == b["conv_err"], (key, a, b)
             assert a["conv_err"] <= 1e-8 or a["conv_iters"] >= a["cap"], (key, a)

@@ -50,6 +50,8 @@ s, g = _self_periodic_sim(nbx, nby, os.environ.get("AXES", "xy"))  # "xy": ghost
 with s:
     s.nu = 1e-3
     print("self-periodic patch: %d blocks, %d ghost blocks, halo set of %d x %d-block patches, n_inner %d" % (g.nblocks, g.nghost, g.halo_tile, g.halo_tile, g.n_inner))
-    t_self = run(s, "self-periodic (RCCL)")
+    if os.environ.get("ORG"):  # cup2d_set_nrank_organisation: "deferred,split", e.g. ORG=1,1 = the overlap organisation
+        s.set_nrank_organisation(*[int(v) for v in os.environ["ORG"].split(",")])
+    t_self = run(s, "self-periodic (RCCL)%s" % (" ORG=" + os.environ["ORG"] if os.environ.get("ORG") else ""))
     L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
 print("N-rank path / plain = %.3f" % (t_self / t_plain))

@@ -335,10 +335,11 @@ for nbx, nby, axes in ((32, 16, "x"), (64, 64, "x"), (32, 32, "xy")) + (((512, 2
                     out_form_overlap = list(fo)
                 split_x = xo
             # a converged solve under this organisation as well (the end of the solve is learnt a launch later when deferred)
-            s.fill(L.PRES, 0.0)
-            rc_ = s.poisson_solve(tol=1e-8, max_restarts=100, max_iter=cap)
-            assert rc_["iters"] == conv["iters"] or spl == 1, (dfr, spl, rc_, conv)
-            assert rc_["err"] <= 1e-8 or rc_["iters"] >= cap, (dfr, spl, rc_)
+            if nbx * nby <= 1024:
+                s.fill(L.PRES, 0.0)
+                rc_ = s.poisson_solve(tol=1e-8, max_restarts=100, max_iter=cap)
+                assert rc_["iters"] == conv["iters"] or spl == 1, (dfr, spl, rc_, conv)
+                assert rc_["err"] <= 1e-8 or rc_["iters"] >= cap, (dfr, spl, rc_)
         s.set_nrank_organisation(-1, -1)
         d5 = -1.0
         if axes == "xy":  # eight iterations of the two-launch MERGE 2 organisation against the five sweeps on the same periodic operator

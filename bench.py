@@ -521,9 +521,10 @@ def main():
         run.one_step()
 
     # Timed region: EXACTLY --steps steps.  Per-kernel HIP-event pairs are recorded on the launch stream
-    # inside it in SAMPLED mode (every launch outside the solver, every 8th BiCGSTAB iteration: a pair costs
-    # ~4 us of stream time, so full instrumentation would cost 10 % of the step); the roofline objects are
-    # computed from those samples.  The same K steps are repeated afterwards without any events and
+    # inside it in SAMPLED mode (every 16th BiCGSTAB iteration; the launches outside the solver in every 4th step: an event
+    # pair is a barrier packet that keeps the kernels on either side of it from overlapping, ~12 us per pair -- round 5 measured
+    # 18.17 against 17.90 ms per step with twice the samples); the roofline objects are computed from those samples and, where a
+    # short --steps leaves fewer than MIN_ROOFLINE_LAUNCHES of them, from more steps sampled the same way outside the timed region.  The same K steps are repeated afterwards without any events and
     # reported as ms_per_step_no_kernel_timers.
     # N ranks: the timed region runs WITHOUT per-kernel events (resolving the event pool drains the stream, and with the
     # scalar/communication launches of the N-rank organisation that costs the pipelined solve far more than the 1 % it

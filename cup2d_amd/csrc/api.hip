@@ -1274,6 +1274,10 @@ int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max
                int max_iter, double *dt_out, int *iters, double *linf) {
   CUP2D_CHECK_CTX(c);
   CUP2D_TRY(amr_operator_ready(c, "step"));
+  if (c->timing == 2) {  // sampled timing: the launches outside the solver in every 4th step (ctx.h prof_outer)
+    c->prof_outer = (c->prof_step++ % 4) == 0;
+    c->prof_sample = c->prof_outer;
+  }
   // the previous call on this context was a cup2d_step that left max|u| of its result behind (ctx.h)
   c->use_cached_umax = !c->amr.active && !c->vel_ptr_exposed && c->umax_partials > 0 && c->api_calls == c->umax_valid_at + 1;
   double dt = 0;
@@ -1439,6 +1443,8 @@ int cup2d_set_timing(cup2d_ctx *c, int enabled) {
   c->prof_used = 0;
   c->timing = enabled == 2 ? 2 : (enabled ? 1 : 0);
   c->prof_sample = true;
+  c->prof_outer = true;
+  c->prof_step = 0;
   for (int i = 0; i < CUP2D_T_NTIMERS; i++) { c->t_ms[i] = 0; c->t_calls[i] = 0; }
   return CUP2D_OK;
 }

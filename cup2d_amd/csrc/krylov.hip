@@ -880,7 +880,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
       CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
       if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
-    c->prof_sample = (k % 8 == 0) && k < max_iter;  // sampled timing: an event pair costs ~4 us of stream time
+    c->prof_sample = (k % 16 == 0) && k < max_iter;  // sampled timing (ctx.h prof_outer)
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       if (c->precond == PRECOND_FD)
@@ -946,7 +946,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
     if (!merge) CUP2D_TRY(finish(c, gridE, 2, 1, 3, true, &c->h_status[slot]));
     CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
-  c->prof_sample = true;
+  c->prof_sample = c->prof_outer;
   CUP2D_HIP_CHECK(hipMemcpyAsync(c->h_sc, c->d_sc, sizeof init, hipMemcpyDeviceToHost, c->stream));
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->have_last = false;

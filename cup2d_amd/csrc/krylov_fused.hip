@@ -1238,7 +1238,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (overlap) c->last_merge = 4;
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
-      c->prof_sample = true;
+      c->prof_sample = c->prof_outer;
       FusedArgs a = {};
       a.in0 = c->d_p; a.in1 = c->d_nu; a.in2 = c->d_r; a.w = c->d_rhat; a.vout = P[0]; a.yout = N[0];
       CUP2D_TRY(eab_sweep<0>(c, a, merge));
@@ -1258,7 +1258,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
         if (*(volatile int *)&c->h_status[slot] != 0) break;
       }
-      c->prof_sample = (k % 8 == 0) && k < max_iter;
+      c->prof_sample = (k % 16 == 0) && k < max_iter;
       const int o = k & 1, n = o ^ 1;
       enqueued = k + 1;
       if (overlap) {
@@ -1412,7 +1412,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
     int *const report = last_of_group ? &c->h_status[slot] : nullptr;
-    c->prof_sample = (k % 8 == 0) && k < max_iter;
+    c->prof_sample = (k % 16 == 0) && k < max_iter;
     double *p_in = (k & 1) ? c->d_p2 : c->d_p, *p_out = (k & 1) ? c->d_p : c->d_p2;
     double *nu_in = (k & 1) ? c->d_nu2 : c->d_nu, *nu_out = (k & 1) ? c->d_nu : c->d_nu2;
     {
@@ -1454,7 +1454,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (gb && !direct) CUP2D_TRY(exchange_end(c, c->d_r, 1, BS));
     if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
-  c->prof_sample = true;
+  c->prof_sample = c->prof_outer;
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt.  Which buffer holds y_opt is in the scalars: the launch reads it there,
   // so it is enqueued behind the last iteration without the host having seen the solve end (one wait per solve instead of two;
   // a caller that asked for the last iterate takes the host's route below).  Enqueued BEFORE the copies of the scalars: a

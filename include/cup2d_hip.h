@@ -547,9 +547,9 @@ int cup2d_halo_exchange(cup2d_ctx *ctx, int field, int width);
 
 /* ---------------------------------------------------------------- instrumentation -------- */
 /* HIP-event timing per kernel family, recorded on the context stream around the launches:
- * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every launch outside the solver, every 8th
- * BiCGSTAB iteration inside it (an event pair costs ~4 us of stream time; 16 of them per iteration are
- * 10 % of a 4096^2 step, sampled they are ~1 %); (ctx, 0) off.  cup2d_get_timing returns accumulated GPU
+ * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every 16th BiCGSTAB iteration, and the launches outside the
+ * solver in every 4th cup2d_step (an event pair is a barrier packet between two kernels, ~12 us of stream time: every launch
+ * timed costs 10 % of a 4096^2 step, sampled < 1 %); (ctx, 0) off.  cup2d_get_timing returns accumulated GPU
  * milliseconds and the number of timed launches since timing was enabled.  Events are resolved lazily
  * (no extra synchronisation per launch). */
 typedef enum {

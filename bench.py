@@ -997,6 +997,8 @@ def main():
             "gpu_ms_per_step": gpu_split, "solve_to_tolerance": tol_leg,
             "kernels": timers, "roofline_extra_sampled_steps_outside_timed_region": extra_sampled_steps,
             "cpu_baseline": cpu, "amr_configs4": amr, "nrank_path_on_one_gpu": nrank_proxy, "placement": placement, "second_size": second_size,
+            # (the last key of the line as well: a record that keeps only the tail of stdout still says whether the timed work was real)
+            "verified_ok": None if verified is None else bool(verified.get("ok")),
         }
     if second is None or world == 1:
         run.close()

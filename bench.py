@@ -295,6 +295,38 @@ class Runner:
         self.sim.close()
 
 
+def north_star_floors(sim, args, nsteps=6):
+    """The two floors of the fused WENO5 stage kernel, measured the way the timed region measures the kernel itself: whole
+    steps on the bench's context and data with the sampled per-kernel HIP events (mode 3: the launches outside the solver in
+    every step), stage 2 behind stage 1 as in a step -- once with the product kernel, once with the instantiation that does
+    no loads / stores inside its loop (the arithmetic alone, on real velocities), once with the one that does no arithmetic
+    (the memory skeleton), and the product again.  The velocity is put back before every step (a knocked-out stage leaves
+    garbage).  cup2d_debug_walk_knockout, advect.hip KO."""
+    from cup2d_amd import lib as L
+    lib_, ctx = sim.L, sim.ctx
+    i1, i2 = L.TIMER_NAMES.index("advect_stage"), L.TIMER_NAMES.index("advect_stage2")
+    L.check(lib_.cup2d_copy_field(ctx, L.TMPV, L.VEL), "copy_field")   # TMPV is not written by the fused step
+    out = {}
+    try:
+        for tag, ko in (("product", 0), ("arithmetic_alone", 2), ("memory_skeleton", 1), ("product_again", 0)):
+            sim.debug_walk_knockout(ko)
+            L.check(lib_.cup2d_copy_field(ctx, L.VEL, L.TMPV), "copy_field")
+            sim.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+            sim.set_timing(3)
+            for _ in range(nsteps):
+                L.check(lib_.cup2d_copy_field(ctx, L.VEL, L.TMPV), "copy_field")
+                sim.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+            (m1, n1), (m2, n2) = sim.get_timing(i1), sim.get_timing(i2)
+            sim.set_timing(0)
+            out[tag] = {"stage1": round(1e3 * m1 / max(1, n1), 2), "stage2": round(1e3 * m2 / max(1, n2), 2), "launches": n1 + n2}
+            beat("north-star floors")
+    finally:
+        sim.debug_walk_knockout(0)
+        L.check(lib_.cup2d_copy_field(ctx, L.VEL, L.TMPV), "copy_field")
+    out["how"] = "us per launch, HIP events on the launch stream, %d whole steps each, same context / data / timers as the timed region" % nsteps
+    return out
+
+
 def tolerance_leg(step, sync, nsteps=5):
     """What a user of the reference waits for after step 10 (run.sh:13-14, main.cpp:7028-7030): the same step with the solve
     ended by -poissonTol 1e-3 -poissonTolRel 1e-2 -maxPoissonRestarts 0 (cap 1000 = -maxPoissonIterations) instead of by the cap
@@ -353,6 +385,26 @@ def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step, with_toler
         del vel
         el, r = _proxy_time(args, s, nst)
         form = s.last_solver_form()
+        # the cost of an iteration on the N-rank path, measured inside THIS context: the period of an iteration = (step of
+        # --iters iterations - step of 10) / (--iters - 10), and what of it is not inside the two sweeps (their HIP-event averages
+        # in the same context): pack launches, RCCL kernels, idle stream between them
+        inside = None
+        try:
+            if args.iters > 20:
+                a10 = argparse.Namespace(**vars(args))
+                a10.iters = 10
+                el10, _ = _proxy_time(a10, s, nst)
+                period = (el - el10) / (args.iters - 10)
+                s.set_timing(2)
+                for _ in range(4):
+                    s.step(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=args.iters)
+                tc, te = s.get_timing(L.TIMER_NAMES.index("sweep_C")), s.get_timing(L.TIMER_NAMES.index("sweep_EA"))
+                s.set_timing(0)
+                if tc[1] and te[1]:
+                    sw = (tc[0] / tc[1] + te[0] / te[1]) * 1e-3
+                    inside = {"period_us": round(period * 1e6, 1), "sweeps_us": round(sw * 1e6, 1), "outside_us": round((period - sw) * 1e6, 1)}
+        except Exception as e:  # informative
+            inside = {"error": str(e)[:120]}
         tol_leg = tolerance_leg(s.step, s.synchronize, 3) if with_tolerance_leg else None
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "comm_stats")
@@ -361,6 +413,9 @@ def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step, with_toler
             "ms_per_step": round(el * 1e3, 3), "value": round(nbx * nby * 64 / el / 1e6, 2), "unit": "Mcell-updates/s",
             "plain_context_ms_per_step": round(plain_s_per_step * 1e3, 3), "ratio_to_plain": round(el / plain_s_per_step, 4),
             "fixed_us_per_iteration_over_plain": round((el - plain_s_per_step) / max(1, r["iters"]) * 1e6, 1),
+            "iteration_period_us": (inside or {}).get("period_us"), "sweeps_us_per_iteration": (inside or {}).get("sweeps_us"),
+            "outside_the_sweeps_us_per_iteration": (inside or {}).get("outside_us"), "inside_error": (inside or {}).get("error"),
+            "form": "%s merge %d" % (form[0], form[1]),
             "iters": r["iters"], "solver_form": list(form), "ghost_blocks": g.nghost, "halo_set_patch": g.halo_tile,
             "n_inner": g.n_inner, "exchanges": ex.value, "allgathers": ag.value, "solve_to_tolerance": tol_leg}
 
@@ -375,7 +430,7 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
     out["what"] = ("the N-rank code path of the step on one GPU: a patch that is its own W, E, S and N neighbour (ghost blocks on "
                    "all four sides, four send/recv pairs per ncclGroup to self with the reduction records riding in the group, the scalar "
                    "update in the consumer sweeps: k_edge MERGE 3)")
-    out["timeline"] = "profiles/r05_nrank_timeline.txt"
+    out["timeline"] = "profiles/r06_nrank_timeline.txt"
     others = []
     for (bx, by, axes, pl) in ((nbx, nby, "x", plain), (nbx, max(1, nby // 2), "xy", None)):
         try:
@@ -383,6 +438,22 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
         except Exception as e:  # informative
             others.append({"blocks": "%dx%d" % (bx, by), "error": str(e)[:200]})
     out["other_patches"] = others
+    # BASELINE.json configs[3] on paper: 8 ranks of 4096 x 2048 cells against ONE GPU on the whole 8192^2 grid (timed here), before a
+    # single link is crossed -- the ceiling of the strong-scaling figure the library's own per-rank costs allow
+    try:
+        import cup2d_amd
+        n8 = 2 * nbx
+        with cup2d_amd.Simulation(n8, n8, nu=1e-3, cfl=0.5, device=device) as big:
+            big.set_math(args.math == "strict")
+            big.set_solver(fused=args.solver == "fused", finish_in_kernel=args.finish == "kernel")
+            big.vel = _proxy_velocity(n8, n8)
+            el8, _ = _proxy_time(args, big, 3)
+        one = n8 * n8 * 64 / el8 / 1e6
+        rankv = others[1].get("value")
+        out["configs3_on_paper"] = {"one_gpu_%dx%d_cells" % (n8 * 8, n8 * 8): round(one, 1), "per_rank_patch_%s" % others[1].get("blocks"): rankv,
+                                    "eight_ranks_over_one_gpu": round(8 * rankv / one, 2) if rankv else None}
+    except Exception as e:  # informative
+        out["configs3_on_paper"] = {"error": str(e)[:120]}
     return out
 
 
@@ -409,6 +480,23 @@ def amr_leg(args, device):
         L.check(s.L.cup2d_synchronize(s._ctx), "synchronize")
         el = (time.perf_counter() - t0) / nst
         solver, stats = s.last_solver(), s.matrix_stats()
+        # the launches of an iteration on the hybrid operator (HIP events, sampled), in the same context
+        kernels_us, iteration_us = None, None
+        try:
+            import ctypes
+            L.check(s.L.cup2d_set_timing(s._ctx, 2), "set_timing")
+            for _ in range(4):
+                s.step(max_iter=args.iters)
+            kernels_us = {}
+            for name in ("sweep_A", "sweep_C", "sweep_E", "sweep_EA", "advect_stage", "poisson_rhs", "project"):
+                ms, n = ctypes.c_double(), ctypes.c_int()
+                L.check(s.L.cup2d_get_timing(s._ctx, L.TIMER_NAMES.index(name), ctypes.byref(ms), ctypes.byref(n)), "get_timing")
+                if n.value:
+                    kernels_us[name] = round(1e3 * ms.value / n.value, 1)
+            L.check(s.L.cup2d_set_timing(s._ctx, 0), "set_timing")
+            iteration_us = round(sum(kernels_us.get(k, 0.0) for k in ("sweep_A", "sweep_C", "sweep_E", "sweep_EA")), 1)
+        except Exception as e:  # informative
+            kernels_us = {"error": str(e)[:120]}
         try:
             amr_tol = tolerance_leg(s.step, lambda: L.check(s.L.cup2d_synchronize(s._ctx), "synchronize"), 3)
         except Exception as e:  # informative
@@ -447,7 +535,7 @@ def amr_leg(args, device):
                         "iters on the assembled coarse-fine operator" % (8 << args.amr_lfine, args.iters),
             "blocks": g.nblocks, "cells": g.nblocks * 64, "blocks_per_level": np.bincount(g.blocks[:, 0]).tolist(),
             "value": round(g.nblocks * 64 / el / 1e6, 2), "unit": "Mcell-updates/s", "ms_per_step": round(el * 1e3, 3),
-            "iters": r["iters"], "solver": solver, "solve_to_tolerance": amr_tol, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
+            "iters": r["iters"], "solver": solver, "iteration_us": iteration_us, "kernels_us": kernels_us, "solve_to_tolerance": amr_tol, "operator": stats, "operator_install_ms": round(t_op * 1e3, 1),
             "grid_build_ms": round(t_grid * 1e3, 1), "plan_on_8_ranks": plan8,
             "regrid": {"changed": bool(changed), "blocks_before": warm["blocks_before"], "blocks_after": nb_after,
                        "ms": round(t_adapt * 1e3, 1), "first_ms": regrids[0]["ms"], "all": regrids,
@@ -455,6 +543,111 @@ def amr_leg(args, device):
                        "what": "adapt(): tags, 2:1 balance, plan + tables of the new leaves (host, leaf lists only), new context, "
                                "prolongation / restriction / copy of five fields by k_amr_regrid between the two contexts (no "
                                "field crosses PCIe), operator"}}
+
+
+def _g(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _r(x, n=1):
+    return round(x, n) if isinstance(x, (int, float)) else x
+
+
+def compact_line(full, detail_path):
+    """The line the driver records: the contract's keys, `roofline` (dominant kernel), `cpu_baseline`, and `summary` -- the numbers of
+    every leg without their prose (that is in the detail file)."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    cfg = dict(full["config"])
+    comm = cfg.pop("comm", None)
+    line["config"] = cfg
+    if comm:
+        cfg["comm"] = {k: comm.get(k) for k in ("cartesian", "rccl_ranks", "shared_gpu", "exchanges", "allgathers", "allreduces")}
+        cfg["comm"]["transport"] = str(comm.get("transport"))[:40]
+        cfg["comm"]["selftest_us"] = [_g(comm, "selftest", "exchange_us"), _g(comm, "selftest", "reduce_us")]
+        if comm.get("organisations"):
+            cfg["comm"]["organisations_ms_per_step"] = {k.split(" ")[0].split(":")[0]: v.get("ms_per_step", v.get("error"))
+                                                        for k, v in comm["organisations"].items()}
+    rf = full.get("roofline")
+    line["roofline"] = {k: rf.get(k) for k in ("kernel", "family", "bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_cell",
+                                               "avg_launch_ms", "launches", "share_of_gpu_time")} if rf else None
+    cpu = full.get("cpu_baseline")
+    if cpu and "error" not in cpu:
+        line["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "solver", "sample", "host_hardware_threads")}
+        fh = cpu.get("reference_functors_at_headline_size") or {}
+        if "advect_diffuse" in fh:
+            line["cpu_baseline"]["reference_functors_at_%d2_mcells_per_s" % fh.get("n", 0)] = {
+                "advect_diffuse": fh["advect_diffuse"], "pressure_rhs1": fh["pressure_rhs1"], "cores": fh.get("cores"), "kind": "reference"}
+    else:
+        line["cpu_baseline"] = cpu
+    S = {"verified": full.get("verified_summary"), "ms_per_step_no_kernel_timers": full.get("ms_per_step_no_kernel_timers")}
+    ns = full.get("roofline_north_star")
+    if ns:
+        tr = ns.get("traffic")
+        alg = ns["bytes_per_cell"] * _g(full, "config", "global_cells", default=0) / max(1, full["n_gpus"])
+        S["north_star"] = {"kernel": ns["kernel"], "frac": ns["frac"], "avg_us": _r(ns["avg_launch_ms"] * 1e3, 1), "launches": ns["launches"],
+                           "bytes_per_cell": ns["bytes_per_cell"], "traffic_over_algorithmic": _r(tr / alg, 3) if tr and alg else None,
+                           "fp64_frac_of_32T": ns.get("fp64_frac_of_measured_ceiling_32T")}
+        for st in ("stage1", "stage2"):
+            if st in ns:
+                S["north_star"][st] = {k: ns[st].get(k) for k in ("avg_launch_us", "launches", "hbm_frac", "floor_memory_us", "floor_arithmetic_us",
+                                                                  "bound", "frac_of_larger_floor", "floor_leg_vs_timed_region")}
+        if _g(ns, "floors", "error"):
+            S["north_star"]["floors_error"] = ns["floors"]["error"]
+    g = full.get("gpu_ms_per_step") or {}
+    S["gpu_ms_per_step"] = {k: g.get(k) for k in ("solver_sweeps", "outside_the_sweeps")}
+    S["kernels"] = {}
+    for fam, r in (full.get("roofline_all") or {}).items():
+        alg = r["bytes_per_cell"] * _g(full, "config", "global_cells", default=0) / max(1, full["n_gpus"])
+        S["kernels"][fam] = {"k": r["kernel"], "us": _r(r["avg_launch_ms"] * 1e3, 1), "frac": r["frac"], "n": r["launches"],
+                             "B_per_cell": r["bytes_per_cell"], "x_alg": _r(r["traffic"] / alg, 2) if r.get("traffic") and alg else None}
+    for fam in ("project", "reduce", "final_x", "scalars"):
+        t = _g(full, "kernels", fam)
+        if t and t.get("launches"):
+            S["kernels"][fam] = {"us": _r(t["ms_avg"] * 1e3, 1), "n": t["launches"]}
+    sv = full.get("solver")
+    if sv:
+        S["iteration"] = {"us": _r(sv["ms_per_iteration"] * 1e3, 1), "B_per_cell": sv["bytes_per_cell_iteration"], "frac": sv["frac_hbm"]}
+    tl = full.get("solve_to_tolerance")
+    if tl:
+        S["solve_to_tolerance"] = {k: tl.get(k) for k in ("iters_median", "ms_per_step_median", "ms_not_in_iterations_or_fringe", "error") if k in tl}
+    ss = full.get("second_size")
+    if ss:
+        S["second_size_2048"] = {k: ss.get(k) for k in ("value", "ms_per_step", "error") if k in ss}
+    am = full.get("amr_configs4")
+    if am:
+        S["amr_configs4"] = ({"error": am["error"]} if "error" in am else
+                             {"value": am["value"], "ms_per_step": am["ms_per_step"], "blocks": am["blocks"], "solver": am.get("solver"),
+                              "iteration_us": am.get("iteration_us"), "kernels_us": am.get("kernels_us"),
+                              "regrid_ms": _g(am, "regrid", "ms"), "regrid_stages_ms": _g(am, "regrid", "stages_ms"),
+                              "tolerance": {k: _g(am, "solve_to_tolerance", k) for k in ("iters_median", "ms_per_step_median")}})
+    nr = full.get("nrank_path_on_one_gpu")
+    if nr:
+        if "error" in nr:
+            S["nrank_path_on_one_gpu"] = {"error": nr["error"]}
+        else:
+            def patch(p):
+                if "error" in p:
+                    return {"error": p["error"][:80]}
+                return {k: p.get(k) for k in ("ms_per_step", "plain_context_ms_per_step", "ratio_to_plain", "fixed_us_per_iteration_over_plain",
+                                              "outside_the_sweeps_us_per_iteration", "value", "form")}
+            S["nrank_path_on_one_gpu"] = {"%s_%s" % (p.get("blocks"), p.get("ghost_sides")): patch(p) for p in [nr] + list(nr.get("other_patches") or [])}
+            for k in ("configs3_on_paper",):
+                if nr.get(k):
+                    S["nrank_path_on_one_gpu"][k] = nr[k]
+    pl = full.get("placement") or {}
+    S["placement"] = {k: _r(pl.get(k), 1) for k in ("candidates", "kept_us", "slowest_us", "first_us") if k in pl} or pl
+    sl = full.get("second_layout")
+    if sl:
+        S["second_layout"] = {k: sl.get(k) for k in ("layout", "value", "ms_per_step", "cells_per_rank", "scaling", "error") if k in sl}
+    line["summary"] = S
+    line["detail"] = detail_path
+    line["verified_ok"] = full.get("verified_ok")
+    return line
 
 
 def main():
@@ -538,16 +731,25 @@ def main():
     cells = cells_rank * world
     value = cells * args.steps / elapsed / 1e6
     extra_sampled_steps = 0
+    acc = {name: list(sim.get_timing(i)) for i, name in enumerate(L.TIMER_NAMES)}   # the samples of the timed region
     if not args.no_kernel_timers:
-        # too few sampled launches for a per-kernel average (a short --steps): keep sampling OUTSIDE the timed region
-        def sampled(name):
-            return sim.get_timing(L.TIMER_NAMES.index(name))[1]
-        while max(sampled("sweep_E"), sampled("sweep_EA")) < MIN_ROOFLINE_LAUNCHES and extra_sampled_steps < 64:
-            run.one_step()
-            extra_sampled_steps += 1
+        # too few sampled launches for a per-kernel average (every family, the north-star kernel included: one launch of each
+        # RK stage per step): keep sampling OUTSIDE the timed region, with the launches outside the solver sampled in every step
+        def short():
+            return (max(acc["sweep_E"][1], acc["sweep_EA"][1]) < MIN_ROOFLINE_LAUNCHES
+                    or acc["advect_stage"][1] + acc["advect_stage2"][1] < MIN_ROOFLINE_LAUNCHES)
+        if short():
+            sim.set_timing(3)
+            base = {k: list(v) for k, v in acc.items()}
+            while short() and extra_sampled_steps < 64:
+                run.one_step()
+                extra_sampled_steps += 1
+                for i, name in enumerate(L.TIMER_NAMES):
+                    ms, calls = sim.get_timing(i)
+                    acc[name] = [base[name][0] + ms, base[name][1] + calls]
     timers = {}
-    for i, name in enumerate(L.TIMER_NAMES):
-        ms, calls = sim.get_timing(i)
+    for name in L.TIMER_NAMES:
+        ms, calls = acc[name]
         timers[name] = {"ms_total": round(ms, 4), "launches": calls, "ms_avg": round(ms / calls, 5) if calls else None}
     # the two RK stages of the north-star kernel are timed apart (stage 1: 32 B/cell, stage 2: 48); "advect_stage" below is
     # the family, one launch of each per step
@@ -770,48 +972,31 @@ def main():
         north.update({"mcells_per_s": round(cells_rank / sec / 1e6, 1), "fp64_instr_per_cell": fp64_per_cell,
                       "fp64_T_lane_instr_per_s": round(rate, 2), "fp64_frac_of_measured_ceiling_32T": round(rate / 32.0, 4),
                       "fp64_frac_of_nominal_39.3T": round(rate / 39.3, 4)})
-        # both roofs per stage, and the floors measured with knock-out builds of the kernel (DESIGN.md 4.1:
-        # arithmetic alone 113 us = 50.8 M wave-instructions / 1024 SIMDs x 4 cycles at the 1.75 GHz the part sustains under
-        # FP64 load; stage 2's memory skeleton alone 142 us = its 896 MB of L2-miss traffic at the 6.29 TB/s copy ceiling)
-        for st, bpc, floor_us, floor_what in (("stage1", 32.0, 113.0, "FP64 issue (arithmetic alone)"),
-                                              ("stage2", 48.0, 142.0, "HBM (memory skeleton alone)")):
+        # per stage: both roofs, and the two floors of the kernel MEASURED IN THIS RUN (north_star_floors below: the same context,
+        # the same data, whole steps with the same sampled timers -- knock-out instantiations of the kernel, advect.hip KO)
+        for st, bpc in (("stage1", 32.0), ("stage2", 48.0)):
             t = stage_t[st]
             if t["launches"] and (nx, ny) == (4096, 4096):
                 ssec = t["ms_total"] / t["launches"] * 1e-3
                 gb = bpc * cells_rank / ssec / 1e9
                 fr = fp64_per_cell * cells_rank / ssec / 1e12
-                north[st] = {"avg_launch_ms": round(ssec * 1e3, 4), "bytes_per_cell": bpc, "hbm_frac": round(gb / HBM_PEAK_GBS, 4),
-                             "hbm_frac_of_copy_ceiling": round(gb / HBM_COPY_CEILING_GBS, 4),
-                             "fp64_frac_of_measured_ceiling_32T": round(fr / 32.0, 4),
-                             "measured_floor_us": floor_us, "floor": floor_what, "frac_of_floor": round(floor_us / (ssec * 1e6), 4)}
-        # the two floors of the quad form measured ON THIS BOX (timing-only builds of advect.hip, csrc/Makefile `variants`:
-        # -DWALK_KNOCKOUT=1 = no arithmetic, the memory skeleton; =2 = no loads / stores in the loop, the arithmetic alone), each
-        # in a child process through CUP2D_LIB, next to the product library timed the same way
-        if not args.no_north_star_floors and world == 1:
-            floors = {}
-            for tag, lib in (("product", None), ("memory_skeleton_no_arithmetic", "libcup2d_hip_walk_nomath.so"),
-                             ("arithmetic_no_loads_or_stores", "libcup2d_hip_walk_nomem.so")):
-                path = os.path.join(ROOT, "cup2d_amd", "variants", lib) if lib else None
-                if path and not os.path.exists(path):
-                    floors[tag] = {"error": "not built (make -C cup2d_amd/csrc variants)"}
-                    continue
-                try:
-                    env = dict(os.environ)
-                    if path:
-                        env["CUP2D_LIB"] = path
-                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_advect_stages.py"), str(nx), "10"], env=env,
-                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
-                    line = [l for l in r.stdout.decode().splitlines() if "us per launch" in l][-1]
-                    tok = line.split(":")[-1].split()
-                    floors[tag] = {tok[k]: float(tok[k + 1]) for k in range(0, len(tok) - 1, 2)}
-                except Exception as e:  # informative
-                    floors[tag] = {"error": str(e)[:160]}
-                beat("north-star floors")
-            north["floors_on_this_box_us"] = dict(floors, what="HIP events around each of 10 launches at %d^2 (tools/gpu_advect_stages.py): rhs = the "
-                                                              "functor alone, stage1 / stage2 = the fused RK stages; a launch can be no shorter than "
-                                                              "the larger of its two floors" % nx)
-        north["target_note"] = ("0.70 of HBM peak at 40 B/cell = 120 us per launch: below stage 2's measured memory floor (142 us) and "
-                                "6 % above stage 1's arithmetic floor (113 us); the ceiling of this design is 0.66 (DESIGN.md 4.1)")
+                north[st] = {"avg_launch_us": round(ssec * 1e6, 2), "launches": t["launches"], "bytes_per_cell": bpc,
+                             "hbm_frac": round(gb / HBM_PEAK_GBS, 4), "hbm_frac_of_copy_ceiling": round(gb / HBM_COPY_CEILING_GBS, 4),
+                             "fp64_frac_of_measured_ceiling_32T": round(fr / 32.0, 4)}
+        if not args.no_north_star_floors and world == 1 and dist is None and walk:
+            try:
+                fl = north_star_floors(sim, args)
+                north["floors"] = fl
+                for st in ("stage1", "stage2"):
+                    if st in north and fl.get("product", {}).get(st):
+                        mem, ari, prod = fl["memory_skeleton"][st], fl["arithmetic_alone"][st], fl["product"][st]
+                        north[st].update({"floor_memory_us": mem, "floor_arithmetic_us": ari, "product_in_floor_leg_us": prod,
+                                          "bound": "FP64 issue" if ari >= mem else "HBM",
+                                          "frac_of_larger_floor": round(max(mem, ari) / prod, 4),
+                                          "floor_leg_vs_timed_region": round(prod / north[st]["avg_launch_us"], 4)})
+            except Exception as e:  # informative
+                north["floors"] = {"error": str(e)[:200]}
+            beat("north-star floors")
     # one BiCGSTAB iteration = sweeps A..E + 3 scalar kernels (sum of the sampled average durations)
     it_bytes = sum(ALGO_BYTES[k] for k in sweeps)
     solver = None
@@ -876,7 +1061,7 @@ def main():
                 best = max(sweep, key=lambda t: sweep[t][0])
                 r = sweep[best][1]
                 cpu = {"value": sweep[best][0], "unit": "Mcell-updates/s", "cores": r.get("threads", best),
-                       "kind": "reference functors + restated solver",
+                       "kind": "reference", "solver": "CPU restatement of cuda.cu (the reference has no CPU solver)",
                        "thread_scaling_note": "the reference loop gets SLOWER beyond ~16 threads: its functors scale (OpenMP over blocks), "
                                               "but the Poisson solve has no CPU path in the reference (cuda.cu is its only solver) and is "
                                               "timed here as the serial CPU port of cuda.cu; with every hardware thread spinning in "
@@ -985,9 +1170,8 @@ def main():
             "ms_per_step_no_kernel_timers": round(elapsed_plain / args.steps * 1e3, 3) if elapsed_plain else None,
             "higher_is_better": True,
             "scaling": "strong" if args.layout == "configs3" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d uniform cells per GPU (%dx%d 8x8 blocks), nu=1e-3, CFL 0.5; step = dt + RK2 WENO5 "
-                                   "advect-diffuse + Poisson rhs + %d BiCGSTAB iters (block-Jacobi) + projection"
-                                   % (nx, ny, nx // 8, ny // 8, args.iters),
+            "config": {"workload": "%dx%d uniform cells per GPU; step = dt + RK2 WENO5 advect-diffuse + Poisson rhs + %d BiCGSTAB its + projection"
+                                   % (nx, ny, args.iters),
                        "layout": args.layout, "global_cells": cells, "global_grid": "%dx%d" % (nx * px, ny * py),
                        "parallelism": run.par, "math": args.math, "bicgstab_iters_per_step": args.iters,
                        "solver": "fused" if fused else "sweeps", "finish": "kernel" if mk == "true" else "launch",
@@ -1005,7 +1189,17 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        # everything measured goes to a side file; stdout carries ONE compact line (< 8 KB: a record that keeps the tail of
+        # stdout keeps all of it) with the contract's keys and a summary of every leg
+        detail_path = os.environ.get("CUP2D_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except Exception as e:
+            detail_path = "not written: %s" % str(e)[:80]
+        line = compact_line(out, os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path)
+        os.write(json_fd, (json.dumps(line, separators=(",", ":")) + "\n").encode())
     os.close(json_fd)
 
 

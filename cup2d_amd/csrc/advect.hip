@@ -126,7 +126,10 @@ __global__ __launch_bounds__(WG, 4) void k_advect_diffuse(const double2 *__restr
 // ---- the quad form (advect_walk.h): one wave = 2 x 2 blocks, the reconstruction walks along the grid lines ----------
 // 13 KB of LDS per wave (ghosted 22 x 22 tile + hand-over buffer) -> three workgroups of four waves per CU; the next
 // quad's 11 loads per lane (own cells, old values, three ghost cells) are in flight while the current one is computed.
-template <int MODE, bool OLDLAB>
+// KO (timing aid, WRONG results, reachable through cup2d_debug_walk_knockout only: bench.py's floors of this kernel, measured in
+// the process, on the data and behind the launches of the product): 1 = no arithmetic -- the memory skeleton of the loop;
+// 2 = no loads / stores inside the loop -- the arithmetic alone, on the wave's first quad
+template <int MODE, bool OLDLAB, int KO = 0>
 __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restrict__ vel, const walk::V2 *__restrict__ vold,
                                                        double *__restrict__ out, const int *__restrict__ quads, int nq,
                                                        int chunk, double afc, double dfc, int prio_mode) {
@@ -191,17 +194,14 @@ __global__ __launch_bounds__(WG, 3) void k_advect_walk(const walk::V2 *__restric
     // the next quad of this wave (its last one is simply fetched twice)
     cur.advance();
     WALK_READ(E, vnext);  // (waits for everything issued so far: the loads of this quad, the stores of the one before last)
-#ifndef WALK_KNOCKOUT
-#define WALK_KNOCKOUT 0  // timing aid: 1 = no arithmetic (memory skeleton only), 2 = no loads / stores inside the loop
-#endif
-    if (pending && WALK_KNOCKOUT != 2) walk::flush(L, lane, out2, pb0, pb1, pb2, pb3);
+    if (pending && KO != 2) walk::flush(L, lane, out2, pb0, pb1, pb2, pb3);
     if (NEED_OLD) walk::stage_old(R, L, lane);
     wave_lds_sync();
-    if (WALK_KNOCKOUT != 2) {
+    if (KO != 2) {
       walk::fetch<NEED_OLD>(R, vel, vold, E, lane, gp);
       vnext = entry_ahead(1)[tl];
     }
-    if (WALK_KNOCKOUT == 1) {
+    if (KO == 1) {
       pb0 = cb0, pb1 = cb1, pb2 = cb2, pb3 = cb3;
       pending = true;
       continue;
@@ -280,14 +280,16 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
     if (p->nquads) {
       const double k = mode == 0 ? 1.0 : coef;
       const walk::V2 *wv = (const walk::V2 *)vel, *wo = (const walk::V2 *)vold;
-#define LAUNCHW(M, OL)                                                                                             \
-  hipLaunchKernelGGL((k_advect_walk<M, OL>),                                                                       \
+#define LAUNCHW(M, OL, KO)                                                                                         \
+  hipLaunchKernelGGL((k_advect_walk<M, OL, KO>),                                                                   \
                      dim3(wchunk > 0 ? chunked_grid(p->nquads, wchunk)                                             \
-                                     : resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<M, OL>), p->nquads)), \
+                                     : resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<M, OL, KO>), p->nquads)), \
                      dim3(WG), 0, c->stream, wv, wo, out, p->d_quads, p->nquads, wchunk, k * afac, k * dfac, wprio)
-      if (mode == 0) LAUNCHW(0, false);
-      else if (vold == vel) LAUNCHW(1, true);
-      else LAUNCHW(1, false);
+      if (mode == 0) LAUNCHW(0, false, 0);
+      else if (c->walk_knockout == 1) { if (vold == vel) LAUNCHW(1, true, 1); else LAUNCHW(1, false, 1); }
+      else if (c->walk_knockout == 2) { if (vold == vel) LAUNCHW(1, true, 2); else LAUNCHW(1, false, 2); }
+      else if (vold == vel) LAUNCHW(1, true, 0);
+      else LAUNCHW(1, false, 0);
 #undef LAUNCHW
       CUP2D_HIP_CHECK(hipGetLastError());
     }

@@ -345,6 +345,7 @@ static int amr_phased(cup2d_ctx *c, int blocks, const double *field, int dim, in
   const bool ghosts = c->nghost > 0 && c->exchange;
   if (blocks == CUP2D_BLOCKS_ALL && !ghosts) {
     launch((const int32_t *)nullptr, c->nblocks);
+    CUP2D_HIP_CHECK(hipGetLastError());
     return CUP2D_OK;
   }
   const AmrTopo::Phase *P = nullptr;

@@ -1270,14 +1270,24 @@ int cup2d_set_gather(cup2d_ctx *c, int nsend, const int32_t *idx) {
 }
 
 // ---- whole step (main.cpp:6576-7187, body-free) -------------------------------------------------
+static int step_impl(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
+                     int max_iter, double *dt_out, int *iters, double *linf);
 int cup2d_step(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
                int max_iter, double *dt_out, int *iters, double *linf) {
   CUP2D_CHECK_CTX(c);
   CUP2D_TRY(amr_operator_ready(c, "step"));
-  if (c->timing == 2) {  // sampled timing: the launches outside the solver in every 4th step (ctx.h prof_outer)
-    c->prof_outer = (c->prof_step++ % 4) == 0;
+  if (c->timing == 2) {  // sampled timing: the launches outside the solver in every 4th step (ctx.h prof_outer; mode 3: in every step)
+    c->prof_outer = c->prof_every_step || (c->prof_step++ % 4) == 0;
     c->prof_sample = c->prof_outer;
   }
+  const int rc = step_impl(c, nu, cfl, max_error, max_rel_error, max_restarts, max_iter, dt_out, iters, linf);
+  // the sampling of the launches outside the solver is a property of cup2d_step: operators called on their own (halo, AMR
+  // operators, rhs) between two steps are always sampled
+  c->prof_outer = c->prof_sample = true;
+  return rc;
+}
+static int step_impl(cup2d_ctx *c, double nu, double cfl, double max_error, double max_rel_error, int max_restarts,
+                     int max_iter, double *dt_out, int *iters, double *linf) {
   // the previous call on this context was a cup2d_step that left max|u| of its result behind (ctx.h)
   c->use_cached_umax = !c->amr.active && !c->vel_ptr_exposed && c->umax_partials > 0 && c->api_calls == c->umax_valid_at + 1;
   double dt = 0;
@@ -1431,6 +1441,12 @@ int cup2d_set_comm_strip_capacity(cup2d_ctx *c, int doubles) {
 }
 
 // ---- instrumentation -----------------------------------------------------------------------------
+int cup2d_debug_walk_knockout(cup2d_ctx *c, int knockout) {
+  CUP2D_CHECK_CTX(c);
+  if (knockout < 0 || knockout > 2) { set_error("debug_walk_knockout: 0, 1 or 2"); return CUP2D_ERR_ARG; }
+  c->walk_knockout = knockout;
+  return CUP2D_OK;
+}
 int cup2d_set_timing(cup2d_ctx *c, int enabled) {
   CUP2D_CHECK_CTX(c);
   if (enabled && c->prof_ev.empty()) {
@@ -1441,7 +1457,8 @@ int cup2d_set_timing(cup2d_ctx *c, int enabled) {
   }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->prof_used = 0;
-  c->timing = enabled == 2 ? 2 : (enabled ? 1 : 0);
+  c->timing = (enabled == 2 || enabled == 3) ? 2 : (enabled ? 1 : 0);
+  c->prof_every_step = enabled == 3;  // 3: sampled inside the solver, the launches outside it in EVERY step
   c->prof_sample = true;
   c->prof_outer = true;
   c->prof_step = 0;

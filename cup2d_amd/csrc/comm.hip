@@ -125,6 +125,7 @@ struct RcclComm {
   std::vector<int> csoff[CELL_SETS], croff[CELL_SETS], ccnt[CELL_SETS], crcnt[CELL_SETS];  // the same for the cell plans (cup2d_comm_set_cell_counts)
   bool direct = false;       // every peer's ghost blocks are consecutive: whole blocks can be received in place
   bool defer_ok = false;     // ... on every rank, and every rank has ghost blocks: the reduction records may ride in the send/recv group
+  bool split_ok = false;     // every rank's inner / halo cut falls on a tile boundary: split sweeps are possible on ALL ranks
   double *d_send = nullptr, *d_recv = nullptr, *d_red = nullptr, *d_gather = nullptr;
   long long n_exchange = 0, n_allreduce = 0, n_allgather = 0;  // calls issued (diagnostics)
 };
@@ -234,6 +235,7 @@ int comm_blocks_wait(cup2d_ctx *c) {
 const double *comm_gathered(const cup2d_ctx *c) { return c->rccl ? c->rccl->d_gather : nullptr; }
 int comm_nranks(const cup2d_ctx *c) { return c->rccl ? c->rccl->nranks : 1; }
 bool comm_defer_ok(const cup2d_ctx *c) { return c->rccl && c->comm_user == (void *)c->rccl && c->rccl->defer_ok; }
+bool comm_split_ok(const cup2d_ctx *c) { return c->rccl && c->comm_user == (void *)c->rccl && c->rccl->split_ok; }
 int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v2, bool on_comm_stream, const GhostRP *ghosts, bool records) {
   RcclComm *rc = c->rccl;
   rc->n_exchange++;
@@ -470,10 +472,15 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     // [1]: the reduction records in the send/recv group and the scalar updates in the consumer sweeps (krylov_fused.hip
     // "deferred"): every rank must have ghost blocks (a block exchange per reduction point to ride on); CUP2D_DEFER_SCALARS=0
     static const bool defer_on = [] { const char *e = getenv("CUP2D_DEFER_SCALARS"); return !e || atoi(e) != 0; }();
-    const double mine[2] = {(rc->direct && env_on) ? 1.0 : 0.0, (rc->direct && env_on && defer_on && c->nghost > 0 && !rc->peer.empty()) ? 1.0 : 0.0};
-    double all[2] = {0.0, 0.0};
+    // [2]: split sweeps (halo set first).  With the deferred update a split sweep and an unsplit one differ on the wire (records
+    // in the send/recv group against an all-gather behind the inner launch), so a rank must not decide from its own n_inner
+    // alone: on small grids the ranks' cuts differ (8 x 8 blocks per rank in 1 x 3: 56 / 48 / 56 inner blocks)
+    const bool split_here = c->n_inner > 0 && c->n_inner < c->nblocks && c->n_inner % FUSED_TILE == 0;
+    const double mine[3] = {(rc->direct && env_on) ? 1.0 : 0.0, (rc->direct && env_on && defer_on && c->nghost > 0 && !rc->peer.empty()) ? 1.0 : 0.0,
+                            split_here ? 1.0 : 0.0};
+    double all[3] = {0.0, 0.0, 0.0};
     CUP2D_HIP_CHECK(hipMemcpy(rc->d_red, mine, sizeof mine, hipMemcpyHostToDevice));
-    r = api->AllReduce(rc->d_red, rc->d_red, 2, ncclDouble, ncclMin, rc->red, c->stream);
+    r = api->AllReduce(rc->d_red, rc->d_red, 3, ncclDouble, ncclMin, rc->red, c->stream);
     if (r != ncclSuccess) {
       set_error("comm_init: ncclAllReduce(direct) -> %s", api->GetErrorString(r));
       return CUP2D_ERR_COMM;
@@ -483,6 +490,7 @@ int cup2d_comm_init(cup2d_ctx *c, int nranks, int rank, const void *id_bytes, in
     CUP2D_HIP_CHECK(hipMemset(rc->d_red, 0, sizeof(double) * 8));
     rc->direct = all[0] == 1.0;
     rc->defer_ok = all[1] == 1.0;
+    rc->split_ok = all[2] == 1.0;
   }
   CUP2D_TRY(cup2d_set_comm(c, rccl_exchange, rccl_wait, rccl_allreduce, rc, rc->d_send, rc->d_recv, rc->d_red));
   return cup2d_set_comm_strip_capacity(c, (int)strip);  // three whole blocks per strip: allocated above

@@ -149,6 +149,8 @@ struct cup2d_ctx {
   int math = CUP2D_MATH_FAST;
   int grid = 0;  // persistent grid size (upper bound)
   int num_cus = 0;
+  int walk_knockout = 0;  // cup2d_debug_walk_knockout: timing-only instantiations of the quad WENO5 stage kernel (advect.hip KO)
+  int spare_cus = 0;  // N ranks, overlap organisation: CUs the persistent Krylov sweeps leave to the communication stream's kernel
   std::vector<std::pair<const void *, int>> resident;  // kernel -> workgroups per CU (occupancy query, cached)
   int32_t *d_nbr = nullptr;
   std::vector<int32_t> h_nbr;                 // host copy (advect.hip builds its quad plans from it)
@@ -228,6 +230,7 @@ struct cup2d_ctx {
   // outside the solver in every 4th cup2d_step (prof_outer says whether this step is one of them)
   int prof_step = 0;
   bool prof_outer = true;
+  bool prof_every_step = false;  // cup2d_set_timing 3
   std::vector<hipEvent_t> prof_ev;
   std::vector<int> prof_id;
   int prof_used = 0;
@@ -438,6 +441,7 @@ int comm_exchange_blocks(cup2d_ctx *c, int nv, double *v0, double *v1, double *v
 const double *comm_gathered(const cup2d_ctx *c);  // [nranks][RED_REC]
 int comm_nranks(const cup2d_ctx *c);
 bool comm_defer_ok(const cup2d_ctx *c);           // agreed over all ranks at cup2d_comm_init
+bool comm_split_ok(const cup2d_ctx *c);           // every rank can split its sweeps (its inner / halo cut is a tile boundary): agreed likewise
 // the standalone form of what a MERGE 3 sweep does with the gathered records (the last pending stage of a solve)
 int comm_apply_gathered(cup2d_ctx *c, int nsum, int with_max, int stage);
 int comm_gather_records(cup2d_ctx *c);  // d_red of every rank -> the gathered records (one all-gather, compute stream)

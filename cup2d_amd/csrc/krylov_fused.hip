@@ -737,7 +737,9 @@ int launch_init_residual(cup2d_ctx *c, double *x, const double *b, int *GP, bool
 static int fused_grid(const cup2d_ctx *c, int count) {
   const int ntiles = (count + TB - 1) / TB;
   int g = (ntiles + FWAVES - 1) / FWAVES;
-  const int cap = c->num_cus > 0 ? c->num_cus : 256;
+  int cap = c->num_cus > 0 ? c->num_cus : 256;
+  // N ranks: CUs the persistent sweeps leave to the communication stream's kernels (a multiple of 8: one per XCD and step)
+  if (c->spare_cus > 0 && cap > 8 + c->spare_cus) cap -= c->spare_cus;
   if (g > cap) g = cap;
   if (g >= 8) g -= g % 8;
   return g < 1 ? 1 : g;
@@ -1098,6 +1100,7 @@ static int tune_placement(cup2d_ctx *c) {
 int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter, int *iters,
                      int *restarts, double *linf, double *linf_init) {
   CUP2D_TRY(ensure_fused_buffers(c));
+  c->spare_cus = 0;
   c->have_last = false;  // whatever happens below, the previous solve's last iterate is no longer this solve's
   // cup2d_step's solve on the same-level stencil: the initial guess is zero and PRES need not hold it (api.hip)
   const bool x0_zero = c->x0_is_zero && !c->mat.active;
@@ -1216,7 +1219,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // 12 us: 23.3 ms per step against 21.9 in one launch with the exchange behind it, 14.1 against 13.5 on a 4096 x 2048
     // patch.  Off by default; what it would gain with a slower link than a copy on one GPU is what an N-GPU run has to show.
     static const bool split_on = [] { const char *e = getenv("CUP2D_SWEEP_SPLIT"); return e && atoi(e) != 0; }();
-    const bool split = (c->org_split < 0 ? split_on : c->org_split != 0) && merge == 2 && gb && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
+    const bool split_asked = (c->org_split < 0 ? split_on : c->org_split != 0) && merge == 2 && gb;
+    const bool split_here = split_asked && c->n_inner > 0 && c->n_inner < nb && c->n_inner % TB == 0;
     const bool ghost_local = ghost_local_enabled() && merge == 2 && gb;  // r' and p'' of the ghost blocks formed here, nu'' travels (k_ghost_rp)
     // N ranks with the in-library communicator, "deferred" (the default there): per reduction point ONE pack launch and ONE RCCL
     // kernel -- the rank's reduction record travels to every rank inside the ncclGroup that carries the ghost blocks (no
@@ -1226,12 +1230,19 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // The host learns of the end of the solve one launch later than before (C+D' of iteration k reports the state after
     // iteration k - 1).  Agreed over all ranks at cup2d_comm_init (comm_defer_ok); CUP2D_DEFER_SCALARS=0 keeps round 4's form.
     const bool defer_any = merge == 2 && direct && ghost_local && comm_defer_ok(c) && c->org_defer != 0;
+    // (with the deferred update the split and the unsplit sweep are two wire protocols: the choice is the one all ranks agreed
+    // on at cup2d_comm_init, not this rank's own cut; without it both forms look the same to the peers)
+    const bool split = defer_any ? (split_asked && comm_split_ok(c)) : split_here;
     const bool defer = defer_any && !split;
     // ... and with SPLIT sweeps ("overlap": cup2d_set_nrank_organisation(ctx, 1, 1)): the halo-set launch of the consumer sweep
     // runs the pending update in its prologue (MERGE 4: it finishes nothing), its ghost blocks travel on the communication
     // stream while the inner launch runs (MERGE 3 with nothing pending: it sums the partials of both launches), and the records
     // go round in ONE all-gather behind it -- per reduction point one small collective is exposed, the block transfer is not
     const bool overlap = defer_any && split;
+    // (overlap: the sweeps leave one CU per XCD free, so that the send/recv kernel on the communication stream starts beside the
+    // inner launch at once instead of waiting for a workgroup of the persistent grid to retire.  Measured to self on the 512 x 512
+    // four-sided patch, tools/gpu_calls/gpu_r06_call1.sh: 24.8 -> 23.8 ms per step; the serial organisation: 22.5)
+    c->spare_cus = overlap ? 8 : 0;
     KrylovScalars *S[2] = {c->d_sc, c->d_sc2};
     int sq = 0, enqueued = 0;
     if (defer) c->last_merge = 3;
@@ -1455,6 +1466,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     if (last_of_group) CUP2D_HIP_CHECK(hipEventRecord(c->solve_ev[slot], c->stream));
   }
   c->prof_sample = c->prof_outer;
+  c->spare_cus = 0;
   // cuda.cu:546-547: return x_opt = x0 + P_inv y_opt.  Which buffer holds y_opt is in the scalars: the launch reads it there,
   // so it is enqueued behind the last iteration without the host having seen the solve end (one wait per solve instead of two;
   // a caller that asked for the last iterate takes the host's route below).  Enqueued BEFORE the copies of the scalars: a

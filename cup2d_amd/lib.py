@@ -30,7 +30,7 @@ SYMBOLS = [
     "cup2d_laplacian_sub", "cup2d_poisson_rhs", "cup2d_pressure_correction", "cup2d_add_correction", "cup2d_project",
     "cup2d_max_abs_vel", "cup2d_compute_dt", "cup2d_poisson_solve", "cup2d_apply_A", "cup2d_precond",
     "cup2d_get_P_inv", "cup2d_step", "cup2d_halo_plan", "cup2d_halo_pack", "cup2d_halo_unpack",
-    "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_comm_strip_capacity", "cup2d_set_timing", "cup2d_get_timing",
+    "cup2d_halo_pack_vec", "cup2d_halo_unpack_vec", "cup2d_set_comm", "cup2d_set_comm_strip_capacity", "cup2d_set_timing", "cup2d_get_timing", "cup2d_debug_walk_knockout",
     "cup2d_set_P_inv", "cup2d_set_precond", "cup2d_set_matrix_coo", "cup2d_clear_matrix", "cup2d_set_gather", "cup2d_matrix_stats", "cup2d_amr_install_poisson", "cup2d_trim_pool",
     "cup2d_set_solver", "cup2d_set_solver_form", "cup2d_set_nrank_organisation", "cup2d_get_last_solver", "cup2d_get_last_solver_form", "cup2d_get_placement", "cup2d_solver_keep_last", "cup2d_solver_last_iterate", "cup2d_set_amr", "cup2d_amr_poisson_coo", "cup2d_amr_tables", "cup2d_amr_validate_states", "cup2d_amr_regrid", "cup2d_amr_regrid_plan", "cup2d_amr_regrid_changed", "cup2d_amr_regrid_local", "cup2d_amr_regrid_device", "cup2d_amr_regrid_jobs",
     "cup2d_download_blocks", "cup2d_upload_blocks", "cup2d_copy_blocks",
@@ -163,6 +163,7 @@ def load_library():
     L.cup2d_comm_stats.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i), LL, LL, LL]
     L.cup2d_halo_exchange.argtypes = [vp, i, i]
     L.cup2d_set_timing.argtypes = [vp, i]
+    L.cup2d_debug_walk_knockout.argtypes = [vp, i]
     L.cup2d_get_timing.argtypes = [vp, i, ctypes.POINTER(d), ctypes.POINTER(i)]
     _LIB = L
     return L

@@ -310,8 +310,12 @@ class Simulation(BodyOps):
 
     # ---- instrumentation -----------------------------------------------------------------------
     def set_timing(self, on=True):
-        """False/0 off, True/1 every launch, 2 sampled (see include/cup2d_hip.h)"""
+        """False/0 off, True/1 every launch, 2 sampled, 3 sampled with the launches outside the solver in every step (include/cup2d_hip.h)"""
         _l.check(self.L.cup2d_set_timing(self._ctx, int(on)), "set_timing")
+
+    def debug_walk_knockout(self, knockout):
+        """timing aid (include/cup2d_hip.h): 1 / 2 = the quad WENO5 stage without its arithmetic / without its memory traffic; wrong results"""
+        _l.check(self.L.cup2d_debug_walk_knockout(self._ctx, int(knockout)), "debug_walk_knockout")
 
     def get_timing(self, timer):
         ms, n = ctypes.c_double(), ctypes.c_int()

@@ -211,7 +211,7 @@ int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 int cup2d_get_last_solver_form(cup2d_ctx *ctx, int *form, int *merge, int *handover);
 /* The placement search of the solver's vectors (krylov_fused.hip tune_placement: the durations of the two launches of an
  * iteration come in two modes that follow where the eleven vectors they stream lie in device memory; the first two-launch solve
- * of a context on a grid of 2048^2 cells and more tries CUP2D_PLACEMENT_TRIES = 16 complete sets and keeps the fastest).
+ * of a context on a grid of 2048^2 cells and more tries CUP2D_PLACEMENT_TRIES = 8 complete sets and keeps the fastest).
  * candidates = sets timed (0: no search ran), the microseconds per iteration of the kept set, of the slowest set seen and of
  * the set the context was created with.  Diagnostic (bench.py "placement"). */
 int cup2d_get_placement(cup2d_ctx *ctx, int *candidates, double *kept_us, double *slowest_us, double *first_us);
@@ -549,7 +549,8 @@ int cup2d_halo_exchange(cup2d_ctx *ctx, int field, int width);
 /* HIP-event timing per kernel family, recorded on the context stream around the launches:
  * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every 16th BiCGSTAB iteration, and the launches outside the
  * solver in every 4th cup2d_step (an event pair is a barrier packet between two kernels, ~12 us of stream time: every launch
- * timed costs 10 % of a 4096^2 step, sampled < 1 %); (ctx, 0) off.  cup2d_get_timing returns accumulated GPU
+ * timed costs 10 % of a 4096^2 step, sampled < 1 %); (ctx, 3) as 2 with the launches outside the solver sampled in EVERY
+ * cup2d_step; (ctx, 0) off.  Operators called on their own between two steps are always sampled.  cup2d_get_timing returns accumulated GPU
  * milliseconds and the number of timed launches since timing was enabled.  Events are resolved lazily
  * (no extra synchronisation per launch). */
 typedef enum {
@@ -574,6 +575,11 @@ typedef enum {
 } cup2d_timer;
 int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);
+/* Timing aid for the roofline of the fused WENO5 stage (bench.py "roofline_north_star"): knockout = 1 launches the quad kernel
+ * without its arithmetic (the memory skeleton of its loop), 2 without the loads and stores inside its loop (the arithmetic
+ * alone, on each wave's first quad), 0 the product.  RESULTS ARE WRONG while it is not 0: the velocity a knocked-out stage
+ * leaves is garbage.  Nothing in the library sets it; there is no environment switch for it. */
+int cup2d_debug_walk_knockout(cup2d_ctx *ctx, int knockout);
 
 #ifdef __cplusplus
 }

@@ -154,7 +154,9 @@ def run_gpu(rank, world, px, py, nbx, nby):
     # same convergence, not the same count
     # (8 ranks, 487 iterations in the oracle, 642 here with one restart more: a restart throws the Krylov space away, counts move
     # by whole restart cycles -- what is demanded is the solution, checked below against the global operator)
-    assert info["iters"] <= 2 * io["iters"] + 5 and io["iters"] <= 2 * info["iters"] + 5, (info, io)
+    # ... which is relaxed for the time-sliced 8-rank layout only: on 2 / 4 ranks the counts agree to a quarter
+    slack = 2.0 if world >= 8 else 1.25
+    assert info["iters"] <= slack * io["iters"] + 5 and io["iters"] <= slack * info["iters"] + 5, (info, io)
     assert info["err"] <= tol
     gathered = [None] * world
     dist.all_gather_object(gathered, (cx, cy, sim.pres))
@@ -188,7 +190,7 @@ def run_gpu(rank, world, px, py, nbx, nby):
     sim.fill(L.PRES, 0.0)
     info5 = sim.poisson_solve(tol=1e-9, rel_tol=0.0, max_restarts=100)
     assert sim.last_solver() == "sweeps" and info5["err"] <= 1e-9
-    assert info5["iters"] <= 2 * io["iters"] + 5 and io["iters"] <= 2 * info5["iters"] + 5, (info5, io)
+    assert info5["iters"] <= 1.25 * io["iters"] + 5 and io["iters"] <= 1.25 * info5["iters"] + 5, (info5, io)
     assert not sim.comm_errors, sim.comm_errors
     dist.barrier()
     sim.close()

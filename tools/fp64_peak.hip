@@ -23,6 +23,23 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
 #pragma unroll
         for (int k = 0; k < 16; k++) x[i] = __builtin_fma(x[i], a, b);
       }
+      if (OP == 9 && (i & 1) == 0) {   // two reciprocals the plain way: 2 x (rcp + Newton) = 2 rcp + 4 fma (+ 16 fma of filler per pair)
+        double r0 = __builtin_amdgcn_rcp(x[i]), r1 = __builtin_amdgcn_rcp(x[i + 1]);
+        r0 = __builtin_fma(__builtin_fma(-x[i], r0, 1.0), r0, r0);
+        r1 = __builtin_fma(__builtin_fma(-x[i + 1], r1, 1.0), r1, r1);
+        x[i] = r0; x[i + 1] = r1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[i] = __builtin_fma(x[i], a, b); x[i + 1] = __builtin_fma(x[i + 1], a, b); }
+      }
+      if (OP == 10 && (i & 1) == 0) {  // ... from ONE reciprocal of the product: 1 mul + rcp + 2 fma + 2 mul
+        const double pr = x[i] * x[i + 1];
+        double r = __builtin_amdgcn_rcp(pr);
+        r = __builtin_fma(__builtin_fma(-pr, r, 1.0), r, r);
+        const double r0 = r * x[i + 1], r1 = r * x[i];
+        x[i] = r0; x[i + 1] = r1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[i] = __builtin_fma(x[i], a, b); x[i + 1] = __builtin_fma(x[i + 1], a, b); }
+      }
       if (OP == 8) {                                                                    // 16 fma + (cvt, rcp_f32, cvt)
         x[i] = (double)__builtin_amdgcn_rcpf((float)x[i]);
 #pragma unroll
@@ -135,6 +152,8 @@ int main() {
     run<6>("cvt,add32,cvt (x3)", wgs);
     run<7>("16fma+rcp64 (x17)", wgs);
     run<8>("16fma+3 (x19)", wgs);
+    run<9>("2x(rcp+N)+16fma /pair", wgs);
+    run<10>("rcp(prod)+N+3mul+16fma", wgs);
   }
   return 0;
 }

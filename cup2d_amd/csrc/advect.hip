@@ -262,7 +262,15 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
                   double coef, int first, int count) {
   if (count <= 0) return CUP2D_OK;
   const double afac = -dt * c->h, dfac = nu * dt;  // main.cpp:5446-5447
-  ProfScope prof(c, (mode == 1 && vold != vel) ? CUP2D_T_ADVECT_STAGE2 : CUP2D_T_ADVECT_STAGE);  // stage 2 reads its own old values: 48 B/cell
+  const int timer = (mode == 1 && vold != vel) ? CUP2D_T_ADVECT_STAGE2 : CUP2D_T_ADVECT_STAGE;  // stage 2 reads its own old values: 48 B/cell
+  // cup2d_debug_walk_knockout (the floors of bench.py's roofline): the knocked-out instantiation is launched -- and timed --
+  // FIRST, on the stage's own inputs with the launches of the step in front of it, and writes to a scratch slab; the product
+  // launch follows untimed, so that the step stays a step and the next one meets the same conditions
+  const int ko = (c->math != CUP2D_MATH_STRICT && mode == 1) ? c->walk_knockout : 0;
+  if (ko && !c->d_ko_scratch) {
+    CUP2D_HIP_CHECK(dev_malloc(&c->d_ko_scratch, (size_t)c->ntotal * BC * 2 * sizeof(double)));
+  }
+  ProfScope prof(c, ko ? -1 : timer);
   const double2 *v = (const double2 *)vel, *vo = (const double2 *)vold;
   double2 *o = (double2 *)out;
   constexpr int chunk = 16;  // groups (of 4 blocks) per workgroup of the per-block kernel (0 would select the persistent grid)
@@ -285,9 +293,17 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
                      dim3(wchunk > 0 ? chunked_grid(p->nquads, wchunk)                                             \
                                      : resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<M, OL, KO>), p->nquads)), \
                      dim3(WG), 0, c->stream, wv, wo, out, p->d_quads, p->nquads, wchunk, k * afac, k * dfac, wprio)
+      if (ko) {
+        double *real_out = out;
+        out = c->d_ko_scratch;
+        {
+          ProfScope pko(c, timer);
+          if (ko == 1) { if (vold == vel) LAUNCHW(1, true, 1); else LAUNCHW(1, false, 1); }
+          else { if (vold == vel) LAUNCHW(1, true, 2); else LAUNCHW(1, false, 2); }
+        }
+        out = real_out;
+      }
       if (mode == 0) LAUNCHW(0, false, 0);
-      else if (c->walk_knockout == 1) { if (vold == vel) LAUNCHW(1, true, 1); else LAUNCHW(1, false, 1); }
-      else if (c->walk_knockout == 2) { if (vold == vel) LAUNCHW(1, true, 2); else LAUNCHW(1, false, 2); }
       else if (vold == vel) LAUNCHW(1, true, 0);
       else LAUNCHW(1, false, 0);
 #undef LAUNCHW

@@ -425,6 +425,7 @@ void cup2d_destroy(cup2d_ctx *c) {
   dev_free(c->d_nbr);
   for (int f = 0; f < CUP2D_NFIELDS; f++) dev_free(c->d_field[f]);
   dev_free(c->d_vscratch);
+  dev_free(c->d_ko_scratch);
   if (c->vec_arena) {  // the solver's eleven vectors are pieces of one allocation (krylov_fused.hip tune_placement)
     double **piece[] = {&c->d_r, &c->d_s, &c->d_p, &c->d_p2, &c->d_nu, &c->d_nu2, &c->d_t, &c->d_y, &c->d_yopt, &c->d_xopt, &c->d_rhat};
     for (double **q : piece) *q = nullptr;

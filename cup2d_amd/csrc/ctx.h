@@ -157,6 +157,7 @@ struct cup2d_ctx {
   std::vector<cup2d::WalkPlan> walk_plans;    // one per block range asked for
   double *d_field[CUP2D_NFIELDS] = {nullptr};
   double *d_vscratch = nullptr;  // RK2 mid-point velocity (vector slab)
+  double *d_ko_scratch = nullptr;  // cup2d_debug_walk_knockout: where a knocked-out stage launch writes (allocated on first use)
   // Krylov vectors (scalar slabs; z/z2 carry ghost blocks)
   double *d_r = nullptr, *d_rhat = nullptr, *d_p = nullptr, *d_nu = nullptr, *d_t = nullptr;
   double *d_z = nullptr, *d_z2 = nullptr, *d_xopt = nullptr;
@@ -282,8 +283,8 @@ int prof_resolve(cup2d_ctx *c);
 struct ProfScope {
   cup2d_ctx *c;
   int slot;
-  ProfScope(cup2d_ctx *c_, int id) : c(c_), slot(-1) {
-    if (!c->timing || (c->timing == 2 && !c->prof_sample)) return;
+  ProfScope(cup2d_ctx *c_, int id) : c(c_), slot(-1) {  // id < 0: nothing is timed
+    if (id < 0 || !c->timing || (c->timing == 2 && !c->prof_sample)) return;
     if ((size_t)(2 * c->prof_used + 2) > c->prof_ev.size()) (void)prof_resolve(c);
     slot = c->prof_used++;
     c->prof_id[slot] = id;

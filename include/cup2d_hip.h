@@ -577,8 +577,10 @@ int cup2d_set_timing(cup2d_ctx *ctx, int enabled);
 int cup2d_get_timing(cup2d_ctx *ctx, int timer, double *ms_total, int *calls);
 /* Timing aid for the roofline of the fused WENO5 stage (bench.py "roofline_north_star"): knockout = 1 launches the quad kernel
  * without its arithmetic (the memory skeleton of its loop), 2 without the loads and stores inside its loop (the arithmetic
- * alone, on each wave's first quad), 0 the product.  RESULTS ARE WRONG while it is not 0: the velocity a knocked-out stage
- * leaves is garbage.  Nothing in the library sets it; there is no environment switch for it. */
+ * alone, on each wave's first quad), 0 the product.  While it is not 0 every fused stage launches the knocked-out kernel FIRST
+ * -- under the stage's timer, on the stage's inputs, writing to a scratch slab -- and the product kernel behind it, untimed:
+ * the step's results are unchanged, its stage timers hold the knocked-out launches.  Nothing in the library sets it; there is
+ * no environment switch for it. */
 int cup2d_debug_walk_knockout(cup2d_ctx *ctx, int knockout);
 
 #ifdef __cplusplus

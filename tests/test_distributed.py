@@ -222,6 +222,16 @@ def test_amr_4084_blocks_on_3_ranks_matches_the_single_context_gpu(strips):
     launch("amr_big", 3, 0, 0, 0, 0, 29831 + int(strips), timeout=900, CUP2D_AMR_STRIPS=strips, CUP2D_POISON_GHOSTS="1")
 
 
+@pytest.mark.gpu
+def test_amr_16k_blocks_on_8_ranks_matches_the_single_context_gpu():
+    """BASELINE.json configs[4]'s shape at a size eight ranks sharing one GPU can step (finest level 2048^2-equivalent, 16 k
+    blocks on three levels, 2 k per rank): ranges, ghost blocks, cell plans (NaN-poisoned ghosts), every block operator STRICT
+    bit for bit against the single context on the whole grid, a capped step, one regrid with migration between the eight
+    ranks = the single-context regrid bit for bit, a step on the re-partitioned grid (main.cpp:6494-6504, 5055-5424)"""
+    launch("amr_big", 8, 0, 0, 0, 0, 29841, timeout=1500, CUP2D_AMR_STRIPS="1", CUP2D_POISON_GHOSTS="1", CUP2D_TEST_LFINE="8",
+           CUP2D_TEST_MAXITER="8")
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_amr_whole_block_exchange_cpu_gloo(world):
     """the adapted-grid plan driven through a real multi-process exchange on the CPU (gloo): ghost blocks, face arrays,

@@ -405,7 +405,7 @@ def nrank_proxy_patch(args, device, nbx, nby, axes, plain_s_per_step, with_toler
         n, p, ex, ar, ag = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
         L.check(s.L.cup2d_comm_stats(s.ctx, ctypes.byref(n), ctypes.byref(p), ctypes.byref(ex), ctypes.byref(ar), ctypes.byref(ag)), "comm_stats")
         L.check(s.L.cup2d_comm_finalize(s.ctx), "comm_finalize")
-    return {"blocks": "%dx%d" % (nbx, nby), "ghost_sides": "WE" if axes == "x" else "WESN", "peers": p.value,
+    return {"blocks": "%dx%d" % (nbx, nby), "ghost_sides": {"x": "WE", "y": "SN", "xy": "WESN"}[axes], "peers": p.value,
             "ms_per_step": round(el * 1e3, 3), "value": round(nbx * nby * 64 / el / 1e6, 2), "unit": "Mcell-updates/s",
             "plain_context_ms_per_step": round(plain_s_per_step * 1e3, 3), "ratio_to_plain": round(el / plain_s_per_step, 4),
             "fixed_us_per_iteration_over_plain": round((el - plain_s_per_step) / max(1, r["iters"]) * 1e6, 1),
@@ -428,9 +428,14 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
                    "update in the consumer sweeps: k_edge MERGE 3)")
     out["timeline"] = "profiles/r06_nrank_timeline.txt"
     others = []
-    for (bx, by, axes, pl) in ((nbx, nby, "x", plain), (nbx, max(1, nby // 2), "xy", None)):
+    plain_half = [None]
+    for (bx, by, axes, pl) in ((nbx, nby, "x", plain), (nbx, max(1, nby // 2), "xy", None), (nbx, max(1, nby // 2), "y", "half")):
         try:
+            if pl == "half":  # (the plain context of that size was timed for the patch before)
+                pl = plain_half[0]
             others.append(nrank_proxy_patch(args, device, bx, by, axes, pl))
+            if axes == "xy" and by != nby:
+                plain_half[0] = others[-1]["plain_context_ms_per_step"] * 1e-3
         except Exception as e:  # informative
             others.append({"blocks": "%dx%d" % (bx, by), "error": str(e)[:200]})
     out["other_patches"] = others
@@ -445,9 +450,13 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
             big.vel = _proxy_velocity(n8, n8)
             el8, _ = _proxy_time(args, big, 3)
         one = n8 * n8 * 64 / el8 / 1e6
-        rankv = others[1].get("value")
-        out["configs3_on_paper"] = {"one_gpu_%dx%d_cells" % (n8 * 8, n8 * 8): round(one, 1), "per_rank_patch_%s" % others[1].get("blocks"): rankv,
-                                    "eight_ranks_over_one_gpu": round(8 * rankv / one, 2) if rankv else None}
+        rank4, rank2 = others[1].get("value"), others[2].get("value") if len(others) > 2 else None
+        # (a rank of the 2 x 4 layout has one neighbour in x and one or two in y: 768 or 1280 ghost blocks in two or three messages; the
+        # patch with ghost blocks on all four sides has 1536 in four, the one with its two long sides 1024 in two)
+        out["configs3_on_paper"] = {"one_gpu_%dx%d_cells" % (n8 * 8, n8 * 8): round(one, 1),
+                                    "per_rank_patch_%s_four_sides" % others[1].get("blocks"): rank4,
+                                    "per_rank_patch_%s_two_long_sides" % others[1].get("blocks"): rank2,
+                                    "eight_ranks_over_one_gpu": [round(8 * v / one, 2) if v else None for v in (rank4, rank2)]}
     except Exception as e:  # informative
         out["configs3_on_paper"] = {"error": str(e)[:120]}
     return out

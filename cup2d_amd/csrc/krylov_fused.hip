@@ -1239,10 +1239,10 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     // stream while the inner launch runs (MERGE 3 with nothing pending: it sums the partials of both launches), and the records
     // go round in ONE all-gather behind it -- per reduction point one small collective is exposed, the block transfer is not
     const bool overlap = defer_any && split;
-    // (overlap: the sweeps leave one CU per XCD free, so that the send/recv kernel on the communication stream starts beside the
+    // (split sweeps: they leave one CU per XCD free, so that the send/recv kernel on the communication stream starts beside the
     // inner launch at once instead of waiting for a workgroup of the persistent grid to retire.  Measured to self on the 512 x 512
     // four-sided patch, tools/gpu_calls/gpu_r06_call1.sh: 24.8 -> 23.8 ms per step; the serial organisation: 22.5)
-    c->spare_cus = overlap ? 8 : 0;
+    c->spare_cus = split ? 8 : 0;  // (round 4's split sweeps too: the two split organisations take their partial sums over the same grids)
     KrylovScalars *S[2] = {c->d_sc, c->d_sc2};
     int sq = 0, enqueued = 0;
     if (defer) c->last_merge = 3;

@@ -296,16 +296,16 @@ class DistributedSimulation(Simulation):
 
 def self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=0, axes="x"):
     """One rank that is its own neighbour through the in-library communicator: ghost blocks on both x sides (axes "x": a domain
-    periodic in x, walls in y) or on all four sides (axes "xy": doubly periodic -- what an INTERIOR rank of a decomposition has,
+    periodic in x, walls in y; axes "y": the same in y) or on all four sides (axes "xy": doubly periodic -- what an INTERIOR rank of a decomposition has,
     and every rank of BASELINE.json configs[3]'s 2 x 4 layout has two or three of: halo-set patches that meet in corners, four
     peers in one ncclGroup, four consecutive ghost ranges received in place), each filled from the opposite edge by ncclSend /
     ncclRecv to self.  Everything a rank of an N-rank run does -- the halo set ordered last, pack kernels, whole ghost blocks of
     the Krylov vectors through RCCL, the MERGE 2 kernels, an all-gather and a one-wave kernel per reduction -- on ONE GPU: the
     tests of the communicator's data path (tests/test_comm.py) and the N-rank-path leg of bench.py use it.  Returns (Simulation,
     BlockGrid); the caller finalises the communicator (cup2d_comm_finalize) before closing."""
-    if axes not in ("x", "xy"):
-        raise ValueError("axes must be 'x' or 'xy'")
-    sides = (0, 1) if axes == "x" else (0, 1, 2, 3)
+    if axes not in ("x", "y", "xy"):
+        raise ValueError("axes must be 'x', 'y' or 'xy'")
+    sides = {"x": (0, 1), "y": (2, 3), "xy": (0, 1, 2, 3)}[axes]
     g = BlockGrid(nbx, nby, ghost_sides=tuple(k in sides for k in range(4)))
     s = Simulation(nbx, nby, nu=nu, cfl=cfl, device=device, grid=g, h=1.0 / (8 * max(nbx, nby)))
     sb, sf, rb, rf = [], [], [], []
@@ -328,6 +328,8 @@ def self_periodic_simulation(nbx, nby, nu=1e-3, cfl=0.5, device=0, axes="x"):
     # (receive offset 0) take the E strips (send offset nby), the E ghosts the W strips; likewise S <- N, N <- S
     if axes == "x":
         soff, roff, cnt = [nby, 0], [0, nby], [nby, nby]
+    elif axes == "y":  # (the S and N sides only: what the ranks of a 2 x 4 layout have towards their long sides)
+        soff, roff, cnt = [nbx, 0], [0, nbx], [nbx, nbx]
     else:
         soff, roff, cnt = [nby, 0, 2 * nby + nbx, 2 * nby], [0, nby, 2 * nby, 2 * nby + nbx], [nby, nby, nbx, nbx]
     peer = np.zeros(len(cnt), dtype=np.int32)

@@ -19,11 +19,19 @@ def test_bench_line_at_world_8_sharing_one_gpu():
     env = dict(os.environ, CUP2D_BENCH_SHARE_GPU="1", CUP2D_BENCH_WATCHDOG_S="200", OMP_NUM_THREADS="4")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "256", "--steps", "2", "--warmup", "1",
            "--layout", "configs3", "--configs3-n", "1024", "--iters", "20", "--no-cpu-baseline"]
+    env["CUP2D_BENCH_DETAIL"] = os.path.join(ROOT, "gpurun_out", "bench_detail_world8_test.json")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=840, cwd=ROOT)
     err = r.stderr.decode("utf-8", "replace")
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout.decode()[-2000:], err[-4000:])
-    J = json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 8000, len(lines[0])   # the whole line fits a record that keeps the last 8 KB of stdout
+    assert line["n_gpus"] == 8 and line["summary"]["verified"]["ok"] is True and line["verified_ok"] is True
+    assert line["config"]["comm"]["cartesian"] == "2x4" and len(line["config"]["comm"]["organisations_ms_per_step"]) == 4, line["config"]
+    assert line["summary"]["second_layout"]["layout"] == "weak", line["summary"]
+    with open(os.path.join(ROOT, line["detail"])) as f:   # everything measured: the side file the line names
+        J = json.load(f)
+    assert J["value"] == line["value"] and J["ms_per_step"] == line["ms_per_step"]
     assert J["n_gpus"] == 8 and J["steps"] == 2 and J["warmup"] == 1 and J["unit"] == "Mcell-updates/s" and J["value"] > 0
     assert J["scaling"] == "strong" and J["config"]["layout"] == "configs3" and J["config"]["parallelism"] == "cart2x4"
     assert J["config"]["global_grid"] == "1024x1024" and J["config"]["global_cells"] == 1024 * 1024

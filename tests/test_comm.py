@@ -53,13 +53,13 @@ def _hip():
 
 
 def _self_periodic_sim(nbx, nby, axes="x"):
-    """one rank that is its own W and E (axes "xy": and S and N) neighbour (cup2d_amd.distributed.self_periodic_simulation)"""
+    """one rank that is its own W and E (axes "y": S and N; "xy": all four) neighbour (cup2d_amd.distributed.self_periodic_simulation)"""
     from cup2d_amd.distributed import self_periodic_simulation
     return self_periodic_simulation(nbx, nby, axes=axes)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("axes", ["x", "xy"])
+@pytest.mark.parametrize("axes", ["x", "y", "xy"])
 def test_rccl_send_recv_to_self_fills_the_ghost_strips(gpu_lib, axes):
     """axes "xy": ghost blocks on all four sides (what an interior rank of a decomposition has; the ranks of the 2 x 4 layout of
     BASELINE.json configs[3] have two or three): four send/recv pairs in one ncclGroup"""

@@ -5,7 +5,9 @@
 // on the dense topology tables of cup2d_set_amr instead of the tree / Info hash maps.  (The tests keep a Python
 // statement of the same algorithm and require the two to agree bit for bit.)
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -296,74 +298,98 @@ void amr_blocks_reading_ghosts(int nowned, int ntotal, const int32_t *kind, cons
 // column order with duplicate columns summed in arrival order (what the triplet route stores).  At regrid time this is
 // the difference between 0.14 s and 0.01 s on a 63 k-block grid: 94 % of the blocks are plain.
 void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half,
-                         std::vector<int32_t> &reg, std::vector<long long> &ptr, std::vector<int32_t> &ecol,
-                         std::vector<double> &eval, int *nregular) {
+                         std::vector<int32_t> &reg, std::vector<long long> &ptr, HostStage &stage, int32_t **ecol_out,
+                         double **eval_out, int *nregular) {
   reg.assign((size_t)4 * nowned, CUP2D_WALL);
   ptr.assign((size_t)nowned + 1, 0);
-  ecol.clear();
-  eval.clear();
-  // chunks of blocks in parallel, each into its own entry lists (a block's 64 rows are independent of every other
-  // block's); then laid end to end
-  const int nchunks = chunk_count(nowned, 512);
-  std::vector<std::vector<int32_t>> ccol((size_t)nchunks);
-  std::vector<std::vector<double>> cval((size_t)nchunks);
-  std::vector<int> cplain((size_t)nchunks, 0);
+  *ecol_out = nullptr;
+  *eval_out = nullptr;
+  // Pieces of 128 blocks handed out by a counter (the blocks with rows to build sit in a band of the Hilbert order: equal
+  // contiguous shares leave most threads without work), each into its own entry lists -- a block's 64 rows are independent of
+  // every other block's --; then laid end to end, in block order, by the same threads.
+  constexpr int PIECE = 128;
+  const int npieces = (nowned + PIECE - 1) / PIECE;
+  std::vector<std::vector<int32_t>> ccol((size_t)npieces);
+  std::vector<std::vector<double>> cval((size_t)npieces);
+  std::vector<int> cplain((size_t)npieces, 0);
   std::vector<long long> width((size_t)nowned, 0);
-  parallel_chunks(nowned, 512, [&](long long lo, long long hi, int t) {
+  std::atomic<int> next{0};
+  const int nthreads = host_threads();
+  const auto work = [&](long long, long long, int) {
     std::vector<std::pair<long long, double>> sorted;
     std::vector<Row> rows(64);
-    std::vector<int32_t> &oc = ccol[t];
-    std::vector<double> &ov = cval[t];
-    for (int b = (int)lo; b < (int)hi; b++) {
-      bool plain = true;
-      for (int s = 0; s < 4; s++) {
-        const int k = kind[4 * b + s];
-        plain = plain && (k == CUP2D_AMR_WALL || (k == CUP2D_AMR_SAME && nbr2[(4 * b + s) * 2] < nowned));
-      }
-      if (plain) {
-        for (int s = 0; s < 4; s++)
-          reg[(size_t)4 * b + s] = kind[4 * b + s] == CUP2D_AMR_SAME ? nbr2[(4 * b + s) * 2] : CUP2D_WALL;
-        cplain[t]++;
-        continue;
-      }
-      reg[(size_t)4 * b] = SELL_STORED;
-      int w = 0;
-      for (int l = 0; l < 64; l++) {
-        rows[l] = Row();
-        build_row(rows[l], b, l & 7, l >> 3, kind, nbr2, half);
-        w = rows[l].n > w ? rows[l].n : w;
-      }
-      width[b] = w;
-      const size_t base = oc.size();
-      oc.resize(base + (size_t)w * 64);
-      ov.resize(base + (size_t)w * 64, 0.0);
-      for (int l = 0; l < 64; l++) {
-        sorted.clear();
-        for (int k = 0; k < rows[l].n; k++) sorted.emplace_back(rows[l].col[k], rows[l].val[k]);
-        std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &c2) { return a.first < c2.first; });
-        for (int k = 0; k < w; k++) {
-          const size_t e = base + (size_t)k * 64 + l;
-          if (k < (int)sorted.size()) {
-            oc[e] = (int32_t)sorted[k].first;
-            ov[e] = sorted[k].second;
-          } else {  // padding: own row, coefficient 0
-            oc[e] = b * 64 + l;
-            ov[e] = 0.0;
+    for (;;) {
+      const int t = next.fetch_add(1);
+      if (t >= npieces) break;
+      const int lo = t * PIECE, hi = std::min(nowned, lo + PIECE);
+      std::vector<int32_t> &oc = ccol[t];
+      std::vector<double> &ov = cval[t];
+      for (int b = lo; b < hi; b++) {
+        bool plain = true;
+        for (int s = 0; s < 4; s++) {
+          const int k = kind[4 * b + s];
+          plain = plain && (k == CUP2D_AMR_WALL || (k == CUP2D_AMR_SAME && nbr2[(4 * b + s) * 2] < nowned));
+        }
+        if (plain) {
+          for (int s = 0; s < 4; s++)
+            reg[(size_t)4 * b + s] = kind[4 * b + s] == CUP2D_AMR_SAME ? nbr2[(4 * b + s) * 2] : CUP2D_WALL;
+          cplain[t]++;
+          continue;
+        }
+        reg[(size_t)4 * b] = SELL_STORED;
+        int w = 0;
+        for (int l = 0; l < 64; l++) {
+          rows[l] = Row();
+          build_row(rows[l], b, l & 7, l >> 3, kind, nbr2, half);
+          w = rows[l].n > w ? rows[l].n : w;
+        }
+        width[b] = w;
+        const size_t base = oc.size();
+        oc.resize(base + (size_t)w * 64);
+        ov.resize(base + (size_t)w * 64, 0.0);
+        for (int l = 0; l < 64; l++) {
+          sorted.clear();
+          for (int k = 0; k < rows[l].n; k++) sorted.emplace_back(rows[l].col[k], rows[l].val[k]);
+          std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &c2) { return a.first < c2.first; });
+          for (int k = 0; k < w; k++) {
+            const size_t e = base + (size_t)k * 64 + l;
+            if (k < (int)sorted.size()) {
+              oc[e] = (int32_t)sorted[k].first;
+              ov[e] = sorted[k].second;
+            } else {  // padding: own row, coefficient 0
+              oc[e] = b * 64 + l;
+              ov[e] = 0.0;
+            }
           }
         }
       }
     }
-  });
+  };
+  parallel_chunks(nthreads, 1, work);
   int nreg = 0;
   for (int b = 0; b < nowned; b++) ptr[b + 1] = ptr[b] + width[b] * 64;
-  ecol.reserve((size_t)ptr[nowned]);
-  eval.reserve((size_t)ptr[nowned]);
-  for (int t = 0; t < nchunks; t++) {  // chunk t covers blocks [nowned t / nchunks, nowned (t + 1) / nchunks): in block order
-    ecol.insert(ecol.end(), ccol[t].begin(), ccol[t].end());
-    eval.insert(eval.end(), cval[t].begin(), cval[t].end());
-    nreg += cplain[t];
-  }
+  for (int t = 0; t < npieces; t++) nreg += cplain[t];
   *nregular = nreg;
+  const size_t entries = (size_t)ptr[nowned];
+  if (entries == 0) return;
+  char *base = static_cast<char *>(host_stage_reserve(stage, entries * (sizeof(int32_t) + sizeof(double))));
+  if (!base) return;  // (the caller reports it: entries > 0 and no buffer)
+  // values first: 8-byte aligned whatever the number of entries
+  double *ev = reinterpret_cast<double *>(base);
+  int32_t *ec = reinterpret_cast<int32_t *>(base + entries * sizeof(double));
+  next = 0;
+  parallel_chunks(nthreads, 1, [&](long long, long long, int) {
+    for (;;) {
+      const int t = next.fetch_add(1);
+      if (t >= npieces) break;
+      if (ccol[t].empty()) continue;
+      const size_t at = (size_t)ptr[(size_t)t * PIECE];
+      memcpy(ec + at, ccol[t].data(), ccol[t].size() * sizeof(int32_t));
+      memcpy(ev + at, cval[t].data(), cval[t].size() * sizeof(double));
+    }
+  });
+  *ecol_out = ec;
+  *eval_out = ev;
 }
 
 }  // namespace cup2d

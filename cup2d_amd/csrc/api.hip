@@ -152,6 +152,24 @@ void host_res_destroy(HostRes &r) {
 }
 }  // namespace
 
+HostStage &host_stage() {
+  static HostStage S;
+  return S;
+}
+void *host_stage_reserve(HostStage &S, size_t bytes) {
+  if (bytes <= S.cap) return S.p;
+  if (S.p) (void)hipHostFree(S.p);
+  S.p = nullptr;
+  S.cap = 0;
+  size_t want = bytes + bytes / 4;  // (a grid that grows a little finds its buffer)
+  if (hipHostMalloc(&S.p, want) != hipSuccess) {
+    S.p = nullptr;
+    return nullptr;
+  }
+  S.cap = want;
+  return S.p;
+}
+
 hipError_t dev_malloc_raw(void **p, size_t bytes) {
   DevPool &P = pool();
   if (!P.on) return hipMalloc(p, bytes);
@@ -1024,27 +1042,33 @@ int cup2d_clear_matrix(cup2d_ctx *c) {
   return CUP2D_OK;
 }
 // upload of an operator in (hybrid) sliced-ELL form + the tables of the tile-fused sweeps
+// (ecol / eval: `entries` stored entries; pinned: they lie in the process's pinned staging buffer, whose lock the caller holds --
+// the two big copies are then asynchronous and overlap the tiling below; they have been waited for when this returns)
 static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<int32_t> &reg, const std::vector<long long> &ptr,
-                        const std::vector<int32_t> &ecol, const std::vector<double> &eval, int nregular) {
-  const size_t entries = ecol.size();
+                        const int32_t *ecol, const double *eval, size_t entries, bool pinned, int nregular) {
   const auto stored = [&](int s) { return reg[(size_t)4 * s] == SELL_STORED; };
   StageClock clk("install_sell");
   CUP2D_TRY(cup2d_clear_matrix(c));
   SellMatrix &M = c->mat;
   CUP2D_HIP_CHECK(dev_malloc(&M.d_ptr, ptr.size() * sizeof(long long)));
-  CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
   if (entries) {
     CUP2D_HIP_CHECK(dev_malloc(&M.d_col, entries * sizeof(int32_t)));
     CUP2D_HIP_CHECK(dev_malloc(&M.d_val, entries * sizeof(double)));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol.data(), entries * sizeof(int32_t), hipMemcpyHostToDevice));
-    CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval.data(), entries * sizeof(double), hipMemcpyHostToDevice));
+    if (pinned) {
+      CUP2D_HIP_CHECK(hipMemcpyAsync(M.d_col, ecol, entries * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      CUP2D_HIP_CHECK(hipMemcpyAsync(M.d_val, eval, entries * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+      CUP2D_HIP_CHECK(hipMemcpy(M.d_col, ecol, entries * sizeof(int32_t), hipMemcpyHostToDevice));
+      CUP2D_HIP_CHECK(hipMemcpy(M.d_val, eval, entries * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
+  CUP2D_HIP_CHECK(hipMemcpy(M.d_ptr, ptr.data(), ptr.size() * sizeof(long long), hipMemcpyHostToDevice));
   CUP2D_HIP_CHECK(dev_malloc(&M.d_reg, reg.size() * sizeof(int32_t)));
   CUP2D_HIP_CHECK(hipMemcpy(M.d_reg, reg.data(), reg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   M.nregular = nregular;
   M.entries = entries;
   M.halo = halo;
-  clk.lap("upload ptr / col / val / reg");
+  clk.lap("upload ptr / reg (col / val in flight)");
   if (hybrid) {
     // tables of the tile-fused sweeps (ctx.h SellMatrix): the tiling, which tiles are all plain, whose z the rows of the
     // other tiles read
@@ -1082,25 +1106,42 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
     M.h_slot.assign((size_t)nbk, 0);
     for (int t = 0; t < ntiles; t++)
       for (int s = tile0[t]; s < tile0[t + 1]; s++) M.h_slot[s] = t * FUSED_TILE + (s - tile0[t]);
-    const auto flag = [&](long long b) {
-      if (b >= 0 && b < nbk) M.h_zmask[(size_t)(M.h_slot[b] / FUSED_TILE)] |= 1 << (M.h_slot[b] % FUSED_TILE);
-    };
+    // which z the rows of the general tiles read: the tiles in parallel (a few thousand of them hold two million column
+    // indices), every thread into its own mask, the masks OR-ed at the end
+    std::vector<unsigned char> is_general((size_t)ntiles, 0);
     for (int t = 0; t < ntiles; t++) {
-      const int b0 = tile0[t], b1 = tile0[t + 1];
       bool general = false;
-      for (int s = b0; s < b1; s++) general = general || stored(s);
+      for (int s = tile0[t]; s < tile0[t + 1]; s++) general = general || stored(s);
+      is_general[(size_t)t] = general;
       if (!general) continue;
-      for (int s = b0; s < b1; s++) {
+      for (int s = tile0[t]; s < tile0[t + 1]; s++) {
         gen.push_back(s);
-        flag(s);
-        if (stored(s)) {
-          for (long long e = ptr[s]; e < ptr[s + 1]; e++) flag(ecol[e] >> 6);
-        } else {
-          for (int side = 0; side < 4; side++) flag(reg[(size_t)4 * s + side]);
-        }
         for (int side = 0; side < 4; side++) fnbr[(size_t)4 * s + side] = FUSED_GENERAL;
       }
     }
+    const int nmask = chunk_count(ntiles, 64);
+    std::vector<std::vector<int32_t>> masks((size_t)nmask);
+    parallel_chunks(ntiles, 64, [&](long long lo, long long hi, int th) {
+      std::vector<int32_t> &zm = masks[(size_t)th];
+      zm.assign((size_t)ntiles, 0);
+      const auto flag = [&](long long b) {
+        if (b >= 0 && b < nbk) zm[(size_t)(M.h_slot[b] / FUSED_TILE)] |= 1 << (M.h_slot[b] % FUSED_TILE);
+      };
+      for (long long t = lo; t < hi; t++) {
+        if (!is_general[(size_t)t]) continue;
+        for (int s = tile0[t]; s < tile0[t + 1]; s++) {
+          flag(s);
+          if (stored(s)) {
+            for (long long e = ptr[s]; e < ptr[s + 1]; e++) flag(ecol[e] >> 6);
+          } else {
+            for (int side = 0; side < 4; side++) flag(reg[(size_t)4 * s + side]);
+          }
+        }
+      }
+    });
+    for (const auto &zm : masks)
+      if (!zm.empty())
+        for (int t = 0; t < ntiles; t++) M.h_zmask[(size_t)t] |= zm[(size_t)t];
     M.ntiles = ntiles;
     clk.lap("tiling");
     CUP2D_HIP_CHECK(dev_malloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
@@ -1116,6 +1157,7 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
     }
     clk.lap("upload tile tables");
   }
+  if (pinned && entries) CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));  // col / val have left the staging buffer
   M.active = true;
   return CUP2D_OK;
 }
@@ -1223,7 +1265,7 @@ int cup2d_set_matrix_coo(cup2d_ctx *c, int halo, long long nnz, const int32_t *r
     ecol[e] = col[k];
     eval[e] = val[k];
   }
-  return install_sell(c, halo, hybrid, reg, ptr, ecol, eval, nregular);
+  return install_sell(c, halo, hybrid, reg, ptr, ecol.data(), eval.data(), entries, false, nregular);
 }
 int cup2d_matrix_stats(cup2d_ctx *c, int *plain_blocks, int *general_tile_blocks, long long *stored_entries) {
   CUP2D_CHECK_CTX(c);
@@ -1236,14 +1278,19 @@ int cup2d_matrix_stats(cup2d_ctx *c, int *plain_blocks, int *general_tile_blocks
 int cup2d_amr_install_poisson(cup2d_ctx *c) {
   CUP2D_CHECK_CTX(c);
   if (!c->amr.active) { set_error("amr_install_poisson: cup2d_set_amr first"); return CUP2D_ERR_ARG; }
-  std::vector<int32_t> reg, ecol;
+  std::vector<int32_t> reg;
   std::vector<long long> ptr;
-  std::vector<double> eval;
+  int32_t *ecol = nullptr;
+  double *eval = nullptr;
   int nregular = 0;
   StageClock clk("amr_install_poisson");
-  amr_assemble_hybrid(c->nblocks, c->amr.h_kind.data(), c->amr.h_nbr2.data(), c->amr.h_half.data(), reg, ptr, ecol, eval, &nregular);
+  HostStage &stage = host_stage();
+  std::lock_guard<std::mutex> hold(stage.mu);  // the staging buffer is this call's until its upload has been waited for
+  amr_assemble_hybrid(c->nblocks, c->amr.h_kind.data(), c->amr.h_nbr2.data(), c->amr.h_half.data(), reg, ptr, stage, &ecol, &eval, &nregular);
   clk.lap("assemble rows");
-  const int rc = install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, nregular);
+  const size_t entries = (size_t)ptr[(size_t)c->nblocks];
+  if (entries && !ecol) { set_error("amr_install_poisson: no pinned staging buffer for %zu entries", entries); return CUP2D_ERR_HIP; }
+  const int rc = install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, entries, true, nregular);
   clk.lap("install_sell");
   return rc;
 }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/cup2d_hip.h"
@@ -375,8 +376,18 @@ inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_raw(reinte
 void dev_free(void *p);
 void dev_release(void *p);  // hipFree past the pool (api.hip)
 // amr_host.hip: the Poisson operator of an adapted grid straight in the hybrid sliced-ELL form
+// The stored entries land in ONE pinned staging buffer of the process (host_stage: grow-only, handed out under a lock that the
+// caller holds until its upload has been waited for): [entries] int32 columns, then [entries] double values -- the upload is
+// then one asynchronous copy each at the link's rate instead of the runtime's staging of pageable memory.
+struct HostStage {
+  std::mutex mu;
+  void *p = nullptr;
+  size_t cap = 0;
+};
+HostStage &host_stage();
+void *host_stage_reserve(HostStage &S, size_t bytes);  // (call with S.mu held) nullptr: out of pinned memory
 void amr_assemble_hybrid(int nowned, const int32_t *kind, const int32_t *nbr2, const int32_t *half, std::vector<int32_t> &reg,
-                         std::vector<long long> &ptr, std::vector<int32_t> &ecol, std::vector<double> &eval, int *nregular);
+                         std::vector<long long> &ptr, HostStage &stage, int32_t **ecol, double **eval, int *nregular);
 int matrix_exchange(cup2d_ctx *c, double *vec);         // fill vec[m .. m+halo) from the neighbour ranks
 int project_impl(cup2d_ctx *c, double dt);
 int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_restarts, int max_iter,

@@ -17,6 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_at_world_8_sharing_one_gpu():
     env = dict(os.environ, CUP2D_BENCH_SHARE_GPU="1", CUP2D_BENCH_WATCHDOG_S="200", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):  # (a test that ran a one-rank process group in this
+        env.pop(k, None)                                                           # process leaves them behind: bench.py would take itself for a rank)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "256", "--steps", "2", "--warmup", "1",
            "--layout", "configs3", "--configs3-n", "1024", "--iters", "20", "--no-cpu-baseline"]
     env["CUP2D_BENCH_DETAIL"] = os.path.join(ROOT, "gpurun_out", "bench_detail_world8_test.json")

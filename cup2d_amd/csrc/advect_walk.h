@@ -285,10 +285,24 @@ WALK_HD double rcp_newton(double d) {  // weno.h fast_rcp
 // component of cell 0; consecutive cells are 2 * STRIDE doubles apart.  DOP / DOM: somebody in the tile upwinds with
 // plus / minus (wave-uniform).  tail(cell, d, lap, centre, adv) receives the upwind difference (derivative(),
 // main.cpp:202-208), the second difference, the value of the cell and its advecting velocity.
+// 1 / (a b) from ONE reciprocal: ra = r b, rb = r a with r = rcp_newton(a b).  The weights' denominators are sums of products of
+// squares, >= 1e-21 and -- for velocities below 1e18 in the units of the grid -- far below the overflow of their product.
+// v_rcp_f64 issues at 3.25 x the cost of an FMA on gfx950 (tools/fp64_peak.hip, round 6): two reciprocals the plain way cost
+// 2 x (3.25 + 2), this way 3.25 + 2 + 3.
+WALK_HD void rcp_pair(double a, double b, double &ra, double &rb) {
+  const double r = rcp_newton(a * b);
+  ra = r * b;
+  rb = r * a;
+}
+
+#ifndef WALK_RCP_PAIRS
+#define WALK_RCP_PAIRS 1
+#endif
 template <bool DOP, bool DOM, int STRIDE, class Tail>
 WALK_HD void walk_strip(const double *__restrict__ s, const double *__restrict__ a, Tail &&tail) {
   constexpr double K = 13.0 / 3.0, E4 = 4e-6, THIRD = 1.0 / 3.0;
   constexpr int C0 = DOP ? -1 : 0, C1 = DOM ? 8 : 7, ST = 2 * STRIDE;
+  constexpr bool PAIRS = WALK_RCP_PAIRS != 0;
   // every LDS read of the strip is issued here, ahead of the arithmetic: read where they are used, each one exposes
   // its latency (the walk is one dependent chain per lane and only three waves share a SIMD)
   double v[C1 - C0 + 5], adv[8];
@@ -308,6 +322,9 @@ WALK_HD void walk_strip(const double *__restrict__ s, const double *__restrict__
   // so that its rounding error scales with the differences, not with the values (the reference subtracts two rounded
   // face values, main.cpp:202-208: its own error of ~1e-16 |u| is what the FAST tolerance has to cover).
   double QPm1 = 0, QMm1 = 0, dPm1 = 0;
+  // one-sided upwinding, reciprocals in pairs: the first centre of a pair waits here with what its tail needs
+  double hnum = 0, hden = 1, hlin = 0, hlap = 0, hcen = 0;
+  bool held = false;
 #pragma unroll
   for (int c = C0; c <= C1; c++) {
     const double sE = v[c + 2 - (C0 - 2)];
@@ -317,27 +334,60 @@ WALK_HD void walk_strip(const double *__restrict__ s, const double *__restrict__
     const double b1 = __builtin_fma(t2, t2, m1), b2 = __builtin_fma(t4, t4, m2), b3 = __builtin_fma(t6, t6, m3);
     const double q1 = b1 * b1, q2 = b2 * b2, q3 = b3 * b3;
     const double W1 = q2 * q3, W3 = q1 * q2, X2 = (q1 + q1) * q3;
-    double QP = 0, QM = 0;
-    if (DOP && c <= 7) {
-      const double num = __builtin_fma(W1, a1, __builtin_fma(X2, e2, W3 * __builtin_fma(1.5, e2, h3)));
-      const double den = __builtin_fma(3.0, X2 + W3, W1);
-      QP = num * rcp_newton(den);
+    const bool doP = DOP && c <= 7, doM = DOM && c >= 0;
+    double numP = 0, denP = 1, numM = 0, denM = 1;
+    if (doP) {
+      numP = __builtin_fma(W1, a1, __builtin_fma(X2, e2, W3 * __builtin_fma(1.5, e2, h3)));
+      denP = __builtin_fma(3.0, X2 + W3, W1);
     }
-    if (DOM && c >= 0) {
-      const double num = __builtin_fma(W3, a3, __builtin_fma(X2, e2, W1 * __builtin_fma(1.5, e2, h1)));
-      const double den = __builtin_fma(3.0, X2 + W1, W3);
-      QM = num * rcp_newton(den);
+    if (doM) {
+      numM = __builtin_fma(W3, a3, __builtin_fma(X2, e2, W1 * __builtin_fma(1.5, e2, h1)));
+      denM = __builtin_fma(3.0, X2 + W1, W3);
     }
-    const double dP = (QP - QPm1) + __builtin_fma(0.5, e1, D1);   // plus(c) - plus(c-1): cell c
-    const double dM = (QM - QMm1) + __builtin_fma(-0.5, e2, D1);  // minus(c) - minus(c-1): cell c-1
-    if (DOP && !DOM) {
-      if (c >= 0) tail(c, dP, e2, sC, adv[c < 0 ? 0 : c]);   // U > 0: plus(c) - plus(c-1)
-    } else if (!DOP && DOM) {
-      if (c >= 1) tail(c - 1, dM, e1, sB, adv[c < 1 ? 0 : c - 1]);  // else : minus(c+1) - minus(c)
-    } else {
+    if (DOP && DOM) {  // both sides: the two reciprocals of a centre from one
+      double QP = 0, QM = 0;
+      if (PAIRS && doP && doM) {
+        double rp, rm;
+        rcp_pair(denP, denM, rp, rm);
+        QP = numP * rp;
+        QM = numM * rm;
+      } else {
+        if (doP) QP = numP * rcp_newton(denP);
+        if (doM) QM = numM * rcp_newton(denM);
+      }
+      const double dP = (QP - QPm1) + __builtin_fma(0.5, e1, D1);   // plus(c) - plus(c-1): cell c
+      const double dM = (QM - QMm1) + __builtin_fma(-0.5, e2, D1);  // minus(c) - minus(c-1): cell c-1
       if (c >= 1) tail(c - 1, adv[c < 1 ? 0 : c - 1] > 0 ? dPm1 : dM, e1, sB, adv[c < 1 ? 0 : c - 1]);
+      QPm1 = QP; QMm1 = QM; dPm1 = dP;
+    } else {
+      // one side: the tail of centre c needs Q(c) - Q(c-1) + lin, the second difference and the centre value
+      //   U > 0 : cell c,     plus(c) - plus(c-1),    lin = D1 + e1/2, lap = e2, centre = sC     (c >= 0)
+      //   else  : cell c - 1, minus(c) - minus(c-1),  lin = D1 - e2/2, lap = e1, centre = sB     (c >= 1)
+      const double num = DOP ? numP : numM, den = DOP ? denP : denM;
+      const double lin = DOP ? __builtin_fma(0.5, e1, D1) : __builtin_fma(-0.5, e2, D1);
+      const double lap = DOP ? e2 : e1, cen = DOP ? sC : sB;
+      const int cell = DOP ? c : c - 1;
+      if (!PAIRS) {
+        const double Q = num * rcp_newton(den);
+        if (cell >= 0) tail(cell, (Q - QPm1) + lin, lap, cen, adv[cell < 0 ? 0 : cell]);
+        QPm1 = Q;
+      } else if (!held && c < C1) {  // first of a pair
+        hnum = num; hden = den; hlin = lin; hlap = lap; hcen = cen;
+        held = true;
+      } else if (held) {             // second of a pair: both reciprocals, both tails
+        double r0, r1;
+        rcp_pair(hden, den, r0, r1);
+        const double Q0 = hnum * r0, Q1 = num * r1;
+        if (cell - 1 >= 0) tail(cell - 1, (Q0 - QPm1) + hlin, hlap, hcen, adv[cell - 1 < 0 ? 0 : cell - 1]);
+        if (cell >= 0) tail(cell, (Q1 - Q0) + lin, lap, cen, adv[cell < 0 ? 0 : cell]);
+        QPm1 = Q1;
+        held = false;
+      } else {                       // the odd centre at the end
+        const double Q = num * rcp_newton(den);
+        if (cell >= 0) tail(cell, (Q - QPm1) + lin, lap, cen, adv[cell < 0 ? 0 : cell]);
+        QPm1 = Q;
+      }
     }
-    QPm1 = QP; QMm1 = QM; dPm1 = dP;
     sB = sC; sC = sD; sD = sE;
     D0 = D1; D1 = D2; D2 = D3;
     e1 = e2; e2 = e3; m1 = m2; m2 = m3; a1 = a2; a2 = a3; h1 = h2; h2 = h3;

@@ -953,8 +953,8 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 // same again on every later solve; another process on the same box: 126, 117, 118, 127, ... (tools/gpu_placement_modes.py,
 // tools/gpu_calls/gpu_r04_call18.sh).  Start offsets inside the allocations move nothing, one large
 // allocation carved up is reproducibly the slow mode (round 3).  So the first fused solve of a context on a large grid
-// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 8, within CUP2D_PLACEMENT_MAX_GB = 16 GB and a quarter of the free
-// memory) complete sets of the eleven vectors -- all held while it
+// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 8; three times as many while all of them look alike; within
+// CUP2D_PLACEMENT_MAX_GB = 40 GB and a quarter of the free memory) complete sets of the eleven vectors -- all held while it
 // looks, so that every set is other memory --, times three iterations' worth of the two launches on each (the MERGE 0
 // instances on zero-filled vectors with a scratch scalar record: no reduction finish, nothing of the context's state
 // touched), keeps the fastest set and gives the others back: 2 ms per set at 4096^2, once per context.  A set in the fast
@@ -963,7 +963,7 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 static int tune_placement(cup2d_ctx *c) {
   static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 8; }();
   // what the search may hold beyond the context's own set while it looks (per process: ranks that share a GPU each search)
-  static const double budget_gb = [] { const char *e = getenv("CUP2D_PLACEMENT_MAX_GB"); return e ? atof(e) : 16.0; }();
+  static const double budget_gb = [] { const char *e = getenv("CUP2D_PLACEMENT_MAX_GB"); return e ? atof(e) : 40.0; }();
   if (c->placement_tuned) return CUP2D_OK;
   c->placement_tuned = true;
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
@@ -976,6 +976,11 @@ static int tune_placement(cup2d_ctx *c) {
   const size_t budget = std::min((size_t)(budget_gb * (double)((size_t)1 << 30)), free_b / 4);  // never more than a quarter of what is free
   while (tries > 1 && (size_t)(tries - 1) * NV * bytes > budget) tries--;
   if (tries <= 1) return CUP2D_OK;
+  // Sets that all look alike (within 4 %) are all in ONE mode -- the two modes lie 10 % apart --, and with one set in six fast
+  // (profiles/r06_placement_vmm.txt) eight alike are as likely all slow as not: the search then goes on, up to three times as
+  // many sets within the same budget, and stops at the first one that is 5 % faster than everything before it
+  int tries_more = 3 * tries > 48 ? 48 : 3 * tries;
+  while (tries_more > tries && (size_t)(tries_more - 1) * NV * bytes > budget) tries_more--;
   StageClock clk("tune_placement");
   // Candidate kinds: the context's own vectors (set 0); ARENAS -- one allocation carved into the eleven vectors at a stride of
   // bytes + pad, for every pad of CUP2D_PLACEMENT_ARENA="pad,pad,..." (bytes; experiment: a vector is 2^27 bytes at 4096^2, and
@@ -994,7 +999,7 @@ static int tune_placement(cup2d_ctx *c) {
     return v;
   }();
   struct Cand { double *v[NV]; float ms; void *arena; long long pad; };
-  std::vector<Cand> cand((size_t)tries);
+  std::vector<Cand> cand((size_t)tries_more);
   for (auto &C : cand) { C.arena = nullptr; C.pad = -1; C.ms = 0.f; }
   for (int k = 0; k < NV; k++) cand[0].v[k] = *slot[k];
   cand[0].arena = c->vec_arena;
@@ -1035,7 +1040,9 @@ static int tune_placement(cup2d_ctx *c) {
   };
   // (the context's own vectors may hold anything: the probe computes on what is there; values do not change a duration)
   rc = probe(cand[0]);
-  for (int q = 1; q < tries && rc == CUP2D_OK; q++) {
+  float lo_ms = cand[0].ms, hi_ms = cand[0].ms;
+  for (int q = 1; q < tries_more && rc == CUP2D_OK; q++) {
+    if (q >= tries && (hi_ms - lo_ms > 0.04f * lo_ms)) break;  // two modes seen (or a clearly faster set found): decided
     bool ok = true;
     for (int k = 0; k < NV; k++) cand[q].v[k] = nullptr;
     if ((size_t)(q - 1) < arena_pads.size()) {
@@ -1059,6 +1066,10 @@ static int tune_placement(cup2d_ctx *c) {
       break;
     }
     rc = probe(cand[q]);
+    if (rc == CUP2D_OK) {
+      lo_ms = cand[q].ms < lo_ms ? cand[q].ms : lo_ms;
+      hi_ms = cand[q].ms > hi_ms ? cand[q].ms : hi_ms;
+    }
   }
   int best = 0;
   float worst = cand[0].ms;

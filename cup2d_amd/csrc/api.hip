@@ -865,6 +865,10 @@ int cup2d_project(cup2d_ctx *c, double dt) {
 int cup2d_max_abs_vel(cup2d_ctx *c, double *umax) {
   CUP2D_CHECK_CTX(c);
   if (!umax) return CUP2D_ERR_ARG;
+  if (c->use_cached_umax && c->umax_on_host) {  // ... already reduced and copied behind that projection (cup2d_step)
+    *umax = c->h_red[6];
+    return CUP2D_OK;
+  }
   if (c->use_cached_umax)  // the maxima the previous step's projection left (ctx.h umax_partials)
     CUP2D_TRY(launch_max_from_partials(c, c->d_partials + (size_t)3 * PSTRIDE, c->umax_partials, c->d_red));
   else
@@ -1359,14 +1363,30 @@ static int step_impl(cup2d_ctx *c, double nu, double cfl, double max_error, doub
   } else {
     CUP2D_TRY(cup2d_poisson_rhs(c, dt, 0));
   }
-  c->solve_tail = [](cup2d_ctx *cc, double dt_) { return cup2d_project(cc, dt_); };
+  // ... and behind the projection the maximum of its per-workgroup max|u| (what the NEXT step's dt is made of) on its way to
+  // the host: the solve's final wait covers it, and a step that follows at once starts without a launch or a wait of its own
+  // (one rank; on N ranks the all-reduce of the maximum stays where it is)
+  c->solve_tail = [](cup2d_ctx *cc, double dt_) -> int {
+    const int rc_p = cup2d_project(cc, dt_);
+    if (rc_p != CUP2D_OK) return rc_p;
+    if (!cc->amr.active && !cc->allreduce && cc->umax_partials > 0) {
+      CUP2D_TRY(launch_max_from_partials(cc, cc->d_partials + (size_t)3 * PSTRIDE, cc->umax_partials, cc->d_partials + (size_t)5 * PSTRIDE));
+      CUP2D_HIP_CHECK(hipMemcpyAsync(cc->h_red + 6, cc->d_partials + (size_t)5 * PSTRIDE, sizeof(double), hipMemcpyDeviceToHost, cc->stream));
+      cc->umax_on_host = true;
+    }
+    return CUP2D_OK;
+  };
   c->solve_tail_arg = dt;
   c->solve_tail_ran = false;
+  c->umax_on_host = false;
   const int rc_solve = cup2d_poisson_solve(c, max_error, max_rel_error, max_restarts, max_iter, iters, nullptr, linf, nullptr);
   c->x0_is_zero = false;
   c->solve_tail = nullptr;
   CUP2D_TRY(rc_solve);
-  if (!c->solve_tail_ran) CUP2D_TRY(cup2d_project(c, dt));  // (solvers that wait for their end before the last pass)
+  if (!c->solve_tail_ran) {  // (solvers that wait for their end before the last pass: nothing waits behind this projection)
+    c->umax_on_host = false;
+    CUP2D_TRY(cup2d_project(c, dt));
+  }
   c->umax_valid_at = c->api_calls;  // (umax_partials > 0 only if the same-level projection kernel wrote them)
   if (dt_out) *dt_out = dt;
   return CUP2D_OK;

@@ -203,6 +203,7 @@ struct cup2d_ctx {
   unsigned long long api_calls = 0, umax_valid_at = ~0ull;
   int umax_partials = 0;
   bool vel_ptr_exposed = false, use_cached_umax = false;
+  bool umax_on_host = false;  // cup2d_step reduced those maxima behind its projection and h_red[6] holds the result (valid with use_cached_umax)
   int *h_status = nullptr;               // pinned [SOLVE_AHEAD], written by the last scalar kernel of an iteration
   hipEvent_t solve_ev[SOLVE_AHEAD] = {nullptr};
   double *h_red = nullptr;               // pinned [8]

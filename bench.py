@@ -935,10 +935,12 @@ def main():
         tr = traffic_tab.get(KERNEL_OF[fam], {}).get("hbm_bytes") if (nx, ny) == (4096, 4096) and world == 1 else None
         if fam == "advect_stage" and walk and (nx, ny) == (4096, 4096) and world == 1:
             # the two RK stages are two instantiations; per launch of the family = their mean (one launch each per step)
-            both = [traffic_tab.get("k_advect_walk<1, %s>" % b, {}).get("hbm_bytes") for b in ("true", "false")]
+            # (round 6: the instantiations carry the knock-out parameter: <1, true, 0> is the product)
+            both = [(traffic_tab.get("k_advect_walk<1, %s, 0>" % b) or traffic_tab.get("k_advect_walk<1, %s>" % b, {})).get("hbm_bytes")
+                    for b in ("true", "false")]
             if all(both):
                 tr = 0.5 * (both[0] + both[1])
-                traffic_src[KERNEL_OF[fam]] = traffic_src.get("k_advect_walk<1, true>")
+                traffic_src[KERNEL_OF[fam]] = traffic_src.get("k_advect_walk<1, true, 0>") or traffic_src.get("k_advect_walk<1, true>")
         return {"kernel": KERNEL_OF[fam], "family": fam, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
                 "traffic": tr,

@@ -1295,6 +1295,7 @@ int cup2d_amr_install_poisson(cup2d_ctx *c) {
   const size_t entries = (size_t)ptr[(size_t)c->nblocks];
   if (entries && !ecol) { set_error("amr_install_poisson: no pinned staging buffer for %zu entries", entries); return CUP2D_ERR_HIP; }
   const int rc = install_sell(c, c->nghost * BC, true, reg, ptr, ecol, eval, entries, true, nregular);
+  if (rc != CUP2D_OK) (void)hipStreamSynchronize(c->stream);  // (a copy out of the staging buffer may be in flight: not while the lock goes)
   clk.lap("install_sell");
   return rc;
 }

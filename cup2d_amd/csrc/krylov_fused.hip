@@ -978,7 +978,7 @@ static int tune_placement(cup2d_ctx *c) {
   if (tries <= 1) return CUP2D_OK;
   // Sets that all look alike (within 4 %) are all in ONE mode -- the two modes lie 10 % apart --, and with one set in six fast
   // (profiles/r06_placement_vmm.txt) eight alike are as likely all slow as not: the search then goes on, up to three times as
-  // many sets within the same budget, and stops at the first one that is 5 % faster than everything before it
+  // many sets within the same budget, and stops as soon as the sets timed so far are more than 4 % apart (a second mode has shown)
   int tries_more = 3 * tries > 48 ? 48 : 3 * tries;
   while (tries_more > tries && (size_t)(tries_more - 1) * NV * bytes > budget) tries_more--;
   StageClock clk("tune_placement");

@@ -459,6 +459,13 @@ def nrank_proxy_leg(args, device, nbx, nby, plain_elapsed, plain_steps):
                                     "eight_ranks_over_one_gpu": [round(8 * v / one, 2) if v else None for v in (rank4, rank2)]}
     except Exception as e:  # informative
         out["configs3_on_paper"] = {"error": str(e)[:120]}
+    # the weak series on paper (4096^2 cells per rank, the bench's default layout at N > 1): 8 ranks of the headline patch against the
+    # plain context of the same size = 8 / ratio, with ghost blocks on four sides and on two
+    try:
+        out["weak_on_paper"] = {"eight_ranks_over_one_gpu": [round(8.0 / out["ratio_to_plain"], 2), round(8.0 / others[0]["ratio_to_plain"], 2)],
+                                "patches": ["%s_%s" % (out["blocks"], out["ghost_sides"]), "%s_%s" % (others[0]["blocks"], others[0]["ghost_sides"])]}
+    except Exception as e:  # informative
+        out["weak_on_paper"] = {"error": str(e)[:120]}
     return out
 
 
@@ -641,7 +648,7 @@ def compact_line(full, detail_path):
                 return {k: p.get(k) for k in ("ms_per_step", "plain_context_ms_per_step", "ratio_to_plain", "fixed_us_per_iteration_over_plain",
                                               "outside_the_sweeps_us_per_iteration", "value", "form")}
             S["nrank_path_on_one_gpu"] = {"%s_%s" % (p.get("blocks"), p.get("ghost_sides")): patch(p) for p in [nr] + list(nr.get("other_patches") or [])}
-            for k in ("configs3_on_paper",):
+            for k in ("configs3_on_paper", "weak_on_paper"):
                 if nr.get(k):
                     S["nrank_path_on_one_gpu"][k] = nr[k]
     pl = full.get("placement") or {}

@@ -38,7 +38,7 @@ with open(d + "/stats_full_launches.csv", "w") as o:
 PY
 # the step as the GPU saw it (from the same trace), then drop the raw trace
 f=$(find $OUT/prof_$TAG -name "stats_kernel_trace.csv" | head -1)
-python3 tools/kernel_step_timeline.py $f "k_pressure_rhs" 2>&1 | head -24 | tee $OUT/r06_4096_step_timeline.txt
+python3 tools/kernel_step_timeline.py $f "k_pressure_rhs" 3 2>&1 | head -24 | tee $OUT/r06_4096_step_timeline.txt
 rm -f $f
 STEPS=3 python3 tools/prof_summary.py $TAG 2>&1 | tail -4
 # ---- N-rank timelines ----

@@ -1,5 +1,9 @@
 // ctx.h -- context object and launch helpers shared by the translation units of libcup2d_hip.so
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <system_error>
 #include <thread>
 #include <chrono>
@@ -336,6 +340,46 @@ inline int chunk_count(long long n, long long grain) {
   if (nt > host_threads()) nt = host_threads();
   return (int)(nt < 1 ? 1 : nt);
 }
+// The threads are a POOL of the process (round 6): a regrid runs a dozen of these regions, and sixteen std::thread
+// constructions per region cost it 2-3 ms on a 256-thread host.  Workers are created on first use, detached, and wait on a
+// condition variable; a region is an object of its own (workers that come late for one see its task counter exhausted), one
+// region runs at a time -- a second caller, or a region started from inside a task, runs its chunks serially.
+struct HostRegion {
+  std::function<void(int)> job;
+  int ntasks = 0;
+  std::atomic<int> next{0}, done{0};
+};
+struct HostThreads {
+  std::mutex region_mu;  // one parallel region at a time
+  std::mutex mu;
+  std::condition_variable cv;
+  std::shared_ptr<HostRegion> cur;
+  unsigned long long gen = 0;
+  int nworkers = 0;
+};
+inline HostThreads &host_thread_pool() {
+  static HostThreads *P = new HostThreads;  // (never destroyed: detached workers may be waiting on it when the process ends)
+  return *P;
+}
+inline void host_thread_worker(HostThreads *P) {
+  unsigned long long seen = 0;
+  for (;;) {
+    std::shared_ptr<HostRegion> R;
+    {
+      std::unique_lock<std::mutex> lk(P->mu);
+      P->cv.wait(lk, [&] { return P->gen != seen; });
+      seen = P->gen;
+      R = P->cur;
+    }
+    if (!R) continue;
+    for (;;) {
+      const int t = R->next.fetch_add(1);
+      if (t >= R->ntasks) break;
+      R->job(t);
+      R->done.fetch_add(1);
+    }
+  }
+}
 template <class F>
 inline void parallel_chunks(long long n, long long grain, F fn) {
   const long long nt = chunk_count(n, grain);
@@ -343,19 +387,41 @@ inline void parallel_chunks(long long n, long long grain, F fn) {
     fn(0LL, n, 0);
     return;
   }
-  // a thread that cannot be created (std::system_error: the process is out of threads) must not take the process down from
-  // inside a C ABI call: the chunks that found no thread run here, serially
-  std::vector<std::thread> th;
-  long long started = 0;
-  try {
-    for (; started < nt; started++) {
-      const long long t = started;
-      th.emplace_back([=] { fn(n * t / nt, n * (t + 1) / nt, (int)t); });
-    }
-  } catch (const std::system_error &) {
+  HostThreads &P = host_thread_pool();
+  std::unique_lock<std::mutex> region(P.region_mu, std::try_to_lock);
+  if (!region.owns_lock()) {  // another region is running (or this is a task of one): the chunks here, one after the other
+    for (long long t = 0; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, (int)t);
+    return;
   }
-  for (long long t = started; t < nt; t++) fn(n * t / nt, n * (t + 1) / nt, (int)t);
-  for (auto &x : th) x.join();
+  auto R = std::make_shared<HostRegion>();
+  R->ntasks = (int)nt;
+  R->job = [&fn, n, nt](int t) { fn(n * t / nt, n * (t + 1) / nt, t); };
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    // a thread that cannot be created (std::system_error: the process is out of threads) must not take the process down from
+    // inside a C ABI call: the chunks that find no worker run on the caller
+    try {
+      while (P.nworkers < (int)nt - 1) {
+        std::thread(host_thread_worker, &P).detach();
+        P.nworkers++;
+      }
+    } catch (const std::system_error &) {
+    }
+    P.cur = R;
+    P.gen++;
+  }
+  P.cv.notify_all();
+  for (;;) {  // the caller takes chunks too
+    const int t = R->next.fetch_add(1);
+    if (t >= R->ntasks) break;
+    R->job(t);
+    R->done.fetch_add(1);
+  }
+  while (R->done.load() < R->ntasks) std::this_thread::yield();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.cur.reset();  // (fn dies with this call: nobody may find the region any more; late workers hold their own reference)
+  }
 }
 
 // regrid-time host work, stage by stage, on stderr when CUP2D_HOST_TIMING is set (development aid)

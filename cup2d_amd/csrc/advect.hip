@@ -329,6 +329,15 @@ int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *o
   return CUP2D_OK;
 }
 
+int launch_advect_walk_rhs(cup2d_ctx *c, const double *vel, double *out, const int32_t *d_quads, int nq, double afac, double dfac) {
+  if (nq <= 0) return CUP2D_OK;
+  const walk::V2 *wv = (const walk::V2 *)vel;
+  hipLaunchKernelGGL((k_advect_walk<0, false, 0>), dim3(resident_grid(c, reinterpret_cast<const void *>(&k_advect_walk<0, false, 0>), nq)),
+                     dim3(WG), 0, c->stream, wv, wv, out, d_quads, nq, 0, afac, dfac, 1);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 // KernelVorticity main.cpp:3343-3366: tmp = (0.5/h) * (u_S - u_N + v_E - v_W)
 __global__ __launch_bounds__(WG) void k_vorticity(const double2 *__restrict__ vel, double *__restrict__ out,
                                                   const int *__restrict__ nbr, int first, int count, double i2h) {

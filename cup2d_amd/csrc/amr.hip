@@ -21,6 +21,7 @@
 // irregular sides gather from other blocks through global memory -- this is the first, parity-first version of
 // the AMR path; its tuning follows the uniform path's.
 #include "advect_tile.h"
+#include "advect_walk.h"
 #include "amr_ghost.h"
 #include "block.h"
 
@@ -336,6 +337,78 @@ void amr_phase_release(cup2d_ctx *c) {
     dev_free(P.d_inner); dev_free(P.d_halo);
     P = AmrTopo::Phase();
   }
+  for (int32_t *q : c->amr.quads.d_quads) dev_free(q);
+  dev_free(c->amr.quads.d_left);
+  c->amr.quads = AmrTopo::Quads();
+}
+// The quads of an adapted grid (ctx.h AmrTopo::Quads): four CONSECUTIVE blocks of one level that form a 2 x 2 group by their own
+// links (the four children of a parent are consecutive in the reference's Hilbert order; any such group will do) and whose eight
+// outer sides are domain walls or same-level blocks -- the tile of the quad kernel is then exactly the uniform grid's: ghost
+// layers copied from the neighbour blocks, the wall-normal component flipped at a wall, no corner read (main.cpp:2270-2687 for
+// same-level sides, 3131-3204).  One scan of the tables; the plan entry is advect_walk.h's (build_plan).
+static int amr_quads(cup2d_ctx *c, const AmrTopo::Quads **out) {
+  AmrTopo &A = c->amr;
+  AmrTopo::Quads &Q = A.quads;
+  *out = &Q;
+  if (Q.built) return CUP2D_OK;
+  const int nb = c->nblocks;
+  const auto K = [&](int b, int s) { return A.h_kind[(size_t)4 * b + s]; };
+  const auto NB = [&](int b, int s) { return A.h_nbr2[((size_t)4 * b + s) * 2]; };
+  const auto eligible = [&](int b) {
+    for (int s = 0; s < 4; s++)
+      if (K(b, s) != CUP2D_AMR_WALL && K(b, s) != CUP2D_AMR_SAME) return false;
+    return true;
+  };
+  std::vector<std::vector<int32_t>> per_level(32);
+  std::vector<int32_t> left;
+  for (int b = 0; b < nb;) {
+    bool ok = b + 3 < nb;
+    for (int k = 0; ok && k < 4; k++) ok = A.h_level[(size_t)b + k] == A.h_level[(size_t)b] && eligible(b + k);
+    int sw = -1, se = -1, nw = -1, ne = -1;
+    const auto in = [&](int x) { return x >= b && x < b + 4; };
+    const auto same_in = [&](int o, int s) { return K(o, s) == CUP2D_AMR_SAME && in(NB(o, s)); };
+    if (ok) {
+      int found = 0;
+      for (int k = 0; k < 4; k++)
+        if (same_in(b + k, 1) && same_in(b + k, 3)) { sw = b + k; found++; }
+      ok = found == 1;
+    }
+    if (ok) {
+      se = NB(sw, 1);
+      nw = NB(sw, 3);
+      ok = se != nw && same_in(se, 3);
+      if (ok) ne = NB(se, 3);
+      ok = ok && ne != sw && ne != se && ne != nw && same_in(nw, 1) && NB(nw, 1) == ne && same_in(se, 0) && NB(se, 0) == sw &&
+           same_in(nw, 2) && NB(nw, 2) == sw && same_in(ne, 0) && NB(ne, 0) == nw && same_in(ne, 2) && NB(ne, 2) == se;
+    }
+    if (!ok) {
+      left.push_back(b);
+      b++;
+      continue;
+    }
+    const auto outer = [&](int o, int s) -> int32_t { return K(o, s) == CUP2D_AMR_SAME ? NB(o, s) : -1 - o; };  // a wall: -1 - (own block)
+    const int32_t e[walk::QINTS] = {sw, se, nw, ne, outer(sw, 0), outer(nw, 0), outer(se, 1), outer(ne, 1),
+                                    outer(sw, 2), outer(se, 2), outer(nw, 3), outer(ne, 3)};
+    std::vector<int32_t> &L = per_level[(size_t)A.h_level[(size_t)b]];
+    L.insert(L.end(), e, e + walk::QINTS);
+    b += 4;
+  }
+  for (int l = 0; l < 32; l++) {
+    if (per_level[(size_t)l].empty()) continue;
+    int32_t *d = nullptr;
+    CUP2D_HIP_CHECK(dev_malloc(&d, per_level[(size_t)l].size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(d, per_level[(size_t)l].data(), per_level[(size_t)l].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    Q.level.push_back(l);
+    Q.nq.push_back((int)(per_level[(size_t)l].size() / walk::QINTS));
+    Q.d_quads.push_back(d);
+  }
+  Q.nleft = (int)left.size();
+  if (Q.nleft) {
+    CUP2D_HIP_CHECK(dev_malloc(&Q.d_left, left.size() * sizeof(int32_t)));
+    CUP2D_HIP_CHECK(hipMemcpy(Q.d_left, left.data(), left.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  Q.built = true;
+  return CUP2D_OK;
 }
 // One block functor over the phases of `blocks` (ctx.h): launch(list, n) runs it on n blocks (list == nullptr: blocks 0 .. n-1).
 // ALL on N ranks: `field` (the last of the fields the functor reads across block sides; the others were refreshed by the
@@ -561,6 +634,24 @@ int amr_project(cup2d_ctx *c, double dt) {
 // tmpV = KernelAdvectDiffuse(vel) with the flux correction (main.cpp:6611-6617 / 6627-6633)
 int amr_advect_diffuse_rhs(cup2d_ctx *c, const double *vel, double *tmpV, double nu, double dt, int blocks) {
   const AmrDev T = amr_dev(c);
+  // one rank, FAST arithmetic, all blocks: the quads through the quad kernel, level by level (afac = -dt h), the other blocks
+  // through the per-block kernel with the interpolated tile (CUP2D_ADVECT_WALK=0: every block through that one)
+  static const bool use_walk = [] { const char *e = getenv("CUP2D_ADVECT_WALK"); return !e || atoi(e) != 0; }();
+  if (use_walk && c->math != CUP2D_MATH_STRICT && blocks == CUP2D_BLOCKS_ALL && c->nghost == 0 && ((size_t)c->ntotal << 10) < (1ull << 32)) {
+    const AmrTopo::Quads *Q = nullptr;
+    CUP2D_TRY(amr_quads(c, &Q));
+    for (size_t k = 0; k < Q->level.size(); k++) {
+      const double h = c->amr.h0 / (double)(1 << Q->level[k]);
+      CUP2D_TRY(launch_advect_walk_rhs(c, vel, tmpV, Q->d_quads[k], Q->nq[k], -dt * h, nu * dt));  // main.cpp:5446-5447
+    }
+    if (Q->nleft)
+      hipLaunchKernelGGL(k_amr_advect<WenoFast>, dim3(amr_grid(c, Q->nleft)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV, T,
+                         c->amr.d_faces2, Q->nleft, nu, dt, (const int32_t *)Q->d_left);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_amr_fillcases2, dim3(amr_grid(c)), dim3(WG), 0, c->stream, (double2 *)tmpV, T, c->amr.d_faces2, c->nblocks);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    return CUP2D_OK;
+  }
   CUP2D_TRY(amr_phased(c, blocks, vel, 2, CUP2D_CELLS_HALO3, [&](const int32_t *list, int n) {
     if (c->math == CUP2D_MATH_STRICT)
       hipLaunchKernelGGL(k_amr_advect<WenoStrict>, dim3(amr_grid(c, n)), dim3(WG), 0, c->stream, (const double2 *)vel, (double2 *)tmpV,

@@ -722,6 +722,7 @@ int cup2d_set_amr(cup2d_ctx *c, double h0, const int32_t *level, const int32_t *
   A.h_kind.assign(kind, kind + (size_t)nb * 4);
   A.h_nbr2.assign(nbr2, nbr2 + (size_t)nb * 8);
   A.h_half.assign(half, half + (size_t)nb * 4);
+  A.h_level.assign(level, level + (size_t)nb);
   A.h0 = h0;
   int lmax = 0;
   for (int b = 0; b < nb; b++) lmax = level[b] > lmax ? level[b] : lmax;

@@ -133,6 +133,17 @@ struct AmrTopo {
   double *d_faces = nullptr;     // [nblocks][4][8] fluxes recorded by the functors (BlockCase::d, main.cpp:513-517)
   double *d_faces2 = nullptr;    // [nblocks][4][8][2] the same for vector functors (KernelAdvectDiffuse)
   std::vector<int32_t> h_kind, h_nbr2, h_half;  // host copies: cup2d_amr_install_poisson assembles from them
+  std::vector<int32_t> h_level;
+  // One rank, FAST arithmetic: the same-level 2 x 2 groups of blocks whose eight outer sides are walls or same-level blocks take
+  // the quad form of KernelAdvectDiffuse (advect_walk.h; one list per level: h differs), everything else the per-block kernel
+  // with the interpolated tile (amr.hip amr_quads; built on first use)
+  struct Quads {
+    bool built = false;
+    std::vector<int> level, nq;
+    std::vector<int32_t *> d_quads;
+    int32_t *d_left = nullptr;
+    int nleft = 0;
+  } quads;
   // N ranks: the owned blocks by whether their operators read a ghost block (computeA's inner / halo split on an adapted
   // grid, main.cpp:3035-3057), per operator family: 0 the halo-1 operators, 1 the halo-3 tile (amr.hip amr_phase_lists; built
   // on first use from the kernels' own ghost expressions)
@@ -304,6 +315,8 @@ struct ProfScope {
 // implemented in the kernel translation units
 int launch_advect(cup2d_ctx *c, const double *vel, const double *vold, double *out, int mode, double nu,
                   double dt, double coef, int first, int count);
+// MODE 0 of the quad kernel (out = rhs) on a caller's quad list with the caller's coefficients (adapted grids: amr.hip)
+int launch_advect_walk_rhs(cup2d_ctx *c, const double *vel, double *out, const int32_t *d_quads, int nq, double afac, double dfac);
 int launch_vorticity(cup2d_ctx *c, const double *vel, double *out, int first, int count);
 int launch_pressure_rhs(cup2d_ctx *c, const double *vel, const double *udef, const double *chi,
                         const double *pold, double *out, double dt, int first, int count, double *pold_copy = nullptr);

@@ -103,9 +103,22 @@ class AmrSimulation(BodyOps):
         """the cup2d_ctx* of this simulation (for C-ABI calls that take two contexts)"""
         return self._ctx
 
-    def set_solver(self, fused=False, finish_in_kernel=False):
-        self._solver = (bool(fused), bool(finish_in_kernel))
+    def set_solver(self, fused=False, finish_in_kernel=False, form=None):
+        """form: 'auto' | 'full' | 'edge' | 'eab' (cup2d_set_solver_form; None leaves it as it is).  On the hybrid operator of an
+        adapted grid 'auto' / 'eab' with the finish in the kernel = two sweeps + two rows launches per iteration (k_edge HYB),
+        'full' = three sweeps + two (k_fused HYB)"""
+        if form is None and self._solver is not None and len(self._solver) > 2:
+            form = self._solver[2]  # (kept across the contexts a regrid creates)
+        self._solver = (bool(fused), bool(finish_in_kernel), form)
         _l.check(self.L.cup2d_set_solver(self._ctx, _l.SOLVER_FUSED if fused else _l.SOLVER_SWEEPS, int(finish_in_kernel)), "set_solver")
+        if form is not None:
+            _l.check(self.L.cup2d_set_solver_form(self._ctx, ("auto", "full", "edge", "eab").index(form)), "set_solver_form")
+
+    def last_solver_form(self):
+        """(form, merge, handover mask) of the last fused solve (cup2d_get_last_solver_form): form 'full' | 'edge' | 'eab'"""
+        f, m, h = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _l.check(self.L.cup2d_get_last_solver_form(self._ctx, ctypes.byref(f), ctypes.byref(m), ctypes.byref(h)), "get_last_solver_form")
+        return ("none", "full", "edge", "eab")[f.value], m.value, h.value
 
     def last_solver(self):
         """'fused' or 'sweeps': what the last poisson_solve ran (the hybrid assembled operator takes the tile-fused sweeps)"""

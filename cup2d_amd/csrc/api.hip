@@ -1119,6 +1119,9 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
       for (int s = tile0[t]; s < tile0[t + 1]; s++) general = general || stored(s);
       is_general[(size_t)t] = general;
       if (!general) continue;
+      // (every block of a general tile, the plain ones too.  Round 6 left only the slices with stored rows to k_hyb_rows and swept
+      // the plain blocks of these tiles with the tile: the rows launches 14.0 -> 12.6 us -- they are a chain of a dozen memory
+      // round trips, not work --, the sweeps 42.9 -> 45.7 and 29.3 -> 31.3 us: general tiles then have ring entries; not kept)
       for (int s = tile0[t]; s < tile0[t + 1]; s++) {
         gen.push_back(s);
         for (int side = 0; side < 4; side++) fnbr[(size_t)4 * s + side] = FUSED_GENERAL;
@@ -1149,6 +1152,25 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
         for (int t = 0; t < ntiles; t++) M.h_zmask[(size_t)t] |= zm[(size_t)t];
     M.ntiles = ntiles;
     clk.lap("tiling");
+    if (clk.on) {
+      int ngt = 0, nzt = 0, nshort = 0, ring_max = 0;
+      long long ring_sum = 0;
+      for (int t = 0; t < ntiles; t++) {
+        ngt += is_general[(size_t)t];
+        nzt += M.h_zmask[(size_t)t] != 0;
+        nshort += tile0[t + 1] - tile0[t] < FUSED_TILE;
+        int ring = 0;
+        for (int s = tile0[t]; s < tile0[t + 1]; s++)
+          for (int side = 0; side < 4; side++) {
+            const int32_t nb_ = fnbr[(size_t)4 * s + side];
+            ring += nb_ >= 0 && (nb_ < tile0[t] || nb_ >= tile0[t + 1]);
+          }
+        ring_sum += ring;
+        ring_max = ring > ring_max ? ring : ring_max;
+      }
+      fprintf(stderr, "[cup2d timing] install_sell: %d tiles: %d general, %d with z to store, %d shorter than %d blocks; ring entries %.1f on average, %d at most\n",
+              ntiles, ngt, nzt, nshort, FUSED_TILE, (double)ring_sum / ntiles, ring_max);
+    }
     CUP2D_HIP_CHECK(dev_malloc(&M.d_tile0, tile0.size() * sizeof(int32_t)));
     CUP2D_HIP_CHECK(hipMemcpy(M.d_tile0, tile0.data(), tile0.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     CUP2D_HIP_CHECK(dev_malloc(&M.d_fnbr, fnbr.size() * sizeof(int32_t)));

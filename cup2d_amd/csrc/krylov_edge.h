@@ -94,6 +94,31 @@ static __device__ __forceinline__ void edge_precond(double *S, const double *PE,
   wave_lds_sync();
 }
 
+// HYB: S (v of 16 blocks, block-major) -> S (z = P_inv v of those blocks, block-major): the FULL 64 x 64 product of k_fused's
+// tile_precond -- same fragment maps, same k order: the same bits -- for the tiles of the hybrid operator whose z somebody reads
+// from memory (the general tiles and the blocks their rows reach: a quarter of the tiles of an adapted grid).  This kernel's LDS
+// holds the edge columns only (the staging tiles fill the rest), so the B fragments come from P_inv in memory: 32 KB that every
+// such tile of every workgroup reads, i.e. from the L2.
+static __device__ __forceinline__ void full_precond_mem(double *S, const double *__restrict__ Pinv, int lane) {
+  const int ablk = lane & 15, akk = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) acc[nt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int ks = 0; ks < 16; ks++) {
+    const double xa = S[ablk * XS + 4 * ks + akk];
+    const double *pr = Pinv + (4 * ks + akk) * BC + ablk;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, pr[16 * nt], acc[nt], 0, 0, 0);
+  }
+  wave_lds_sync();  // every lane has read its operands before the tile is overwritten
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) S[(akk + 4 * v) * XS + 16 * nt + ablk] = acc[nt][v];
+  wave_lds_sync();
+}
+
 // bit `lane` of a wave mask (no 1 << lane held in two registers across the loop)
 static __device__ __forceinline__ bool mask_bit(unsigned long long m, int lane) {
   const unsigned half = lane < 32 ? (unsigned)m : (unsigned)(m >> 32);
@@ -132,7 +157,15 @@ static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int 
 //                      rho' = rhat.(s - omega t) = rhat.s - omega rhat.t and ||r'||^2 = s.s - 2 omega t.s + omega^2 t.t
 // Jobs, batches, load schedule and cache policy as in k_fused (krylov_fused.hip); what differs is the job's product (edge
 // columns only, for the tile's own blocks too), where a ghost edge comes from, and the epilogue.
-template <int MODE, int MERGE>
+// HYB (MODE 2 / 3, one rank): the hybrid assembled operator of an adapted grid (ctx.h SellMatrix; nbr = its d_fnbr, count = its
+// number of tiles, A.tile0 / A.zmask / A.zg).  The identity holds on every PLAIN block (same-level or wall sides: its rows are
+// the 5-point rows), so a tile of plain blocks is swept exactly as on a uniform grid.  A block marked FUSED_GENERAL (the table
+// marks every block of a tile that holds a slice with stored coarse-fine rows) gets everything that is a function of its own
+// cells here -- y', r', p'' and their sums (MODE 2), the sums of s (MODE 3) --; its rows (nu'' or t and the dot products with
+// them) are k_hyb_rows' in the launch behind this one, from z in memory: a tile with blocks those rows read (zmask) forms
+// z = P_inv v of its blocks in full and stores theirs.  Two sweeps + two short rows launches per iteration where the full form (k_fused HYB) has three
+// sweeps + two: 112 instead of 136 B/cell.  No sharing between sibling waves (the tiles are not aligned runs of 16).
+template <int MODE, int MERGE, bool HYB = false>
 __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__restrict__ Pinv,
                                                  const int *__restrict__ nbr, KrylovScalars *sc, double *partials,
                                                  int first, int count, int poff, int share, double *red, unsigned *ticket,
@@ -221,7 +254,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   };
 
   // tiles of 16 blocks; the 8 waves of a workgroup take 8 consecutive tiles per round, contiguous ranges per XCD
-  const int ntiles = (count + TB - 1) / TB;
+  const int ntiles = HYB ? count : (count + TB - 1) / TB;
   int t_begin, t_end, t_stride;
   {
     const int G = gridDim.x, w = blockIdx.x;
@@ -253,6 +286,11 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
   const int si = lane >> 2, ss = lane & 3;  // this lane's (block, side) slot of a tile
   const int last = first + count;
   const auto load_nb = [&](int t) -> int {
+    if constexpr (HYB) {
+      if (t >= t_end) return CUP2D_WALL;
+      const int b0 = uniform(A.tile0[t]), nv = uniform(A.tile0[t + 1]) - b0;
+      return si < nv ? nbr[4 * (b0 + si) + ss] : CUP2D_WALL;
+    }
     const int b = first + t * TB + si;
     return (t < t_end && b < last) ? nbr[4 * b + ss] : CUP2D_WALL;
   };
@@ -260,23 +298,31 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     unsigned long long pmask;               // the tile's perimeter slots (neighbour = a block outside the tile)
     int b0, nvalid, nb, nring, npass, sib;  // sib: the sibling wave whose tile holds this slot's neighbour, or -1
     int is_ring, pad;                       // ... of which the ones to recompute (no tail padding: copies stay in registers)
+                                            // pad, HYB: zmask of the tile | (bit b: block b has stored rows) << 16
   };
   // classify the 64 (block, side) neighbour slots of tile t and write its ring list (overwrites the previous tile's)
   // share: edges of the siblings of the same round are taken from their exports (a wait per sibling)
   const bool share_now = (share & 1) != 0;
   const auto classify = [&](int t, int nb) -> Tile {
     Tile T;
-    T.b0 = first + t * TB;
-    T.nvalid = min(TB, last - T.b0);
+    T.b0 = HYB ? uniform(A.tile0[t]) : first + t * TB;
+    T.nvalid = HYB ? uniform(A.tile0[t + 1]) - T.b0 : min(TB, last - T.b0);
     T.nb = nb;
     const bool outside = si < T.nvalid && nb >= 0 && (nb < T.b0 || nb >= T.b0 + T.nvalid);
     // a sibling: another tile this workgroup holds in the same round (tiles t - wave .. t - wave + 7 below t_end)
     const int nt = (nb - first) / TB, t0 = t - wave;
-    const bool sibling = share_now && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
+    const bool sibling = !HYB && share_now && outside && nb >= first && nb < last && nt >= t0 && nt < t0 + FWAVES && nt < t_end;
     T.sib = sibling ? nt - t0 : -1;
     T.pmask = __ballot(outside);
     T.is_ring = outside && !sibling;
     T.pad = 0;
+    if constexpr (HYB) {
+      const unsigned long long gm = __ballot(si < T.nvalid && nb == FUSED_GENERAL);  // bit 4 b: block b
+      int sm = 0;
+#pragma unroll
+      for (int b = 0; b < TB; b++) sm |= (int)((gm >> (4 * b)) & 1ull) << b;
+      T.pad = uniform(A.zmask[t]) | (sm << 16);
+    }
     const unsigned long long rmask = __ballot(T.is_ring);
     T.nring = (KNOCK & 6) ? 0 : __popcll(rmask);
     T.npass = (T.nring + TB - 1) / TB;
@@ -475,12 +521,44 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
     N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb);
     nb_next = load_nb(tile_at(round + 2));
-    if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
+    int stored_mask = 0;  // HYB: the blocks of this tile whose rows are k_hyb_rows'
+    if constexpr (HYB) {
+      const int tp = uniform(T.pad);
+      stored_mask = (tp >> 16) & 0xffff;
+      if ((tp & 0xffff) != 0) {
+        // somebody's stored rows read z of this tile's blocks from memory: the full product, z of those blocks stored
+        full_precond_mem(L.S, Pinv, lane);
+#pragma unroll
+        for (int i = 0; i < TB / 2; i++) {
+          const int blk = 2 * i + hf;
+          if (blk < nvalid && ((tp >> blk) & 1))
+            reinterpret_cast<double2 *>(A.zg)[(size_t)(b0 + blk) * (BC / 2) + hl] = *reinterpret_cast<const double2 *>(L.S + blk * XS + c0);
+        }
+        if (__popc((unsigned)stored_mask) < nvalid) {  // blocks to finish here: on in the edge layout, S[b * XS + 8 * side + q]
+          double ez[BS];
+#pragma unroll
+          for (int q = 0; q < BS; q++) ez[q] = L.S[si * XS + edge_cell(ss, q)];
+          wave_lds_sync();
+#pragma unroll
+          for (int q = 0; q < BS; q++) L.S[si * XS + 8 * ss + q] = ez[q];
+          wave_lds_sync();
+        }
+      } else {
+        edge_precond(L.S, PE, lane);
+      }
+    } else {
+      if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
+    }
     // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
     __builtin_amdgcn_sched_barrier(0);
     issue_ring(Qa, N, 0, 0);
     issue_ring(Qb, N, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (HYB && __popc((unsigned)stored_mask) >= nvalid) {  // every block's rows are k_hyb_rows'
+      wave_lds_sync();
+      T = N;
+      continue;
+    }
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
       // this buffer held round - NXB: a sibling has read it by the END of that round of its own, i.e. once it has published
@@ -531,7 +609,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
 #pragma unroll
     for (int i = 0; i < TB / 2; i++) {
       const int blk = 2 * i + hfo;
-      if (blk < nvalid) {
+      if (blk < nvalid && !(HYB && ((stored_mask >> blk) & 1))) {  // (stored rows: nu'' or t and the sums with them are k_hyb_rows')
         const double *gx = gex + 2 * i * 4 * GS;
         double2 yv = V[i];
         if (!(KNOCK & 4)) {

@@ -242,6 +242,10 @@ struct FusedArgs {
   const double *pg;
   int pn, pstage, pnsum, pmax;
   KrylovScalars *sc_out;
+  // k_edge HYB (MODE 2 / 3 on the hybrid assembled operator, one rank): where z of the blocks the stored rows read goes
+  // (k_hyb_rows takes it from there), which blocks of a tile those are, the tiling (ctx.h SellMatrix d_zmask, d_tile0)
+  double *zg;
+  const int32_t *zmask, *tile0;
 };
 
 // one partial per workgroup and slot for a workgroup of NW waves (block.h's version is for WPG waves)
@@ -623,6 +627,10 @@ __global__ __launch_bounds__(FWG, 1) void k_fused(FusedArgs A, const double *__r
 // of other ranks arrive in between), with the dot products of the sweep:  MODE 0: y = nu', w = rhat;  MODE 1: y = t,
 // w = s = r - alpha nu' formed again.  One wave per block, lane = row (krylov_common.h sell_row).  The partials go behind
 // the poff partials of k_fused; MERGE as there: the last workgroup finishes the reduction of BOTH launches.
+// MODE 2 / 3: behind k_edge HYB (the two-launch organisation on the hybrid operator).  MODE 2: y = nu'', w = rhat, into the
+// slots {rhat.nu'', r'.r', max|r'|} of that launch (the last two are complete there: zeros here), finish = stage 4 and the
+// report to the host.  MODE 3: y = t, w = s, w2 = rhat, into {t.s, t.t, rhat.s, rhat.t, s.s} (rhat.s and s.s complete there),
+// finish = stage 5.
 constexpr int RWAVES = 16, RWG = RWAVES * 64;  // one wave per block; wide workgroups: few tickets (arrive_last), many waves
 template <int MODE, int MERGE>
 __global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, double *__restrict__ y,
@@ -630,9 +638,16 @@ __global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, 
                                                  const long long *__restrict__ sptr, const int32_t *__restrict__ col,
                                                  const double *__restrict__ val, const int32_t *__restrict__ reg,
                                                  const int32_t *__restrict__ list, int nlist, KrylovScalars *sc,
-                                                 double *partials, int poff, double *red, unsigned *ticket) {
-  if (sc->status != 0) return;
-  constexpr int NDOT = MODE == 0 ? 1 : 2;
+                                                 double *partials, int poff, double *red, unsigned *ticket,
+                                                 const double *__restrict__ w2, int *host_status) {
+  if (sc->status != 0) {
+    // (as k_sweepE_y: the last launch of a group of iterations reports to the host, also behind a solve that has ended)
+    if (MODE == 2 && MERGE == 1 && host_status && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(host_status, sc->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  constexpr int NDOT = MODE == 0 ? 1 : MODE == 1 ? 2 : MODE == 2 ? 3 : 5;  // partial slots of the sweep in front
+  constexpr bool WS = MODE == 1 || MODE == 3;                             // w = s = r - alpha nu', formed again
   const int4 *reg4 = (const int4 *)reg;
   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const double c1 = -sc->alpha;
@@ -644,13 +659,22 @@ __global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, 
     const double a = sell_row(z, s, lane, sptr, col, val, reg4);
     const size_t o = (size_t)s * BC + lane;
     y[o] = a;
-    const double w = MODE == 0 ? w0[o] : w0[o] + c1 * w1[o];
+    const double w = WS ? w0[o] + c1 * w1[o] : w0[o];
     acc[0] = __builtin_fma(a, w, acc[0]);
-    if constexpr (NDOT == 2) acc[1] = __builtin_fma(a, a, acc[1]);
+    if constexpr (WS) acc[1] = __builtin_fma(a, a, acc[1]);
+    if constexpr (MODE == 3) acc[3] = __builtin_fma(w2[o], a, acc[3]);
   }
   fused_reduce_store<RWAVES, NDOT, MERGE != 0>(acc, partials + poff);
-  if (MERGE && arrive_last(ticket))
-    finish_reduce<true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr);
+  if constexpr (MODE == 3) {
+    __shared__ double ext5[5 * WG];
+    if (MERGE && arrive_last(ticket)) finish_reduce_n<5>(partials, poff + (int)gridDim.x, red, sc, MERGE == 1 ? 5 : -1, ext5);
+  } else if constexpr (MODE == 2) {
+    if (MERGE && arrive_last(ticket))
+      finish_reduce<true>(partials, poff + (int)gridDim.x, 2, 1, red, sc, MERGE == 1 ? 4 : -1, MERGE == 1 ? host_status : nullptr);
+  } else {
+    if (MERGE && arrive_last(ticket))
+      finish_reduce<true>(partials, poff + (int)gridDim.x, NDOT, 0, red, sc, MERGE == 1 ? MODE + 1 : -1, nullptr);
+  }
 }
 
 // ---- sweep E in the preconditioned space ---------------------------------------------------------
@@ -780,8 +804,15 @@ static bool ghost_local_enabled() {
   static const bool on = [] { const char *e = getenv("CUP2D_GHOST_LOCAL"); return !e || atoi(e) != 0; }();
   return on;
 }
+// ... and, one rank, on the hybrid assembled operator of an adapted grid (k_edge HYB + k_hyb_rows: hyb_eab_sweep)
+static bool hyb_eab_ok(const cup2d_ctx *c, int merge) {
+  return c->mat.active && c->mat.d_fnbr != nullptr && c->mat.halo == 0 && c->nghost == 0 && merge == 1;
+}
 static bool eab_form(const cup2d_ctx *c, int merge, int dbg, bool ghost_blocks) {
   const bool on = form_of(c) == CUP2D_FORM_AUTO || form_of(c) == CUP2D_FORM_EAB;
+  // (on request only -- cup2d_set_solver_form(CUP2D_FORM_EAB) / CUP2D_FUSED_FORM=eab: measured on the 63 k-block grid it does not
+  // beat three sweeps + two rows launches, krylov_edge.h HYB)
+  if (c->mat.active) return form_of(c) == CUP2D_FORM_EAB && hyb_eab_ok(c, merge) && !c->custom_Pinv && dbg == 0;
   const bool ghosts = c->nghost > 0 && c->exchange;
   // (N ranks: the widest message is two whole blocks per strip -- nu' and p' behind the A+B of iteration 0 -- when r' and p'' of
   // the ghost blocks are formed locally (k_ghost_rp, the default), three with CUP2D_GHOST_LOCAL=0: the caller's buffers must
@@ -863,6 +894,40 @@ static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int first, int
 template <int MODE>
 static int eab_sweep(cup2d_ctx *c, const FusedArgs &a, int merge) { return eab_sweep<MODE>(c, a, merge, 0, c->nblocks, 0, nullptr); }
 
+// One sweep of the two-launch organisation on the hybrid operator (one rank, finish in the kernel): k_edge HYB over the tiles,
+// then the rows of the general tiles, whose last workgroup finishes the reduction of both launches (and, MODE 2, reports)
+template <int MODE>
+static int hyb_eab_sweep(cup2d_ctx *c, FusedArgs a, int *host_status) {
+  static_assert(MODE == 2 || MODE == 3, "hyb_eab_sweep: the A+B of iteration 0 is fused_sweep<0>");
+  const SellMatrix &M = c->mat;
+  a.zg = c->d_z; a.zmask = M.d_zmask; a.tile0 = M.d_tile0;
+  int g = (M.ntiles + FWAVES - 1) / FWAVES;
+  const int cus = c->num_cus > 0 ? c->num_cus : 256;
+  if (g > cus) g = cus;
+  if (g >= 8) g -= g % 8;
+  if (g < 1) g = 1;
+  const auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a, c->d_Pinv, M.d_fnbr, c->d_sc, c->d_partials, 0, M.ntiles,
+                       0, 0, c->d_red, c->d_ticket, c->d_fault);
+  };
+  if (M.ngen == 0) {
+    a.host_status = host_status;
+    go(k_edge<MODE, 1, true>);
+    CUP2D_HIP_CHECK(hipGetLastError());
+    return CUP2D_OK;
+  }
+  a.host_status = nullptr;
+  go(k_edge<MODE, 0, true>);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  int g2 = (M.ngen + RWAVES - 1) / RWAVES;
+  if (g2 > cus) g2 = cus;
+  const double *w0 = MODE == 2 ? a.w : a.in0, *w1 = MODE == 2 ? nullptr : a.in1, *w2 = MODE == 2 ? nullptr : a.w;
+  hipLaunchKernelGGL((k_hyb_rows<MODE, 1>), dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col, M.d_val,
+                     M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, w2, host_status);
+  CUP2D_HIP_CHECK(hipGetLastError());
+  return CUP2D_OK;
+}
+
 template <int MODE>
 static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int *GP, bool ghost_blocks) {
   const int nb = c->nblocks;
@@ -906,7 +971,8 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
     const double *w0 = MODE == 0 ? a.w : a.in0, *w1 = MODE == 0 ? nullptr : a.in1;
     const auto rows = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col,
-                         M.d_val, M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket);
+                         M.d_val, M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, (const double *)nullptr,
+                         (int *)nullptr);
     };
     if (merge == 1) rows(k_hyb_rows<MODE, 1>);
     else if (merge == 2) rows(k_hyb_rows<MODE, 2>);
@@ -1151,7 +1217,9 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
                         reinterpret_cast<const void *>(&k_edge<2, 2>), reinterpret_cast<const void *>(&k_edge<3, 2>),
                         reinterpret_cast<const void *>(&k_edge<2, 0>), reinterpret_cast<const void *>(&k_edge<3, 0>),
                         reinterpret_cast<const void *>(&k_edge<2, 3>), reinterpret_cast<const void *>(&k_edge<3, 3>),
-                        reinterpret_cast<const void *>(&k_edge<2, 4>), reinterpret_cast<const void *>(&k_edge<3, 4>)};
+                        reinterpret_cast<const void *>(&k_edge<2, 4>), reinterpret_cast<const void *>(&k_edge<3, 4>),
+                        reinterpret_cast<const void *>(&k_edge<2, 0, true>), reinterpret_cast<const void *>(&k_edge<3, 0, true>),
+                        reinterpret_cast<const void *>(&k_edge<2, 1, true>), reinterpret_cast<const void *>(&k_edge<3, 1, true>)};
     for (const void *k : ke)
       CUP2D_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
     c->fused_lds_opt_in = true;
@@ -1169,7 +1237,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
 
   // the first solve of a context in the two-launch organisation chooses where its vectors lie (tune_placement) -- before
   // anything of this solve is in them; the sc record of this solve was uploaded above and the probe uses its own
-  if (eab_form(c, merge, dbg, gb)) CUP2D_TRY(tune_placement(c));
+  if (eab_form(c, merge, dbg, gb) && !c->mat.active) CUP2D_TRY(tune_placement(c));
   int GP = 0;
   {
     ProfScope prof(c, CUP2D_T_INIT_RESIDUAL);
@@ -1211,7 +1279,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
     c->last_form = eab ? CUP2D_FORM_EAB : edge ? CUP2D_FORM_EDGE : CUP2D_FORM_FULL;
     c->last_merge = merge;
     c->last_handover = 0;
-    if (eab) c->last_handover = ((edge_share_mode(c, 0) & 1) ? 1 : 0) | ((edge_share_mode(c, 2) & 1) ? 4 : 0) | ((edge_share_mode(c, 3) & 1) ? 8 : 0);
+    if (eab && c->mat.active) c->last_handover = 0;
+    else if (eab) c->last_handover = ((edge_share_mode(c, 0) & 1) ? 1 : 0) | ((edge_share_mode(c, 2) & 1) ? 4 : 0) | ((edge_share_mode(c, 3) & 1) ? 8 : 0);
     else if (edge) c->last_handover = ((edge_share_mode(c, 0) & 1) ? 1 : 0) | ((edge_share_mode(c, 1) & 1) ? 2 : 0);
   }
   if (eab) {
@@ -1263,7 +1332,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       c->prof_sample = c->prof_outer;
       FusedArgs a = {};
       a.in0 = c->d_p; a.in1 = c->d_nu; a.in2 = c->d_r; a.w = c->d_rhat; a.vout = P[0]; a.yout = N[0];
-      CUP2D_TRY(eab_sweep<0>(c, a, merge));
+      if (c->mat.active) CUP2D_TRY(fused_sweep<0>(c, a, merge, dbg, &GP, gb));  // (hybrid operator: k_fused HYB + its rows)
+      else CUP2D_TRY(eab_sweep<0>(c, a, merge));
     }
     if (merge == 2) {  // N ranks: the ghost blocks of nu' and p' in flight behind the reduction
       if (direct) CUP2D_TRY(comm_exchange_blocks(c, 2, N[0], P[0], nullptr));
@@ -1361,7 +1431,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
           { ProfScope prof(c, CUP2D_T_SWEEP_C); CUP2D_TRY(eab_sweep<3>(c, a, 2, 0, c->n_inner, gh, nullptr)); }
         } else {
           ProfScope prof(c, CUP2D_T_SWEEP_C);
-          CUP2D_TRY(eab_sweep<3>(c, a, merge));
+          if (c->mat.active) CUP2D_TRY(hyb_eab_sweep<3>(c, a, nullptr));
+          else CUP2D_TRY(eab_sweep<3>(c, a, merge));
         }
       }
       if (merge == 2) {  // MODE 2 recomputes r' of the blocks around a tile: it needs t in the ghost blocks
@@ -1394,7 +1465,8 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
           { ProfScope prof(c, CUP2D_T_SWEEP_EA); CUP2D_TRY(eab_sweep<2>(c, a, 2, 0, c->n_inner, gh, nullptr)); }
         } else {
           ProfScope prof(c, CUP2D_T_SWEEP_EA);
-          CUP2D_TRY(eab_sweep<2>(c, a, merge));
+          if (c->mat.active) CUP2D_TRY(hyb_eab_sweep<2>(c, a, report));
+          else CUP2D_TRY(eab_sweep<2>(c, a, merge));
         }
       }
       if (merge == 2) {

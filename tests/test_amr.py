@@ -890,28 +890,35 @@ def test_amr_tile_fused_solver_on_the_hybrid_operator_gpu(gpu_lib, which):
         if which == "circle7":  # tiles of plain blocks exist: z stays on the chip there
             assert st["general_tile_blocks"] < 0.6 * g.nblocks
         out = {}
-        for kind, fin in (("sweeps", False), ("fused", False), ("fused", True)):
-            s.set_solver(fused=kind == "fused", finish_in_kernel=fin)
+        # ("fused", True, "eab"): the two-launch organisation, on request (k_edge HYB: sweep E with the next A+B, C+D' with the sums of the
+        # next beginning; rho' and ||r'||^2 from those sums: round-off apart from the others, like the uniform grid's)
+        for kind, fin, form in (("sweeps", False, "auto"), ("fused", False, "auto"), ("fused", True, "auto"), ("fused", True, "eab")):
+            s.set_solver(fused=kind == "fused", finish_in_kernel=fin, form=form)
             s.set_field(L.TMP, b)
             s.set_field(L.PRES, np.zeros_like(b))
             info = s.poisson_solve(tol=0.0, rel_tol=0.0, max_restarts=100, max_iter=4)
             assert s.last_solver() == kind and info["iters"] == 4
-            out[(kind, fin)] = (s.get_field(L.PRES).copy(), info)
-        xs, is_ = out[("sweeps", False)]
-        for key in (("fused", False), ("fused", True)):
+            if kind == "fused":
+                assert s.last_solver_form()[0] == ("eab" if form == "eab" else "full"), s.last_solver_form()
+            out[(kind, fin, form)] = (s.get_field(L.PRES).copy(), info)
+        xs, is_ = out[("sweeps", False, "auto")]
+        for key in (("fused", False, "auto"), ("fused", True, "auto"), ("fused", True, "eab")):
             xf, if_ = out[key]
             assert abs(if_["err"] - is_["err"]) <= 1e-12 * max(1.0, is_["err_init"]), (key, if_, is_)
             assert np.abs(xf - xs).max() <= 1e-12 * max(1.0, np.abs(xs).max()), key
-        assert np.array_equal(out[("fused", False)][0], out[("fused", True)][0])  # the finish in the kernel: same order
-        s.set_solver(fused=True, finish_in_kernel=True)
-        s.set_field(L.TMP, b)
-        s.set_field(L.PRES, np.zeros_like(b))
-        info = s.poisson_solve(tol=1e-9, max_restarts=100, max_iter=2000)
-        x = s.get_field(L.PRES)
-        assert info["err"] <= 1e-9 and 0 < info["iters"] < 2000
-        assert np.abs(b.ravel() - A @ x.ravel()).max() <= 1.05e-9
-        d = x.ravel() - xt
-        assert np.abs(d - d.mean()).max() < 1e-5  # the solution up to the constant (residual 1e-9 times the conditioning)
+        assert np.array_equal(out[("fused", False, "auto")][0], out[("fused", True, "auto")][0])  # the finish in the kernel: same order
+        print(which, "two launches vs five sweeps:", np.abs(out[("fused", True, "eab")][0] - xs).max())
+        for form in ("auto", "eab"):
+            s.set_solver(fused=True, finish_in_kernel=True, form=form)
+            s.set_field(L.TMP, b)
+            s.set_field(L.PRES, np.zeros_like(b))
+            info = s.poisson_solve(tol=1e-9, max_restarts=100, max_iter=2000)
+            x = s.get_field(L.PRES)
+            print(which, form, info)
+            assert info["err"] <= 1e-9 and 0 < info["iters"] < 2000
+            assert np.abs(b.ravel() - A @ x.ravel()).max() <= 1.05e-9
+            d = x.ravel() - xt
+            assert np.abs(d - d.mean()).max() < 1e-5  # the solution up to the constant (residual 1e-9 times the conditioning)
 
 
 @pytest.mark.gpu

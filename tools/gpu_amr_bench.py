@@ -30,6 +30,8 @@ with A.AmrSimulation(g) as s:
     print("operator:", s.matrix_stats(), flush=True)
     if os.environ.get("SWEEPS"):
         s.set_solver(fused=False, finish_in_kernel=False)
+    elif os.environ.get("FORM"):  # full: three sweeps + two rows launches per iteration (k_fused HYB); default: two + two (k_edge HYB)
+        s.set_solver(fused=True, finish_in_kernel=True, form=os.environ["FORM"])
     for _ in range(2):
         r = s.step(max_iter=50)
     nst = 5
@@ -38,8 +40,8 @@ with A.AmrSimulation(g) as s:
         r = s.step(max_iter=50)
     L.check(s.L.cup2d_synchronize(s._ctx)) if hasattr(s.L, "cup2d_synchronize") else None
     el = (time.perf_counter() - t0) / nst
-    print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e  [%s solver]"
-          % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"], s.last_solver()), flush=True)
+    print("AMR step %.2f ms: %.1f Mcell-updates/s (%d cells), iters=%d err=%.2e  [%s solver, form %s]"
+          % (el * 1e3, nb * 64 / el / 1e6, nb * 64, r["iters"], r["err"], s.last_solver(), s.last_solver_form()), flush=True)
     if os.environ.get("NOTIMING"):
         sys.exit(0)
     L.check(s.L.cup2d_set_timing(s._ctx, 1))  # per-launch events: the breakdown below, not the figure above

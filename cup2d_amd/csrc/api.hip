@@ -1043,6 +1043,7 @@ int cup2d_clear_matrix(cup2d_ctx *c) {
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
   dev_free(c->mat.d_ptr); dev_free(c->mat.d_col); dev_free(c->mat.d_val); dev_free(c->mat.d_gather);
   dev_free(c->mat.d_reg); dev_free(c->mat.d_fnbr); dev_free(c->mat.d_zmask); dev_free(c->mat.d_tile0); dev_free(c->mat.d_gen);
+  dev_free(c->mat.d_rrec);
   c->mat = SellMatrix();
   return CUP2D_OK;
 }
@@ -1181,6 +1182,16 @@ static int install_sell(cup2d_ctx *c, int halo, bool hybrid, const std::vector<i
     if (M.ngen) {
       CUP2D_HIP_CHECK(dev_malloc(&M.d_gen, gen.size() * sizeof(int32_t)));
       CUP2D_HIP_CHECK(hipMemcpy(M.d_gen, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      std::vector<RowsRec> rr(gen.size());
+      for (size_t k = 0; k < gen.size(); k++) {
+        const int s = gen[k];
+        rr[k].s = s;
+        rr[k].base = ptr[(size_t)s];
+        rr[k].width = (int)((ptr[(size_t)s + 1] - ptr[(size_t)s]) >> 6);
+        for (int q = 0; q < 4; q++) rr[k].reg[q] = reg[(size_t)4 * s + q];
+      }
+      CUP2D_HIP_CHECK(dev_malloc(&M.d_rrec, rr.size() * sizeof(RowsRec)));
+      CUP2D_HIP_CHECK(hipMemcpy(M.d_rrec, rr.data(), rr.size() * sizeof(RowsRec), hipMemcpyHostToDevice));
     }
     clk.lap("upload tile tables");
   }

@@ -80,6 +80,11 @@ struct CellPlan {
 // block, more where coarse-fine interpolation rows exist), padded with (col = own row, val = 0).
 // Columns >= 64*nblocks address halo entries appended to the Krylov vector (cuda.cu:344-402).
 constexpr int32_t SELL_STORED = -2;
+struct alignas(32) RowsRec {  // k_hyb_rows: slice, its width and first entry (d_ptr), its neighbour record (d_reg)
+  int32_t s, width;
+  long long base;
+  int32_t reg[4];
+};
 struct SellMatrix {
   bool active = false;
   int halo = 0;
@@ -104,6 +109,7 @@ struct SellMatrix {
   int32_t *d_fnbr = nullptr;   // [4 nblocks] k_fused's neighbour table: reg of a plain block, FUSED_GENERAL in a general tile
   int32_t *d_zmask = nullptr;  // [ntiles] bit b: z of block b of the tile is read from memory by someone (stored to d_z)
   int32_t *d_gen = nullptr;    // [ngen] the blocks of the general tiles
+  struct RowsRec *d_rrec = nullptr;  // [ngen] ... with what k_hyb_rows needs of each in ONE record (one round trip, not three)
   int ngen = 0;
   std::vector<int32_t> h_zmask, h_slot;  // slot[b] = 16 tile + position; cup2d_set_gather adds the blocks other ranks read
 };

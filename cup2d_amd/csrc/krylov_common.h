@@ -23,16 +23,13 @@ static __device__ __forceinline__ void sum_records(const double *__restrict__ g,
 
 // One row of the hybrid sliced-ELL operator (ctx.h SellMatrix): slice s (= block; wave-uniform), lane = row.  Shared by
 // k_sell (krylov.hip) and k_hyb_rows (krylov_fused.hip).
-static __device__ __forceinline__ double sell_row(const double *__restrict__ x, int s, int lane,
-                                                  const long long *__restrict__ sptr, const int32_t *__restrict__ col,
-                                                  const double *__restrict__ val, const int4 *__restrict__ reg4) {
-  const long long base = sptr[s];
-  const int width = (int)((sptr[s + 1] - base) >> 6);
+// (sell_row_at: the slice's entry range and neighbour record given -- k_hyb_rows reads them from one record per list entry)
+static __device__ __forceinline__ double sell_row_at(const double *__restrict__ x, int s, int lane, long long base, int width, int4 rg,
+                                                     const int32_t *__restrict__ col, const double *__restrict__ val) {
   const int32_t *cp = col + base + lane;
   const double *vp = val + base + lane;
   double a = 0.0;
   int k = 0;
-  const int4 rg = reg4[s];  // wave-uniform
   if (rg.x != SELL_STORED) {
     // a slice of plain same-level rows (ctx.h SellMatrix::d_reg): the 5-point sum straight from x, ghost = own
     // cell at a wall (the row has no entry there and one neighbour less on the diagonal: the same number)
@@ -56,6 +53,13 @@ static __device__ __forceinline__ double sell_row(const double *__restrict__ x, 
   }
   for (; k < width; k++) a = __builtin_fma(vp[k * 64], x[cp[k * 64]], a);
   return a;
+}
+static __device__ __forceinline__ double sell_row(const double *__restrict__ x, int s, int lane,
+                                                  const long long *__restrict__ sptr, const int32_t *__restrict__ col,
+                                                  const double *__restrict__ val, const int4 *__restrict__ reg4) {
+  const long long base = sptr[s];
+  const int width = (int)((sptr[s + 1] - base) >> 6);
+  return sell_row_at(x, s, lane, base, width, reg4[s], col, val);  // (reg4[s]: wave-uniform)
 }
 
 // Finish of a fused reduction by ONE workgroup: sums the per-workgroup partials of slots [0,nsum) and

@@ -635,11 +635,16 @@ constexpr int RWAVES = 16, RWG = RWAVES * 64;  // one wave per block; wide workg
 template <int MODE, int MERGE>
 __global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, double *__restrict__ y,
                                                  const double *__restrict__ w0, const double *__restrict__ w1,
-                                                 const long long *__restrict__ sptr, const int32_t *__restrict__ col,
-                                                 const double *__restrict__ val, const int32_t *__restrict__ reg,
-                                                 const int32_t *__restrict__ list, int nlist, KrylovScalars *sc,
+                                                 const RowsRec *__restrict__ rrec, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, int nlist, KrylovScalars *sc,
                                                  double *partials, int poff, double *red, unsigned *ticket,
                                                  const double *__restrict__ w2, int *host_status) {
+  // The launch is a chain of memory round trips, not work (3.6 blocks per wave; 12.5 us with half the list, api.hip): the
+  // record of the wave's first block is requested BEFORE the look at the solve's status, and one record holds what the list,
+  // d_ptr and d_reg held in three dependent steps
+  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int e0 = blockIdx.x * RWAVES + wave;
+  RowsRec R = rrec[e0 < nlist ? e0 : 0];
   if (sc->status != 0) {
     // (as k_sweepE_y: the last launch of a group of iterations reports to the host, also behind a solve that has ended)
     if (MODE == 2 && MERGE == 1 && host_status && blockIdx.x == 0 && threadIdx.x == 0)
@@ -648,21 +653,22 @@ __global__ __launch_bounds__(RWG) void k_hyb_rows(const double *__restrict__ z, 
   }
   constexpr int NDOT = MODE == 0 ? 1 : MODE == 1 ? 2 : MODE == 2 ? 3 : 5;  // partial slots of the sweep in front
   constexpr bool WS = MODE == 1 || MODE == 3;                             // w = s = r - alpha nu', formed again
-  const int4 *reg4 = (const int4 *)reg;
-  const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const double c1 = -sc->alpha;
   double acc[NDOT];
 #pragma unroll
   for (int i = 0; i < NDOT; i++) acc[i] = 0.0;
-  for (int e = blockIdx.x * RWAVES + wave; e < nlist; e += gridDim.x * RWAVES) {
-    const int s = uniform(list[e]);
-    const double a = sell_row(z, s, lane, sptr, col, val, reg4);
+  for (int e = e0; e < nlist; e += gridDim.x * RWAVES) {
+    if (e != e0) R = rrec[e];
+    const int s = uniform(R.s);
     const size_t o = (size_t)s * BC + lane;
+    // (the operands of the dot products do not depend on the row: requested beside its entries)
+    const double wa = w0[o], wb = WS ? w1[o] : 0.0, wc = MODE == 3 ? w2[o] : 0.0;
+    const double a = sell_row_at(z, s, lane, R.base, uniform(R.width), make_int4(R.reg[0], R.reg[1], R.reg[2], R.reg[3]), col, val);
     y[o] = a;
-    const double w = WS ? w0[o] + c1 * w1[o] : w0[o];
+    const double w = WS ? wa + c1 * wb : wa;
     acc[0] = __builtin_fma(a, w, acc[0]);
     if constexpr (WS) acc[1] = __builtin_fma(a, a, acc[1]);
-    if constexpr (MODE == 3) acc[3] = __builtin_fma(w2[o], a, acc[3]);
+    if constexpr (MODE == 3) acc[3] = __builtin_fma(wc, a, acc[3]);
   }
   fused_reduce_store<RWAVES, NDOT, MERGE != 0>(acc, partials + poff);
   if constexpr (MODE == 3) {
@@ -922,8 +928,8 @@ static int hyb_eab_sweep(cup2d_ctx *c, FusedArgs a, int *host_status) {
   int g2 = (M.ngen + RWAVES - 1) / RWAVES;
   if (g2 > cus) g2 = cus;
   const double *w0 = MODE == 2 ? a.w : a.in0, *w1 = MODE == 2 ? nullptr : a.in1, *w2 = MODE == 2 ? nullptr : a.w;
-  hipLaunchKernelGGL((k_hyb_rows<MODE, 1>), dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col, M.d_val,
-                     M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, w2, host_status);
+  hipLaunchKernelGGL((k_hyb_rows<MODE, 1>), dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, (const RowsRec *)M.d_rrec,
+                     M.d_col, M.d_val, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, w2, host_status);
   CUP2D_HIP_CHECK(hipGetLastError());
   return CUP2D_OK;
 }
@@ -970,9 +976,8 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
     if (g2 > cus) g2 = cus;  // (2 or 4 workgroups per CU change nothing: 7.89 / 8.03 / 8.06 ms per adapted-grid step, round 4)
     const double *w0 = MODE == 0 ? a.w : a.in0, *w1 = MODE == 0 ? nullptr : a.in1;
     const auto rows = [&](auto kernel) {
-      hipLaunchKernelGGL(kernel, dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, M.d_ptr, M.d_col,
-                         M.d_val, M.d_reg, M.d_gen, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, (const double *)nullptr,
-                         (int *)nullptr);
+      hipLaunchKernelGGL(kernel, dim3(g2), dim3(RWG), 0, c->stream, (const double *)c->d_z, a.yout, w0, w1, (const RowsRec *)M.d_rrec, M.d_col,
+                         M.d_val, M.ngen, c->d_sc, c->d_partials, g, c->d_red, c->d_ticket, (const double *)nullptr, (int *)nullptr);
     };
     if (merge == 1) rows(k_hyb_rows<MODE, 1>);
     else if (merge == 2) rows(k_hyb_rows<MODE, 2>);

@@ -830,10 +830,12 @@ static int edge_share_of(cup2d_ctx *c) {  // the grid allows it: every tile has 
   if (c->edge_share < 0) c->edge_share = edge_share_ok(c->h_nbr.data(), 0, c->nblocks) ? 1 : 0;
   return c->edge_share;
 }
-// sharing between sibling waves per kind of sweep (it pays where the ring is four vectors wide, MODE 2; it costs the short
-// C+D sweep more in waiting than it saves): CUP2D_EDGE_SHARE = bit mask, bit MODE; default 0b0101 (A+B and MODE 2)
+// sharing between sibling waves per kind of sweep: CUP2D_EDGE_SHARE = bit mask, bit MODE; default 0b1101 (A+B, MODE 2, MODE 3).
+// It pays where the ring is four vectors wide (MODE 2); in the short C+D sweeps the waiting eats what it saves -- MODE 1 off;
+// MODE 3 (round 6, gpu_r06_call22.sh, alternating processes): 4096^2 120.2 / 119.6 us without, 120.6 / 121.2 with (nothing);
+// 2048^2 39.2 / 39.0 -> 38.1 / 38.1 us, 755 -> 766 Mcell-updates/s: on, for the small grids and the ranks of configs[3]
 static int edge_share_mode(cup2d_ctx *c, int mode) {
-  static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 5; }();
+  static const int mask = [] { const char *e = getenv("CUP2D_EDGE_SHARE"); return e ? atoi(e) : 13; }();
   if (!edge_share_of(c)) return 0;
   return (mask >> mode) & 1;
 }
@@ -1047,9 +1049,13 @@ static int tune_placement(cup2d_ctx *c) {
   const size_t budget = std::min((size_t)(budget_gb * (double)((size_t)1 << 30)), free_b / 4);  // never more than a quarter of what is free
   while (tries > 1 && (size_t)(tries - 1) * NV * bytes > budget) tries--;
   if (tries <= 1) return CUP2D_OK;
-  // Sets that all look alike (within 4 %) are all in ONE mode -- the two modes lie 10 % apart --, and with one set in six fast
-  // (profiles/r06_placement_vmm.txt) eight alike are as likely all slow as not: the search then goes on, up to three times as
-  // many sets within the same budget, and stops as soon as the sets timed so far are more than 4 % apart (a second mode has shown)
+  // The sets come in THREE modes -- 324-330, 341-347 and 357-371 us per iteration at 4096^2 (1 : 1.05 : 1.12; tools/gpu_calls/
+  // gpu_r06_call23.sh: four fast, one or two middle ones among 16 in two processes; every vector of every set read ALONE takes
+  // the same 25.3 us: the mode is a property of the set) --, and a search that stopped at the first sign of a second mode kept
+  // a middle set in five of six processes (gpu_r06_call22.sh: 340-347 kept of 8-9, 910 Mcell-updates/s where a fast set gives
+  // 935).  So: past the first `tries` sets the search goes on, up to three times as many within the same budget, until the
+  // fastest and the slowest set timed so far lie 9.5 % apart -- both ends of the range have shown, the fastest is a fast one.
+  // 5 ms per set, once per context.
   int tries_more = 3 * tries > 48 ? 48 : 3 * tries;
   while (tries_more > tries && (size_t)(tries_more - 1) * NV * bytes > budget) tries_more--;
   StageClock clk("tune_placement");
@@ -1113,7 +1119,7 @@ static int tune_placement(cup2d_ctx *c) {
   rc = probe(cand[0]);
   float lo_ms = cand[0].ms, hi_ms = cand[0].ms;
   for (int q = 1; q < tries_more && rc == CUP2D_OK; q++) {
-    if (q >= tries && (hi_ms - lo_ms > 0.04f * lo_ms)) break;  // two modes seen (or a clearly faster set found): decided
+    if (q >= tries && (hi_ms - lo_ms > 0.095f * lo_ms)) break;  // a fast and a slow set seen: decided
     bool ok = true;
     for (int k = 0; k < NV; k++) cand[q].v[k] = nullptr;
     if ((size_t)(q - 1) < arena_pads.size()) {
@@ -1150,6 +1156,27 @@ static int tune_placement(cup2d_ctx *c) {
       worst = cand[q].ms > worst ? cand[q].ms : worst;
     }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
+  // diagnostic (CUP2D_HOST_TIMING): every vector of every set read ALONE (a max-reduction over it, three times), us -- is the
+  // mode a property of single allocations or of the set?
+  std::vector<std::string> solo((size_t)made);
+  if (clk.on && getenv("CUP2D_PLACEMENT_SOLO")) {
+    for (int q = 0; q < made; q++) {
+      std::string line = "   solo us:";
+      for (int k = 0; k < NV; k++) {
+        (void)launch_max_abs(c, cand[q].v[k], (size_t)nb * BC, c->d_red);
+        CUP2D_HIP_CHECK(hipEventRecord(e0, c->stream));
+        for (int rep = 0; rep < 3; rep++) (void)launch_max_abs(c, cand[q].v[k], (size_t)nb * BC, c->d_red);
+        CUP2D_HIP_CHECK(hipEventRecord(e1, c->stream));
+        CUP2D_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CUP2D_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        char buf[32];
+        snprintf(buf, sizeof buf, " %.1f", 1e3 * ms / 3.0);
+        line += buf;
+      }
+      solo[(size_t)q] = line;
+    }
+  }
   for (int q = 0; q < made; q++) {  // the sets that lost go back to the driver, not into the process pool (dev_release)
     if (q == best) continue;
     if (cand[q].arena) (void)hipFree(cand[q].arena);
@@ -1171,8 +1198,9 @@ static int tune_placement(cup2d_ctx *c) {
   c->placement_first_us = 1e3 * cand[0].ms;
   if (clk.on) {
     for (int q = 0; q < made; q++)
-      fprintf(stderr, "[cup2d timing] tune_placement: set %d (%s, pad %lld, first vector at %p): %.1f us per iteration%s\n", q,
-              cand[q].arena ? "arena" : "separate", cand[q].pad, (void *)cand[q].v[0], 1e3 * cand[q].ms, q == best ? "  <- kept" : "");
+      fprintf(stderr, "[cup2d timing] tune_placement: set %d (%s, pad %lld, first vector at %p): %.1f us per iteration%s%s\n", q,
+              cand[q].arena ? "arena" : "separate", cand[q].pad, (void *)cand[q].v[0], 1e3 * cand[q].ms, q == best ? "  <- kept" : "",
+              solo[(size_t)q].c_str());
     clk.lap("search");
   }
   return rc;

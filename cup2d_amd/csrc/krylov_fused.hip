@@ -1020,23 +1020,38 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 
 // ---- where the solver's vectors lie -----------------------------------------------------------------------------------------
 // The two launches of an iteration stream eleven vectors of ntotal blocks each (p, nu, r in two buffers, t, y in three, rhat).
-// Their durations come in two modes -- C+D' 117 / E+A+B 228 us or 127 / 239 us at 4096^2, 5 % of a step -- and which one a
-// solve gets is a property of WHERE those eleven buffers landed in device memory, nothing else: ten contexts created one after
-// the other in ONE process and kept alive run 117, 122, 117, 127, 127, 126, 123, 127, 126, 127 us (C+D'), each context the
-// same again on every later solve; another process on the same box: 126, 117, 118, 127, ... (tools/gpu_placement_modes.py,
-// tools/gpu_calls/gpu_r04_call18.sh).  Start offsets inside the allocations move nothing, one large
-// allocation carved up is reproducibly the slow mode (round 3).  So the first fused solve of a context on a large grid
-// searches: it allocates up to CUP2D_PLACEMENT_TRIES (default 8; three times as many while all of them look alike; within
-// CUP2D_PLACEMENT_MAX_GB = 40 GB and a quarter of the free memory) complete sets of the eleven vectors -- all held while it
-// looks, so that every set is other memory --, times three iterations' worth of the two launches on each (the MERGE 0
-// instances on zero-filled vectors with a scratch scalar record: no reduction finish, nothing of the context's state
-// touched), keeps the fastest set and gives the others back: 2 ms per set at 4096^2, once per context.  A set in the fast
-// mode turned up among 8 in four of five processes, among 12 in one of two (gpu_r04_call19.sh): the sets of a process are
-// not independent draws, and a process can be out of luck.
+// Their durations come in modes -- 324-330, 341-347 and 357-371 us per iteration at 4096^2 (1 : 1.05 : 1.12) -- and which one a
+// solve gets is a property of WHERE those eleven buffers landed in device memory, nothing else: contexts created one after the
+// other in one process and kept alive each run the same again on every later solve (tools/gpu_placement_modes.py).  What round 6
+// found out about it (tools/gpu_calls/gpu_r06_call23.sh ... call31.sh, profiles/r06_placement_repair.txt):
+//   * every vector of every set, read ALONE, streams at the same rate (25.3 us for 134 MB): no allocation is slow by itself;
+//   * a slow set is slow because of a CONFLICT between two or three of its vectors, streams the launches write among them every
+//     time: the slowest set of a process with ONE vector taken from the fastest set runs 347 (s), 349 (p), 349 (nu) instead of
+//     371 us, with any of the other eight as before; in another process t 348, xopt 351.  The fastest set with any one vector of
+//     the slowest stays fast;
+//   * the conflict is not one of addresses below 64 MiB (pseudo-random offsets of the vectors inside ONE arena, physically
+//     contiguous or not, granularity 256 B to 1 MiB: 80 candidates, all slow; arenas at any stride: slow) -- the vectors of a set
+//     are neighbours in physical memory, and it takes a vector from somewhere else to end it;
+//   * a slow set IS repairable with vectors of other slow sets: the slowest of 12 sets, its s, p, t (and one more) exchanged
+//     with the same slots of other slow sets: 371.7 -> 323.8, 365.4 -> 322.0, 367.8 -> 321.2 us in three processes -- faster than
+//     any complete set the allocator handed out (324-330).
+// So the first fused solve of a context on a large grid (1) allocates CUP2D_PLACEMENT_TRIES (default 8) complete sets of the
+// eleven vectors -- all held while it looks, so that every set is other memory --, (2) times three iterations' worth of the two
+// launches on each (the MERGE 0 instances on zero-filled vectors with scratch scalar records -- one per rotation of the three y
+// buffers --: no reduction finish, nothing of the context's state touched), (3) REPAIRS the fastest: slot by slot, written
+// streams first, its vector is exchanged with the same slot's of up to four other sets and the exchange kept where it gains
+// 1.5 %, (4) if fastest and slowest then still lie less than 9.5 % apart (no fast set seen or made) goes on with more sets, up
+// to six times as many (three on N ranks) within CUP2D_PLACEMENT_MAX_GB (64 GB on one rank, 40 GB on N) and a quarter of the
+// free memory, and repairs once more, (5) keeps the fastest set and gives the others back.  5 ms per set, 2 ms per exchange
+// tried: 0.1 s, once per context.  CUP2D_PLACEMENT_ARENA="pad,pad,..." adds arenas (one allocation carved at 2^27 + pad) as
+// candidates: the experiment's switch.
 static int tune_placement(cup2d_ctx *c) {
   static const int tries_env = [] { const char *e = getenv("CUP2D_PLACEMENT_TRIES"); return e ? atoi(e) : 8; }();
   // what the search may hold beyond the context's own set while it looks (per process: ranks that share a GPU each search)
-  static const double budget_gb = [] { const char *e = getenv("CUP2D_PLACEMENT_MAX_GB"); return e ? atof(e) : 40.0; }();
+  static const double budget_env = [] { const char *e = getenv("CUP2D_PLACEMENT_MAX_GB"); return e ? atof(e) : -1.0; }();
+  // (a context with ghost blocks is one of several ranks, which may share a GPU in the tests: the smaller bound)
+  const bool one_rank = c->nghost == 0 && !c->exchange;
+  const double budget_gb = budget_env >= 0.0 ? budget_env : one_rank ? 64.0 : 40.0;
   if (c->placement_tuned) return CUP2D_OK;
   c->placement_tuned = true;
   const size_t bytes = (size_t)c->ntotal * BC * sizeof(double);
@@ -1049,20 +1064,10 @@ static int tune_placement(cup2d_ctx *c) {
   const size_t budget = std::min((size_t)(budget_gb * (double)((size_t)1 << 30)), free_b / 4);  // never more than a quarter of what is free
   while (tries > 1 && (size_t)(tries - 1) * NV * bytes > budget) tries--;
   if (tries <= 1) return CUP2D_OK;
-  // The sets come in THREE modes -- 324-330, 341-347 and 357-371 us per iteration at 4096^2 (1 : 1.05 : 1.12; tools/gpu_calls/
-  // gpu_r06_call23.sh: four fast, one or two middle ones among 16 in two processes; every vector of every set read ALONE takes
-  // the same 25.3 us: the mode is a property of the set) --, and a search that stopped at the first sign of a second mode kept
-  // a middle set in five of six processes (gpu_r06_call22.sh: 340-347 kept of 8-9, 910 Mcell-updates/s where a fast set gives
-  // 935).  So: past the first `tries` sets the search goes on, up to three times as many within the same budget, until the
-  // fastest and the slowest set timed so far lie 9.5 % apart -- both ends of the range have shown, the fastest is a fast one.
-  // 5 ms per set, once per context.
-  int tries_more = 3 * tries > 48 ? 48 : 3 * tries;
+  // (how rare fast sets are depends on the box: four of 16 in one, one of 25 in two processes of another)
+  int tries_more = (one_rank ? 6 : 3) * tries > 48 ? 48 : (one_rank ? 6 : 3) * tries;
   while (tries_more > tries && (size_t)(tries_more - 1) * NV * bytes > budget) tries_more--;
   StageClock clk("tune_placement");
-  // Candidate kinds: the context's own vectors (set 0); ARENAS -- one allocation carved into the eleven vectors at a stride of
-  // bytes + pad, for every pad of CUP2D_PLACEMENT_ARENA="pad,pad,..." (bytes; experiment: a vector is 2^27 bytes at 4096^2, and
-  // eleven streams an exact power of two apart is the one arrangement known to be slow) --; then separate
-  // allocations, each its own hipMalloc
   static const std::vector<size_t> arena_pads = [] {
     std::vector<size_t> v;
     if (const char *e = getenv("CUP2D_PLACEMENT_ARENA"))
@@ -1080,46 +1085,90 @@ static int tune_placement(cup2d_ctx *c) {
   for (auto &C : cand) { C.arena = nullptr; C.pad = -1; C.ms = 0.f; }
   for (int k = 0; k < NV; k++) cand[0].v[k] = *slot[k];
   cand[0].arena = c->vec_arena;
-  KrylovScalars hs;
-  ::memset(&hs, 0, sizeof hs);
-  hs.alpha = hs.beta = hs.omega = hs.omega_r = hs.rho_prev = hs.rho_curr = 1.0;
-  hs.eps = 1e-21; hs.err = hs.err_init = hs.err_opt = 1.0; hs.max_error = -1.0; hs.max_rel_error = -1.0;
-  hs.max_iter = 1 << 30; hs.iter = 1; hs.ycur = 0; hs.ybest = 1;
+  // three scratch records: sweep E writes the y buffer that is neither the current nor the best one -- every rotation is timed
+  KrylovScalars hs[3];
+  for (int q = 0; q < 3; q++) {
+    ::memset(&hs[q], 0, sizeof hs[q]);
+    hs[q].alpha = hs[q].beta = hs[q].omega = hs[q].omega_r = hs[q].rho_prev = hs[q].rho_curr = 1.0;
+    hs[q].eps = 1e-21; hs[q].err = hs[q].err_init = hs[q].err_opt = 1.0; hs[q].max_error = -1.0; hs[q].max_rel_error = -1.0;
+    hs[q].max_iter = 1 << 30; hs[q].iter = 1; hs[q].ycur = q; hs[q].ybest = (q + 1) % 3;
+  }
   KrylovScalars *d_scratch = nullptr;
   CUP2D_HIP_CHECK(dev_malloc(&d_scratch, sizeof hs));
-  CUP2D_HIP_CHECK(hipMemcpyAsync(d_scratch, &hs, sizeof hs, hipMemcpyHostToDevice, c->stream));
+  CUP2D_HIP_CHECK(hipMemcpyAsync(d_scratch, hs, sizeof hs, hipMemcpyHostToDevice, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   CUP2D_HIP_CHECK(hipEventCreate(&e0));
   CUP2D_HIP_CHECK(hipEventCreate(&e1));
   const int nb = c->nblocks, g = fused_grid(c, nb);
-  int rc = CUP2D_OK, made = 1;
+  int rc = CUP2D_OK, made = 1, probes = 0;
   const auto probe = [&](Cand &C) -> int {
     double *r = C.v[0], *sv = C.v[1], *p = C.v[2], *p2 = C.v[3], *nu = C.v[4], *nu2 = C.v[5], *t = C.v[6], *y = C.v[7], *yo = C.v[8],
            *xo = C.v[9], *rh = C.v[10];
     FusedArgs a3 = {}, a2 = {};
     a3.in0 = r; a3.in1 = nu2; a3.w = rh; a3.yout = t; a3.rev = 1;
     a2.in0 = p2; a2.in1 = nu2; a2.in2 = r; a2.w = rh; a2.vout = p; a2.yout = nu; a2.t = t; a2.y0 = y; a2.y1 = yo; a2.y2 = xo; a2.rout = sv;
-    const auto pair = [&]() {
-      hipLaunchKernelGGL((k_edge<3, 0>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a3, c->d_Pinv, c->d_nbr, d_scratch, c->d_partials, 0, nb, 0,
+    const auto pair = [&](int rot) {
+      hipLaunchKernelGGL((k_edge<3, 0>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a3, c->d_Pinv, c->d_nbr, d_scratch + rot, c->d_partials, 0, nb, 0,
                          edge_share_mode(c, 3) & 1, c->d_red, c->d_ticket, c->d_fault);
-      hipLaunchKernelGGL((k_edge<2, 0>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, d_scratch, c->d_partials, 0, nb, 0,
+      hipLaunchKernelGGL((k_edge<2, 0>), dim3(g), dim3(FWG), EDGE_LDS_BYTES, c->stream, a2, c->d_Pinv, c->d_nbr, d_scratch + rot, c->d_partials, 0, nb, 0,
                          edge_share_mode(c, 2) & 1, c->d_red, c->d_ticket, c->d_fault);
     };
-    pair();  // (warm: the first touch of fresh memory is not what a solve sees)
+    pair(0);  // (warm: the first touch of fresh memory is not what a solve sees)
     CUP2D_HIP_CHECK(hipEventRecord(e0, c->stream));
-    for (int rep = 0; rep < 3; rep++) pair();
+    for (int rep = 0; rep < 3; rep++) pair(rep);
     CUP2D_HIP_CHECK(hipEventRecord(e1, c->stream));
     CUP2D_HIP_CHECK(hipEventSynchronize(e1));
     CUP2D_HIP_CHECK(hipGetLastError());
     CUP2D_HIP_CHECK(hipEventElapsedTime(&C.ms, e0, e1));
     C.ms /= 3.0f;
+    probes++;
     return CUP2D_OK;
   };
   // (the context's own vectors may hold anything: the probe computes on what is there; values do not change a duration)
   rc = probe(cand[0]);
   float lo_ms = cand[0].ms, hi_ms = cand[0].ms;
+  const float first_ms = cand[0].ms;
+  const auto fast_seen = [&]() { return hi_ms - lo_ms > 0.095f * lo_ms; };
+  std::string repair_log;
+  // step (3) over the sets [0, made): separate allocations only (an arena's vectors are not its own to give away)
+  int repaired_at = 0;  // the number of sets the last repair looked at
+  const auto repair = [&]() -> int {
+    if (made < 3 || made == repaired_at) return CUP2D_OK;
+    repaired_at = made;
+    int b = 0;
+    for (int q = 1; q < made; q++) if (cand[q].ms < cand[b].ms) b = q;
+    if (cand[b].arena || cand[b].pad != -1) return CUP2D_OK;
+    static const int order[NV] = {1, 2, 4, 9, 6, 7, 8, 0, 3, 5, 10};  // s, p, nu, xopt, t, y, yopt, r, p2, nu2, rhat
+    const int p0 = probes;
+    for (int oi = 0; oi < NV; oi++) {
+      const int k = order[oi];
+      int tried = 0;
+      for (int j = 1; j < made && tried < 4; j++) {
+        const int q = (b + j + 2 * oi) % made;
+        if (q == b || cand[q].arena || cand[q].pad != -1) continue;
+        tried++;
+        const float before = cand[b].ms;
+        std::swap(cand[b].v[k], cand[q].v[k]);
+        CUP2D_TRY(probe(cand[b]));
+        if (cand[b].ms < 0.985f * before) {
+          char buf[64];
+          snprintf(buf, sizeof buf, " slot %d from set %d: %.1f -> %.1f;", k, q, 1e3 * before, 1e3 * cand[b].ms);
+          repair_log += buf;
+          lo_ms = cand[b].ms < lo_ms ? cand[b].ms : lo_ms;
+          break;
+        }
+        std::swap(cand[b].v[k], cand[q].v[k]);
+        cand[b].ms = before;
+      }
+    }
+    char buf[64];
+    snprintf(buf, sizeof buf, " (set %d, %d probes)", b, probes - p0);
+    repair_log += buf;
+    return CUP2D_OK;
+  };
   for (int q = 1; q < tries_more && rc == CUP2D_OK; q++) {
-    if (q >= tries && (hi_ms - lo_ms > 0.095f * lo_ms)) break;  // a fast and a slow set seen: decided
+    if (q == tries) rc = repair();  // the first batch is in: its best set repaired before more memory is asked for
+    if (q >= tries && (rc != CUP2D_OK || fast_seen())) break;  // a fast and a slow set seen (or made): decided
     bool ok = true;
     for (int k = 0; k < NV; k++) cand[q].v[k] = nullptr;
     if ((size_t)(q - 1) < arena_pads.size()) {
@@ -1148,35 +1197,13 @@ static int tune_placement(cup2d_ctx *c) {
       hi_ms = cand[q].ms > hi_ms ? cand[q].ms : hi_ms;
     }
   }
+  // (fewer sets than a first batch -- the budget --, or every set the budget allows timed and none fast: on all of them)
+  if (rc == CUP2D_OK && (repaired_at == 0 || !fast_seen())) rc = repair();
   int best = 0;
-  float worst = cand[0].ms;
   if (rc == CUP2D_OK)
-    for (int q = 1; q < made; q++) {
+    for (int q = 1; q < made; q++)
       if (cand[q].ms < cand[best].ms) best = q;
-      worst = cand[q].ms > worst ? cand[q].ms : worst;
-    }
   CUP2D_HIP_CHECK(hipStreamSynchronize(c->stream));
-  // diagnostic (CUP2D_HOST_TIMING): every vector of every set read ALONE (a max-reduction over it, three times), us -- is the
-  // mode a property of single allocations or of the set?
-  std::vector<std::string> solo((size_t)made);
-  if (clk.on && getenv("CUP2D_PLACEMENT_SOLO")) {
-    for (int q = 0; q < made; q++) {
-      std::string line = "   solo us:";
-      for (int k = 0; k < NV; k++) {
-        (void)launch_max_abs(c, cand[q].v[k], (size_t)nb * BC, c->d_red);
-        CUP2D_HIP_CHECK(hipEventRecord(e0, c->stream));
-        for (int rep = 0; rep < 3; rep++) (void)launch_max_abs(c, cand[q].v[k], (size_t)nb * BC, c->d_red);
-        CUP2D_HIP_CHECK(hipEventRecord(e1, c->stream));
-        CUP2D_HIP_CHECK(hipEventSynchronize(e1));
-        float ms = 0.f;
-        CUP2D_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        char buf[32];
-        snprintf(buf, sizeof buf, " %.1f", 1e3 * ms / 3.0);
-        line += buf;
-      }
-      solo[(size_t)q] = line;
-    }
-  }
   for (int q = 0; q < made; q++) {  // the sets that lost go back to the driver, not into the process pool (dev_release)
     if (q == best) continue;
     if (cand[q].arena) (void)hipFree(cand[q].arena);
@@ -1194,13 +1221,14 @@ static int tune_placement(cup2d_ctx *c) {
   dev_free(d_scratch);
   c->placement_candidates = made;
   c->placement_best_us = 1e3 * cand[best].ms;
-  c->placement_worst_us = 1e3 * worst;
-  c->placement_first_us = 1e3 * cand[0].ms;
+  c->placement_worst_us = 1e3 * hi_ms;   // the slowest complete set as the allocator handed it out
+  c->placement_first_us = 1e3 * first_ms;
   if (clk.on) {
+    // (sets that gave a vector to the repaired one are listed with the time they had before)
     for (int q = 0; q < made; q++)
-      fprintf(stderr, "[cup2d timing] tune_placement: set %d (%s, pad %lld, first vector at %p): %.1f us per iteration%s%s\n", q,
-              cand[q].arena ? "arena" : "separate", cand[q].pad, (void *)cand[q].v[0], 1e3 * cand[q].ms, q == best ? "  <- kept" : "",
-              solo[(size_t)q].c_str());
+      fprintf(stderr, "[cup2d timing] tune_placement: set %d (%s, pad %lld, first vector at %p): %.1f us per iteration%s\n", q,
+              cand[q].arena ? "arena" : "separate", cand[q].pad, (void *)cand[q].v[0], 1e3 * cand[q].ms, q == best ? "  <- kept" : "");
+    if (!repair_log.empty()) fprintf(stderr, "[cup2d timing] tune_placement: repair:%s\n", repair_log.c_str());
     clk.lap("search");
   }
   return rc;

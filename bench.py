@@ -928,6 +928,10 @@ def main():
                         if "true" in k:                                  # uniform bench runs <MODE, MERGE, false, false>
                             continue
                         k = ",".join(k.split(",")[:2]) + ">"
+                    if k.startswith("k_edge<") and k.count(",") > 1:   # <MODE, MERGE, hybrid operator> (round 6): the uniform
+                        if "true" in k:                                # bench runs <MODE, MERGE, false>
+                            continue
+                        k = ",".join(k.split(",")[:2]) + ">"
                     traffic_tab[k] = v
                     traffic_src[k] = "profiles/" + f
             except Exception:

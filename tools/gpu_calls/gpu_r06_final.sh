@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, the last commit as the driver runs it: the GPU suite, smoke, the bench line
+# round 6, the last commit as the driver runs it: the GPU suite, smoke, the bench line (run again on the second half of the round: placement repair, hand-over in C+D', k_edge HYB on request)
 set -u
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 t0=$(date +%s)
@@ -7,7 +7,7 @@ timeout 1800 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/fi
 echo "pytest rc=$? ($(( $(date +%s) - t0 )) s)"; grep -E "^FAILED|^ERROR|passed|failed" $OUT/final_pytest.log | tail -5
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 t0=$(date +%s)
-timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/final_bench.json 2> $OUT/final_bench.err
+CUP2D_HOST_TIMING=1 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/final_bench.json 2> $OUT/final_bench.err
 echo "bench rc=$? ($(( $(date +%s) - t0 )) s)"; wc -c $OUT/final_bench.json; cat $OUT/final_bench.json
 cp $OUT/bench_detail.json $OUT/final_bench_detail.json
 # the step as the GPU sees it

@@ -63,6 +63,12 @@ constexpr int KNOCK = CUP2D_EDGE_KNOCK;
 #define CUP2D_POLICY2 0x07
 #endif
 constexpr unsigned POL2 = CUP2D_POLICY2;
+// C+D (MODE 1 / 3): halves of the NEXT tile's own batches requested behind this tile's job, next to its ring pass 0 -- they are
+// then in flight across the hand-over, the gathers, the epilogue and the next ring job instead of across the ring job alone
+// (MODE 3 holds 173 registers of 256: one half = 48 more).  0: as before (requested behind the ring's staging)
+#ifndef CUP2D_CD_AHEAD
+#define CUP2D_CD_AHEAD 1
+#endif
 // set bits of a wave mask below this lane (v_mbcnt: no 64-bit lane mask held in registers)
 static __device__ __forceinline__ int bits_below_lane(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -403,6 +409,8 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     T = classify(tile_at(j), load_nb(tile_at(j)));
     issue_ring(Qa, T, 0, 0);  // (always: a batch set that is assigned on SOME paths only is live around the whole loop)
     issue_ring(Qb, T, 0, 1);
+    if constexpr (CD && !HYB && CUP2D_CD_AHEAD >= 1) issue_tile(Ta, T, 0);
+    if constexpr (CD && !HYB && CUP2D_CD_AHEAD >= 2) issue_tile(Tb, T, 1);
   }
   int nb_next = load_nb(tile_at(j + 1));
   for (int round = j; tile_at(round) < t_end; round++) {
@@ -499,8 +507,8 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       stage_ring(Qb, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    issue_tile(Ta, T, 0);
-    issue_tile(Tb, T, 1);
+    if constexpr (!(CD && !HYB && CUP2D_CD_AHEAD >= 1)) issue_tile(Ta, T, 0);  // (else: in flight since the previous tile's job)
+    if constexpr (!(CD && !HYB && CUP2D_CD_AHEAD >= 2)) issue_tile(Tb, T, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (T.npass > 0) ring_job(T.npass - 1);  // the tile's batches are in flight across the job
     __builtin_amdgcn_sched_barrier(0);
@@ -553,6 +561,8 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     issue_ring(Qa, N, 0, 0);
     issue_ring(Qb, N, 0, 1);
+    if constexpr (CD && !HYB && CUP2D_CD_AHEAD >= 1) issue_tile(Ta, N, 0);
+    if constexpr (CD && !HYB && CUP2D_CD_AHEAD >= 2) issue_tile(Tb, N, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (HYB && __popc((unsigned)stored_mask) >= nvalid) {  // every block's rows are k_hyb_rows'
       wave_lds_sync();

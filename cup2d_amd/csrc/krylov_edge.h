@@ -149,6 +149,21 @@ static __device__ __forceinline__ void edge_wait(int *pub, int u, int need, int 
   }
 }
 
+// -DEDGE_PHASES (timing aid, tools/gpu_calls/gpu_r06_call43.sh): every wave adds up the shader-clock cycles it spends in the phases of a
+// tile; waves 0 and 5 of the first two workgroups print their sums for iteration 5.  Round 6 (hand-over on in both launches, 4096^2),
+// cycles per tile, wave 0 / wave 5 of a workgroup:
+//   E+A+B  ring staging 2.5 k / 2.9 k, requests + ring job 8.8 k / 14.1 k, tile staging (+ wait for its batches) 12.2 k / 14.5 k,
+//          tile job 3.5 k / 3.9 k, requests of the next tile 5.9 k / 6.6 k, export 2.4 k / 2.6 k, own edges + imports (+ wait for the
+//          siblings) 13.9 k / 4.0 k, epilogue 6.4 k / 7.7 k: 55-56 k = 26 us -- the siblings pace each other, the slack of the
+//          fastest shows up as its wait at the imports; the launch moves its bytes at the copy ceiling
+//   C+D'   2.3 k, 3.7 k, 0.9 k (its first half is requested a tile ahead), 3.0 k, 2.5 k, 2.3 k, 5.8 k (wait), 5.7 k: 26 k = 12.5 us
+//   (the export in FRONT of the next tile's requests -- the siblings get the edges earlier, the requests fill the wait -- measured: 937.5 /
+//   944.3 against 945.3 / 943.6 Mcell-updates/s, nothing; not kept)
+#ifdef EDGE_PHASES
+#define EPH(k) { const long long now_ = clock64(); eph[k] += now_ - etprev; etprev = now_; }
+#else
+#define EPH(k) {}
+#endif
 // MODE 0 (sweeps A+B): v = p' = beta (p - omega nu) + r   (cuda.cu:478-483; restart: p' = rhat = r, 461-476)
 //                      y = nu' = p' + ghosts(P_inv p') ; partial(rhat . nu')             (484-488)
 // MODE 1 (sweeps C+D): v = s  = r - alpha nu'                                            (499-502)
@@ -413,8 +428,15 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     if constexpr (CD && !HYB && CUP2D_CD_AHEAD >= 2) issue_tile(Tb, T, 1);
   }
   int nb_next = load_nb(tile_at(j + 1));
+#ifdef EDGE_PHASES
+  long long eph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, etprev = clock64();
+  int entile = 0;
+#endif
   for (int round = j; tile_at(round) < t_end; round++) {
     const int t = tile_at(round);
+#ifdef EDGE_PHASES
+    entile++;
+#endif
     const int b0 = T.b0, nvalid = T.nvalid, par = round % NXB;
     const bool more = tile_at(round + 1) < t_end;
     double2 V[TB / 2];  // v of the tile's cells in pair layout
@@ -497,6 +519,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       stage_ring(Qa, 0);
       stage_ring(Qb, 1);
     }
+    EPH(0)
     // (more than 16 ring entries -- block orders other than the reference's: the further passes are requested and waited
     // for in place, BEFORE the tile's batches go out: a ring set and both tile sets at once do not fit the register file)
     for (int pass = 1; pass < T.npass; pass++) {
@@ -512,6 +535,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     __builtin_amdgcn_sched_barrier(0);
     if (T.npass > 0) ring_job(T.npass - 1);  // the tile's batches are in flight across the job
     __builtin_amdgcn_sched_barrier(0);
+    EPH(1)
     // ---- the tile ----
     Tile N = T;
     stage_tile(Ta, 0);
@@ -525,6 +549,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     }
     stage_tile(Tb, 1);
     __builtin_amdgcn_sched_barrier(0);
+    EPH(2)
     // this tile's ring list is dead: the NEXT tile is classified into it (past the wave's last tile: this tile once more --
     // the batch sets must be assigned on EVERY path around the loop, or their old contents stay live through all of it)
     N = classify(more ? tile_at(round + 1) : t, more ? nb_next : T.nb);
@@ -557,6 +582,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
     } else {
       if (!(KNOCK & 4)) edge_precond(L.S, PE, lane);  // the same product for the tile's own blocks: S[b * XS + 8 * side + q]
     }
+    EPH(3)
     // ... and its ring pass 0 requested BEHIND the job: no batch is live across it
     __builtin_amdgcn_sched_barrier(0);
     issue_ring(Qa, N, 0, 0);
@@ -569,6 +595,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       T = N;
       continue;
     }
+    EPH(4)
     // ---- export the z edges of the perimeter sides for the siblings ----
     if (share && !(KNOCK & 4)) {
       // this buffer held round - NXB: a sibling has read it by the END of that round of its own, i.e. once it has published
@@ -589,6 +616,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       wave_lds_sync();
       if (lane == 0) __hip_atomic_store(pub + wave, round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    EPH(5)
     // ---- ghost edges from the own tile and at domain walls (ScalarLab::Neumann2D, main.cpp:3210-3255: ghost = edge cell) ----
     if (si < nvalid && !mask_bit(T.pmask, opaque(lane)) && !(KNOCK & 4)) {
       const int sblk = T.nb < 0 ? si : T.nb - b0, sside = T.nb < 0 ? ss : ss ^ 1;
@@ -612,6 +640,7 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       }
     }
     wave_lds_sync();
+    EPH(6)
     // ---- y = v + ghosts on the block edges (A P_inv v = v + (C + W) z), the fused dot products: two cells per lane, eight
     //      block pairs ----
     const int lo = opaque(lane), hfo = lo >> 5, hlo = lo & 31;
@@ -651,8 +680,15 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
       }
     }
     wave_lds_sync();  // the next tile overwrites S and GE
+    EPH(7)
     T = N;
   }
+#ifdef EDGE_PHASES
+  if (sc->iter == 5 && lane == 0 && blockIdx.x < 2 && (wave == 0 || wave == 5) && entile > 0)
+    printf("EPHASES mode %d wg %d wave %d tiles %d cycles/tile: ring stage(+wait) %lld  issue+ring job %lld  tile stage(+wait) %lld  classify+tile job %lld  "
+           "issue next %lld  export(+wait producers) %lld  own edges + imports(+wait) %lld  epilogue %lld\n", MODE, (int)blockIdx.x, wave, entile, eph[0] / entile,
+           eph[1] / entile, eph[2] / entile, eph[3] / entile, eph[4] / entile, eph[5] / entile, eph[6] / entile, eph[7] / entile);
+#endif
   // this wave publishes nothing more: nobody may wait for it
   if (lane == 0) __hip_atomic_store(pub + wave, 1 << 30, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   fused_reduce_store<FWAVES, NDOT, FIN != 0>(acc, partials + poff);

@@ -652,6 +652,10 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
         const double *gx = gex + 2 * i * 4 * GS;
         double2 yv = V[i];
         if (!(KNOCK & 4)) {
+#ifndef CUP2D_EDGE_BRANCHY_EPILOGUE
+#define CUP2D_EDGE_BRANCHY_EPILOGUE 0
+#endif
+        if constexpr (AB || CUP2D_EDGE_BRANCHY_EPILOGUE) {  // (MODE 0, once per solve, spills 24 registers under the other form)
         if (px == 0) yv.x += gey[2 * i * 4 * GS + 0 * GS];        // west of cell c0
         if (px == BS - 2) yv.y += gey[2 * i * 4 * GS + 1 * GS];   // east of cell c0 + 1
         if (py == 0) {
@@ -663,6 +667,24 @@ __global__ __launch_bounds__(FWG, 1) void k_edge(FusedArgs A, const double *__re
           const double2 g = *reinterpret_cast<const double2 *>(gx + 3 * GS);
           yv.x += g.x;
           yv.y += g.y;
+        }
+        } else {
+        // Branch-free: every lane reads the four ghost operands of its cell pair (the slots exist for every lane; what an interior
+        // lane reads is dropped by the select) and the additions -- the same ones in the same order -- are selected per lane.  Written
+        // with `if`, every one of the four became a branch with its own LDS round trip behind it (s_and_saveexec ... ds_read ...
+        // s_waitcnt lgkmcnt(0)), 32 per tile: the epilogue took 5.7 k of a C+D' tile's 26 k cycles (-DEDGE_PHASES)
+        const double gw = gey[2 * i * 4 * GS + 0 * GS], ge = gey[2 * i * 4 * GS + 1 * GS];
+        const double2 gs = *reinterpret_cast<const double2 *>(gx + 2 * GS), gn = *reinterpret_cast<const double2 *>(gx + 3 * GS);
+        const double xw = yv.x + gw;
+        yv.x = px == 0 ? xw : yv.x;        // west of cell c0
+        const double ye = yv.y + ge;
+        yv.y = px == BS - 2 ? ye : yv.y;   // east of cell c0 + 1
+        const double xs = yv.x + gs.x, ys = yv.y + gs.y;
+        yv.x = py == 0 ? xs : yv.x;
+        yv.y = py == 0 ? ys : yv.y;
+        const double xn = yv.x + gn.x, yn = yv.y + gn.y;
+        yv.x = py == BS - 1 ? xn : yv.x;
+        yv.y = py == BS - 1 ? yn : yv.y;
         }
         }
         if (!(KNOCK & 8)) st2<EAB ? (POL2 & 0x20) != 0 : (POL & (CD ? 0x008 : 0x002)) != 0>(reinterpret_cast<double2 *>(A.yout) + (size_t)(b0 + blk) * (BC / 2) + hlo, yv);

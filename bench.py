@@ -47,6 +47,7 @@ CONFIGS3_N = 8192            # BASELINE.json configs[3]: 8192^2 cells, global
 # file that an 8-rank run executes -- both layouts, the JSON merge, the comm block, the watchdog -- runs before the driver's
 # one 8-GPU run does (tests/test_bench_world8.py).  The line it prints says "shared_gpu": true and is not a measurement.
 SHARE_GPU = os.environ.get("CUP2D_BENCH_SHARE_GPU", "0") == "1"
+SETUP_STEPS = 20  # whole steps at the end of the setup of a one-GPU run, in front of the --warmup steps (main())
 MIN_ROOFLINE_LAUNCHES = 100  # a per-kernel roofline is reported from at least this many event-timed launches
 
 
@@ -722,11 +723,18 @@ def main():
     beat("setup")
     sim = run.sim
     fused = args.solver == "fused"
+    # Setup ends with SETUP_STEPS whole steps (reported as config.setup_steps): the first steps of a process run 0.1-0.15 ms slower
+    # than the steady state whatever is timed in them (tools/gpu_calls/gpu_r06_call49.sh: with --warmup 5 the timed region took
+    # 17.725 / 17.848 ms per step and the same steps repeated at once 17.558 / 17.700; with --warmup 25: 17.679 / 17.666 and 17.654 /
+    # 17.614 -- clocks and caches of a fresh process settling), and the metric is the sustained rate of steps back to back.  The W
+    # warm-up steps the caller asks for follow, then exactly K timed steps; nothing is left out of either.
+    for _ in range(SETUP_STEPS if dist is None else 0):
+        run.one_step()
     for _ in range(args.warmup):
         run.one_step()
 
     # Timed region: EXACTLY --steps steps.  Per-kernel HIP-event pairs are recorded on the launch stream
-    # inside it in SAMPLED mode (every 16th BiCGSTAB iteration; the launches outside the solver in every 4th step: an event
+    # inside it in SAMPLED mode (every 32nd BiCGSTAB iteration -- every 16th until the last commits of round 6: 0.15 ms of an 17.9 ms step --; the launches outside the solver in every 4th step: an event
     # pair is a barrier packet that keeps the kernels on either side of it from overlapping, ~12 us per pair -- round 5 measured
     # 18.17 against 17.90 ms per step with twice the samples); the roofline objects are computed from those samples and, where a
     # short --steps leaves fewer than MIN_ROOFLINE_LAUNCHES of them, from more steps sampled the same way outside the timed region.  The same K steps are repeated afterwards without any events and
@@ -754,7 +762,7 @@ def main():
             # (back to back, the timers read once at the end: a call between two steps makes the second one recompute max|u|
             # with a pass over the velocity in front of RK stage 1 -- not what the timed region runs)
             need_adv = max(0, MIN_ROOFLINE_LAUNCHES - acc["advect_stage"][1] - acc["advect_stage2"][1] + 1) // 2
-            need_sw = max(0, MIN_ROOFLINE_LAUNCHES - max(acc["sweep_E"][1], acc["sweep_EA"][1])) // max(1, args.iters // 16) + 1
+            need_sw = max(0, MIN_ROOFLINE_LAUNCHES - max(acc["sweep_E"][1], acc["sweep_EA"][1])) // max(1, (args.iters + 31) // 32) + 1
             extra_sampled_steps = min(64, max(need_adv, need_sw, 1))
             sim.set_timing(3)
             for _ in range(extra_sampled_steps):
@@ -1196,7 +1204,7 @@ def main():
                        "layout": args.layout, "global_cells": cells, "global_grid": "%dx%d" % (nx * px, ny * py),
                        "parallelism": run.par, "math": args.math, "bicgstab_iters_per_step": args.iters,
                        "solver": "fused" if fused else "sweeps", "finish": "kernel" if mk == "true" else "launch",
-                       "comm": comm_info},
+                       "setup_steps": SETUP_STEPS if dist is None else 0, "comm": comm_info},
             "verified": verified, "second_layout": second,
             "roofline": roofline, "roofline_north_star": north, "roofline_all": all_roof, "solver": solver,
             "gpu_ms_per_step": gpu_split, "solve_to_tolerance": tol_leg,

@@ -250,7 +250,7 @@ struct cup2d_ctx {
   bool prof_sample = true; // sampled mode: record the launches issued now
   // sampled mode (cup2d_set_timing 2): an event pair is a barrier packet on the stream -- the kernels on either side of it do
   // not overlap their tail and head (~12 us per pair, 0.3 ms of a 4096^2 step with every launch outside the solver and every
-  // 8th iteration sampled: round 5 measured 18.17 against 17.90 ms).  So: every 16th BiCGSTAB iteration, and the launches
+  // 8th iteration sampled: round 5 measured 18.17 against 17.90 ms).  So: every 32nd BiCGSTAB iteration (16th until round 6), and the launches
   // outside the solver in every 4th cup2d_step (prof_outer says whether this step is one of them)
   int prof_step = 0;
   bool prof_outer = true;

@@ -880,7 +880,7 @@ int solve_impl(cup2d_ctx *c, double max_error, double max_rel_error, int max_res
       CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
       if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
-    c->prof_sample = (k % 16 == 0) && k < max_iter;  // sampled timing (ctx.h prof_outer)
+    c->prof_sample = (k % 32 == 0) && k < max_iter;  // sampled timing (ctx.h prof_outer)
     {
       ProfScope prof(c, CUP2D_T_SWEEP_A);
       if (c->precond == PRECOND_FD)

@@ -1429,7 +1429,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
         CUP2D_HIP_CHECK(hipEventSynchronize(c->solve_ev[slot]));
         if (*(volatile int *)&c->h_status[slot] != 0) break;
       }
-      c->prof_sample = (k % 16 == 0) && k < max_iter;
+      c->prof_sample = (k % 32 == 0) && k < max_iter;
       const int o = k & 1, n = o ^ 1;
       enqueued = k + 1;
       if (overlap) {
@@ -1585,7 +1585,7 @@ int solve_fused_impl(cup2d_ctx *c, double max_error, double max_rel_error, int m
       if (*(volatile int *)&c->h_status[slot] != 0) break;
     }
     int *const report = last_of_group ? &c->h_status[slot] : nullptr;
-    c->prof_sample = (k % 16 == 0) && k < max_iter;
+    c->prof_sample = (k % 32 == 0) && k < max_iter;
     double *p_in = (k & 1) ? c->d_p2 : c->d_p, *p_out = (k & 1) ? c->d_p : c->d_p2;
     double *nu_in = (k & 1) ? c->d_nu2 : c->d_nu, *nu_out = (k & 1) ? c->d_nu : c->d_nu2;
     {

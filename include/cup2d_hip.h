@@ -547,7 +547,7 @@ int cup2d_halo_exchange(cup2d_ctx *ctx, int field, int width);
 
 /* ---------------------------------------------------------------- instrumentation -------- */
 /* HIP-event timing per kernel family, recorded on the context stream around the launches:
- * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every 16th BiCGSTAB iteration, and the launches outside the
+ * cup2d_set_timing(ctx, 1) every launch; (ctx, 2) sampled -- every 32nd BiCGSTAB iteration, and the launches outside the
  * solver in every 4th cup2d_step (an event pair is a barrier packet between two kernels, ~12 us of stream time: every launch
  * timed costs 10 % of a 4096^2 step, sampled < 1 %); (ctx, 3) as 2 with the launches outside the solver sampled in EVERY
  * cup2d_step; (ctx, 0) off.  Operators called on their own between two steps are always sampled.  cup2d_get_timing returns accumulated GPU

@@ -185,7 +185,10 @@ int cup2d_set_solver(cup2d_ctx *ctx, int kind, int finish_in_kernel);
  *                    (112 B/cell/iteration); finish in the kernel, built-in preconditioner, same-level stencil; one GPU, or
  *                    N ranks in the ghost-block form (whole boundary blocks of t, and of r', p'', nu'' in one message of
  *                    192 doubles per strip: cup2d_set_comm_strip_capacity) with two reductions over the ranks per iteration.
- *                    rho = rhat.r comes from the sums of C+D (rhat.s - omega rhat.t) instead of its own pass over r. */
+ *                    rho = rhat.r comes from the sums of C+D (rhat.s - omega rhat.t) instead of its own pass over r.
+ *                    On the hybrid assembled operator of an adapted grid (one rank, finish in the kernel) EAB is available ON
+ *                    REQUEST only -- two sweeps + two rows launches per iteration (k_edge HYB + k_hyb_rows); AUTO keeps FULL
+ *                    there (three sweeps + two rows launches: measured faster on the 63 k-block grid). */
 typedef enum { CUP2D_FORM_AUTO = 0, CUP2D_FORM_FULL = 1, CUP2D_FORM_EDGE = 2, CUP2D_FORM_EAB = 3 } cup2d_fused_form;
 int cup2d_set_solver_form(cup2d_ctx *ctx, int form);
 /* N ranks, two launches per iteration: which organisation of a reduction point the next solves take (every rank must ask for

@@ -1173,6 +1173,36 @@ static int tune_placement(cup2d_ctx *c) {
         cand[b].ms = before;
       }
     }
+    // ... and, in the wide pass, TWO written streams at once from one donor set (where no single exchange helps, the conflict may
+    // need two vectors moved: a box whose slow sets single exchanges did not repair, profiles/r06_placement_repair.txt item 11.
+    // Tried alone on the slowest set of a batch, tools/gpu_calls/gpu_r06_call54.sh: 370.3 -> 335.5 -> 320.8, 368.1 -> 333.7 -> 323.6,
+    // 373.2 -> 356.4 -> 336.3 -> 324.6 us in two or three pair exchanges)
+    if (wide && !fast_seen()) {
+      static const int wr[5] = {1, 2, 4, 6, 9};  // s, p, nu, t, xopt
+      for (int a = 0; a < 5 && !fast_seen(); a++)
+        for (int e = a + 1; e < 5 && !fast_seen(); e++) {
+          int tried = 0;
+          for (int j = 1; j < made && tried < 4; j++) {
+            const int q = (b + j + a + 2 * e) % made;
+            if (q == b || cand[q].arena || cand[q].pad != -1) continue;
+            tried++;
+            const float before = cand[b].ms;
+            std::swap(cand[b].v[wr[a]], cand[q].v[wr[a]]);
+            std::swap(cand[b].v[wr[e]], cand[q].v[wr[e]]);
+            CUP2D_TRY(probe(cand[b]));
+            if (cand[b].ms < 0.98f * before) {
+              char buf2[80];
+              snprintf(buf2, sizeof buf2, " slots %d + %d from set %d: %.1f -> %.1f;", wr[a], wr[e], q, 1e3 * before, 1e3 * cand[b].ms);
+              repair_log += buf2;
+              lo_ms = cand[b].ms < lo_ms ? cand[b].ms : lo_ms;
+              break;
+            }
+            std::swap(cand[b].v[wr[a]], cand[q].v[wr[a]]);
+            std::swap(cand[b].v[wr[e]], cand[q].v[wr[e]]);
+            cand[b].ms = before;
+          }
+        }
+    }
     char buf[64];
     snprintf(buf, sizeof buf, " (set %d, %d probes%s)", b, probes - p0, wide ? ", wide" : "");
     repair_log += buf;

@@ -1041,7 +1041,7 @@ static int fused_sweep(cup2d_ctx *c, const FusedArgs &a, int merge, int dbg, int
 // buffers --: no reduction finish, nothing of the context's state touched), (3) REPAIRS the fastest: slot by slot, written
 // streams first, its vector is exchanged with the same slot's of up to four other sets and the exchange kept where it gains
 // 1.5 % (and, if that made no fast set, once more with every other set as a donor and 1 % as the bar), (4) if fastest and slowest then
-// still lie less than 12.5 % apart (no fast set seen or made) goes on with more sets, up
+// the fastest still lies less than 10.5 % below the median (no fast set seen or made) goes on with more sets, up
 // to six times as many (three on N ranks) within CUP2D_PLACEMENT_MAX_GB (64 GB on one rank, 40 GB on N) and a quarter of the
 // free memory, and repairs once more, (5) keeps the fastest set and gives the others back.  5 ms per set, 2 ms per exchange
 // tried: 0.1 s, once per context.  CUP2D_PLACEMENT_ARENA="pad,pad,..." adds arenas (one allocation carved at 2^27 + pad) as
@@ -1129,9 +1129,16 @@ static int tune_placement(cup2d_ctx *c) {
   rc = probe(cand[0]);
   float lo_ms = cand[0].ms, hi_ms = cand[0].ms;
   const float first_ms = cand[0].ms;
-  // "a fast and a slow set have shown": fastest and slowest 12.5 % apart.  (9.5 % let a middle set through next to a slow one of the
-  // upper end -- 337 kept beside 372, tools/gpu_calls/gpu_r06_call44.sh --: the modes are ranges, 321-330 | 337-347 | 357-376)
-  const auto fast_seen = [&]() { return hi_ms - lo_ms > 0.125f * lo_ms; };
+  // "a fast set has shown": the fastest 10.5 % below the median.  (Fastest against slowest let middle sets through beside a slow one of
+  // the upper end -- 337 kept beside 372, tools/gpu_calls/gpu_r06_call44.sh --: the modes are ranges, 321-330 | 337-347 | 357-381)
+  // ... measured against the MEDIAN of the complete sets as the allocator handed them out, which is a slow one on every box seen
+  // (the slowest varies, 365-381: against it 333 passed beside 381 on a box where fast sets are rare, gpu_r06_call57.sh)
+  std::vector<float> natural(1, cand[0].ms);
+  const auto fast_seen = [&]() {
+    std::vector<float> v(natural);
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    return v.size() >= 3 && lo_ms < 0.895f * v[v.size() / 2] && hi_ms - lo_ms > 0.095f * lo_ms;
+  };
   std::string repair_log;
   // step (3) over the sets [0, made): separate allocations only (an arena's vectors are not its own to give away)
   int repaired_at = 0;  // the number of sets the last repair looked at
@@ -1238,6 +1245,7 @@ static int tune_placement(cup2d_ctx *c) {
     }
     rc = probe(cand[q]);
     if (rc == CUP2D_OK) {
+      natural.push_back(cand[q].ms);
       lo_ms = cand[q].ms < lo_ms ? cand[q].ms : lo_ms;
       hi_ms = cand[q].ms > hi_ms ? cand[q].ms : hi_ms;
     }

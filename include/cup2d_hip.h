@@ -214,7 +214,7 @@ int cup2d_get_last_solver(cup2d_ctx *ctx, int *kind);
 int cup2d_get_last_solver_form(cup2d_ctx *ctx, int *form, int *merge, int *handover);
 /* The placement search of the solver's vectors (krylov_fused.hip tune_placement: the durations of the two launches of an
  * iteration come in two modes that follow where the eleven vectors they stream lie in device memory; the first two-launch solve
- * of a context on a grid of 2048^2 cells and more tries CUP2D_PLACEMENT_TRIES = 8 complete sets -- up to three times as many until a fast and a slow set have both shown (12.5 % apart) -- and keeps the fastest).
+ * of a context on a grid of 2048^2 cells and more tries CUP2D_PLACEMENT_TRIES = 8 complete sets -- up to three times as many until a fast one has shown or been made (10.5 % below the median) -- and keeps the fastest).
  * candidates = sets timed (0: no search ran), the microseconds per iteration of the kept set, of the slowest set seen and of
  * the set the context was created with.  Diagnostic (bench.py "placement"). */
 int cup2d_get_placement(cup2d_ctx *ctx, int *candidates, double *kept_us, double *slowest_us, double *first_us);
